@@ -1,0 +1,482 @@
+"""CPU oracle for the formation_gym hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (NumPy, float64 by default) of the reference's
+algorithm for `MultiAgentEnv.step` -> `World.step` -> `Scenario.observation /
+reward`.  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
+leg may import it; the product path (gym-formation_amd/) never does and fails
+loudly when the HIP library is missing.
+
+Parity pin: every function below is checked in tests/test_oracle_golden.py
+against fixtures captured from the REAL reference (tests/golden/*.npz, made by
+tests/golden/make_golden.py in the build container) to <= 1e-12, plus scipy's
+published `directed_hausdorff` docstring example.  The reference itself has no
+tests or golden vectors for this path.
+
+Third-party arithmetic on the path: scipy.spatial.distance.directed_hausdorff
+(unpinned by the reference's setup.py; scipy 1.15.3 in this image).  Its
+published semantics - exact max-min Euclidean distance - are restated in
+`directed_hausdorff_bruteforce`.
+
+Reference citations are `path:line` under /root/reference/formation_gym/.
+
+Two restatements live here:
+  * `PortEnv`   - one env, object-per-agent, Python loops over pairs, reward
+                  evaluated 2N times with a Hausdorff max-min each; the same
+                  algorithmic structure as the reference.  This is the
+                  `cpu_baseline` ("port") that bench.py times.
+  * `step_hd` / `step_basic` - batched [B, N] vectorised NumPy; the checker the
+                  GPU parity tests compare against.
+"""
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# constants in force at the BASELINE configs
+# --------------------------------------------------------------------------
+
+
+class HdParams(object):
+    """formation_hd_env constants.  core.py:119-139, formation_hd_env.py:13-33,
+    environment.py:218-221."""
+    dt = 0.1                 # core.py:125
+    damping = 0.25           # core.py:127
+    contact_force = 1e2      # core.py:129
+    contact_margin = 1e-3    # core.py:130
+    sensitivity = 5.0        # environment.py:218 (accel is None)
+    mass = 1.0               # core.py:69,73-75
+    agent_size = 0.03        # formation_hd_env.py:26
+    world_length = 100       # formation_hd_env.py:13,16
+
+    @property
+    def dist_min(self):      # core.py:307  size_a + size_b
+        return self.agent_size + self.agent_size
+
+    @property
+    def collide_thresh(self):  # formation_hd_env.py:121  (size_a + size_b)/2
+        return (self.agent_size + self.agent_size) / 2
+
+
+class BasicParams(HdParams):
+    """basic_formation_env constants.  basic_formation_env.py:7-27,
+    core.py:52,113."""
+    agent_size = 0.1         # basic_formation_env.py:18
+    landmark_size = 0.05     # core.py:52 default
+    world_length = 50        # core.py:113 default
+    num_landmarks = 3        # basic_formation_env.py:7
+
+    @property
+    def collide_thresh(self):  # basic_formation_env.py:91  size_a + size_b
+        return self.agent_size + self.agent_size
+
+
+# --------------------------------------------------------------------------
+# shared scalar pieces
+# --------------------------------------------------------------------------
+
+def softplus_penetration(dist, dist_min, k):
+    """core.py:309-310: k * logaddexp(0, -(dist - dist_min)/k), stable form."""
+    x = -(dist - dist_min) / k
+    return k * (np.maximum(x, 0.0) + np.log1p(np.exp(-np.abs(x))))
+
+
+def directed_hausdorff_bruteforce(u, v):
+    """max_i min_j ||u_i - v_j|| with witness indices (i*, argmin_j D[i*]).
+    Restates scipy.spatial.distance.directed_hausdorff's published semantics
+    (call sites formation_hd_env.py:66); ties resolve to the first index."""
+    u = np.asarray(u, dtype=np.float64)
+    v = np.asarray(v, dtype=np.float64)
+    D = np.sqrt(((u[:, None, :] - v[None, :, :]) ** 2).sum(-1))
+    rowmin = D.min(1)
+    i = int(np.argmax(rowmin))
+    j = int(np.argmin(D[i]))
+    return float(rowmin[i]), i, j
+
+
+def reset_draws(seed, N, num_landmarks=None):
+    """The reference's reset RNG stream (environment.py:106-110 seeds the global
+    legacy MT19937; formation_hd_env.py:77-95 draws N agent positions, N landmark
+    positions, one ideal velocity, 2 doubles each, in that order).
+    Returns (pos[N,2], raw_landmarks[L,2], ideal_vel[2])."""
+    L = N if num_landmarks is None else num_landmarks
+    rs = np.random.RandomState(seed)
+    pos = rs.uniform(-1, +1, (N, 2))
+    raw = rs.uniform(-1, +1, (L, 2))
+    ivel = rs.uniform(-1, +1, 2)
+    return pos, raw, ivel
+
+
+def reset_hd(seeds, N):
+    """Batched formation_hd_env reset (formation_hd_env.py:77-95): one legacy
+    RandomState per env.  Returns dict of float64 arrays."""
+    B = len(seeds)
+    pos = np.zeros((B, N, 2)); shape = np.zeros((B, N, 2)); ivel = np.zeros((B, 2))
+    for b, s in enumerate(seeds):
+        p, raw, iv = reset_draws(int(s), N)
+        pos[b] = p
+        shape[b] = raw - raw.mean(0)           # formation_hd_env.py:93
+        ivel[b] = iv
+    return dict(pos=pos, vel=np.zeros((B, N, 2)), ideal_shape=shape, ideal_vel=ivel,
+                step=np.zeros(B, dtype=np.int32))
+
+
+def reset_basic(seed, N, L=3):
+    """basic_formation_env.py:54-65: agents then landmarks, no ideal velocity."""
+    rs = np.random.RandomState(seed)
+    pos = rs.uniform(-1, +1, (N, 2))
+    lm = rs.uniform(-1, +1, (L, 2))
+    return dict(pos=pos[None], vel=np.zeros((1, N, 2)), landmarks=lm[None],
+                step=np.zeros(1, dtype=np.int32))
+
+
+# --------------------------------------------------------------------------
+# batched vectorised oracle
+# --------------------------------------------------------------------------
+
+def physics_step(pos, vel, act, P, dtype=np.float64):
+    """World.step for agent-only colliders (core.py:206-322 with the early-outs
+    of :292-297 applied: landmarks have collide=False, so only agent-agent
+    pairs survive).  pos, vel, act: [B,N,2].  Returns new (pos, vel).
+
+    environment.py:216-221  u = sensitivity * action (no clipping)
+    core.py:235-236         F_i = mass * u_i   (accel None, no noise)
+    core.py:304-318         pair force on PRE-step positions, ratio m_b/m_a = 1
+    core.py:268-277         v = v*(1-damping) + F/m*dt ; p += v*dt
+    """
+    pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
+    act = np.asarray(act, dtype=dtype)
+    B, N, _ = pos.shape
+    F = dtype(P.mass) * (dtype(P.sensitivity) * act)
+    delta = pos[:, :, None, :] - pos[:, None, :, :]            # [B,i,j,2] = p_i - p_j
+    dist = np.sqrt((delta ** 2).sum(-1))                       # [B,i,j]
+    pen = softplus_penetration(dist, dtype(P.dist_min), dtype(P.contact_margin))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f = dtype(P.contact_force) * delta / dist[..., None] * pen[..., None]
+    eye = np.eye(N, dtype=bool)[None, :, :, None]
+    f = np.where(eye, dtype(0), f)                             # core.py:296 same entity
+    F = F + f.sum(2)
+    vel = vel * dtype(1 - P.damping) + (F / dtype(P.mass)) * dtype(P.dt)
+    pos = pos + vel * dtype(P.dt)
+    return pos, vel
+
+
+def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64):
+    """formation_hd_env.py:52-59 for every agent: [v_i | p_j - p_i (j != i, index
+    order) | zeros 2(N-1) | ideal_shape.flatten() | ideal_vel] -> [B,N,6N]."""
+    pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
+    B, N, _ = pos.shape
+    obs = np.zeros((B, N, 6 * N), dtype=dtype)
+    obs[:, :, 0:2] = vel
+    rel = pos[:, None, :, :] - pos[:, :, None, :]              # [B,i,j,2] = p_j - p_i
+    keep = ~np.eye(N, dtype=bool)
+    obs[:, :, 2:2 * N] = rel[:, keep].reshape(B, N, 2 * (N - 1))
+    obs[:, :, 4 * N - 2:6 * N - 2] = np.asarray(ideal_shape, dtype=dtype).reshape(B, 1, 2 * N)
+    obs[:, :, 6 * N - 2:] = np.asarray(ideal_vel, dtype=dtype)[:, None, :]
+    return obs
+
+
+def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64):
+    """formation_hd_env.py:61-75 for every agent + the integer by-products.
+    Returns dict(indiv[B,N], shared[B], hd[B,2], hd_idx[B,4], near_lm[B,N],
+    near_ag[B,N], cnt[B,N], gap_lm, gap_ag, cnt_margin)."""
+    pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
+    S = np.asarray(ideal_shape, dtype=dtype); iv = np.asarray(ideal_vel, dtype=dtype)
+    B, N, _ = pos.shape
+    pt = pos - pos.mean(1, keepdims=True)                      # :65
+    D = np.sqrt(((pt[:, :, None, :] - S[:, None, :, :]) ** 2).sum(-1))   # [B,i(agent),j(shape)]
+    rowmin = D.min(2); colmin = D.min(1)
+    h1 = rowmin.max(1); h2 = colmin.max(1)
+    H = np.maximum(h1, h2)                                     # :66
+    velterm = np.sqrt(((iv - vel.mean(1)) ** 2).sum(-1))       # :68-69
+    PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
+    thr = dtype(P.collide_thresh)
+    close = PD < thr                                           # :121 strict <
+    close[:, np.arange(N), np.arange(N)] = False               # :73 agent != a
+    cnt = close.sum(2)
+    indiv = -H[:, None] - velterm[:, None] - cnt               # :66,:69,:74
+    shared = indiv.sum(1)                                      # environment.py:136
+    near_lm = D.argmin(2); near_ag = D.argmin(1)
+    i1 = rowmin.argmax(1); j1 = near_lm[np.arange(B), i1]
+    i2 = colmin.argmax(1); j2 = near_ag[np.arange(B), i2]      # (shape idx, agent idx)
+    Ds = np.sort(D, axis=2); Ds0 = np.sort(D, axis=1)
+    off = np.abs(PD - thr) + np.eye(N)[None]
+    return dict(indiv=indiv, shared=shared, hd=np.stack([h1, h2], 1),
+                hd_idx=np.stack([i1, j1, i2, j2], 1).astype(np.int32),
+                near_lm=near_lm.astype(np.int32), near_ag=near_ag.astype(np.int32),
+                cnt=cnt.astype(np.int32), gap_lm=Ds[:, :, 1] - Ds[:, :, 0],
+                gap_ag=Ds0[:, 1, :] - Ds0[:, 0, :], cnt_margin=off.reshape(B, -1).min(1),
+                velterm=velterm, H=H)
+
+
+def step_hd(state, act, P=None, dtype=np.float64):
+    """One MultiAgentEnv.step of formation_hd_env for B envs (environment.py:
+    113-142).  `state` = dict(pos, vel, ideal_shape, ideal_vel, step); returns
+    (new_state, out) with out = dict(obs, reward[B,N,1], done[B,N], indiv, ...)."""
+    P = P or HdParams()
+    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype)
+    step = np.asarray(state["step"]) + 1                       # environment.py:114
+    out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype)
+    out["obs"] = observation_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], dtype)
+    N = pos.shape[1]
+    out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]    # :136-138
+    out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)      # :172-178
+    new_state = dict(state, pos=pos, vel=vel, step=step.astype(np.int32))
+    return new_state, out
+
+
+def observation_basic(pos, vel, landmarks, dtype=np.float64):
+    """basic_formation_env.py:29-41: [v_i | p_i | l_k - p_i | p_j - p_i (j != i) |
+    zeros 2(N-1)] -> [B,N,4+2L+4(N-1)]."""
+    pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
+    lm = np.asarray(landmarks, dtype=dtype)
+    B, N, _ = pos.shape; L = lm.shape[1]
+    dim = 4 + 2 * L + 4 * (N - 1)
+    obs = np.zeros((B, N, dim), dtype=dtype)
+    obs[:, :, 0:2] = vel
+    obs[:, :, 2:4] = pos
+    obs[:, :, 4:4 + 2 * L] = (lm[:, None, :, :] - pos[:, :, None, :]).reshape(B, N, 2 * L)
+    rel = pos[:, None, :, :] - pos[:, :, None, :]
+    keep = ~np.eye(N, dtype=bool)
+    obs[:, :, 4 + 2 * L:4 + 2 * L + 2 * (N - 1)] = rel[:, keep].reshape(B, N, 2 * (N - 1))
+    return obs
+
+
+def reward_basic(pos, landmarks, P, dtype=np.float64):
+    """basic_formation_env.py:43-52: -sum_l min_a ||p_a - l|| - #{a (self
+    included): ||p_a - p_i|| < size_a + size_i}."""
+    pos = np.asarray(pos, dtype=dtype); lm = np.asarray(landmarks, dtype=dtype)
+    B, N, _ = pos.shape
+    D = np.sqrt(((pos[:, :, None, :] - lm[:, None, :, :]) ** 2).sum(-1))   # [B,a,l]
+    cover = D.min(1).sum(1)
+    PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
+    cnt = (PD < dtype(P.collide_thresh)).sum(2)                # includes self
+    indiv = -cover[:, None] - cnt
+    return dict(indiv=indiv, shared=indiv.sum(1), cnt=cnt.astype(np.int32),
+                near_ag=D.argmin(1).astype(np.int32))
+
+
+def step_basic(state, act, P=None, dtype=np.float64):
+    P = P or BasicParams()
+    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype)
+    step = np.asarray(state["step"]) + 1
+    out = reward_basic(pos, state["landmarks"], P, dtype)
+    out["obs"] = observation_basic(pos, vel, state["landmarks"], dtype)
+    N = pos.shape[1]
+    out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]
+    out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)
+    return dict(state, pos=pos, vel=vel, step=step.astype(np.int32)), out
+
+
+def generate_shape(layer):
+    """formation_hd_env.py:123-139 default hierarchical shape, returned [3^(layer+1), 2]."""
+    table = np.array([
+        [[0, -1], [0.5, 0], [0, 1]],
+        [[0, 1.6], [-1, 0], [1, 0]],
+        [[1.5, 0], [0, 0], [-1.5, 0]],
+        [[0, 0.6], [1, 0], [-1, 0]],
+    ], dtype=np.float64)
+    assert layer < table.shape[0], "Layer shape is not enough!"
+    pts = table[0]
+    for l in range(1, layer + 1):
+        pts = np.concatenate([table[l][i] + 0.45 * pts for i in range(3)], 0)
+    return pts
+
+
+# --------------------------------------------------------------------------
+# demo policies (reference __init__.py:19-99), "next" row f2
+# --------------------------------------------------------------------------
+
+def ezpolicy(obs):
+    """__init__.py:19-47 hand-written formation controller on one observation."""
+    obs = np.asarray(obs, dtype=np.float64)
+    n = len(obs) / 6
+    assert float(n).is_integer(), n
+    n = int(n)
+    others = obs[2:2 * n]
+    ideal = obs[4 * n - 2:6 * n - 2].reshape(-1, 2)
+    ideal = ideal - ideal.mean(0)
+    ivel = obs[-2:]
+    cur = np.append(others, [0.0, 0.0]).reshape(-1, 2)
+    cur = cur - cur.mean(0)
+    me = cur[-1]
+    order = np.argsort(np.sqrt(((me - ideal) ** 2).sum(1)), kind="quicksort")
+    act = None
+    for idx in order:
+        closest = int(np.argmin(np.sqrt(((cur - ideal[idx]) ** 2).sum(1))))
+        if closest == n - 1 or idx == order[-1]:
+            act = np.clip(0.5 * (ideal[idx] - me), -1, 1)
+            break
+    done = np.linalg.norm(ideal - cur) < 0.01
+    return act + (ivel if done else 0.3 * ivel)
+
+
+def get_action_bfs(policy, obs, per_layer):
+    """__init__.py:49-99 breadth-first hierarchical expansion of `policy`."""
+    layers = np.log(len(obs)) / np.log(per_layer)
+    assert float(layers).is_integer(), "Observation shape error!"
+    queue = [[np.asarray(o, dtype=np.float64) for o in obs]]
+    acts = []
+    while queue:
+        group = queue.pop(0)
+        n_cur = len(group)
+        n_sub = n_cur // per_layer
+        level = np.log(n_cur) / np.log(per_layer)
+        for i in range(per_layer):
+            lead = group[i * n_sub]
+            rel = np.insert(lead[2:2 * n_cur], 2 * i * n_sub, [0.0, 0.0]).reshape(-1, 2)
+            cent = np.array([rel[n_sub * k:n_sub * (k + 1)].mean(0) for k in range(per_layer)])
+            cent = np.delete(cent - cent[i], i, 0).ravel()
+            ideal = lead[4 * n_cur - 2:6 * n_cur - 2].reshape(-1, 2)
+            tgt = np.array([ideal[n_sub * k:n_sub * (k + 1)].mean(0) for k in range(per_layer)]).ravel()
+            inp = np.concatenate((lead[:2], cent, np.zeros(2 * (per_layer - 1)), tgt, lead[-2:]))
+            sub_vel = policy(inp) * level
+            if n_sub == 1:
+                acts.append(sub_vel)
+                continue
+            nxt = []
+            for j in range(i * n_sub, (i + 1) * n_sub):
+                o = group[j]
+                oth = o[2:2 * n_cur][2 * i * n_sub:2 * (i + 1) * n_sub - 2]
+                shp = o[4 * n_cur - 2:6 * n_cur - 2][2 * i * n_sub:2 * (i + 1) * n_sub]
+                nxt.append(np.concatenate((o[:2], oth, np.zeros(2 * (n_sub - 1)), shp, sub_vel)))
+            queue.append(nxt)
+    return acts
+
+
+# --------------------------------------------------------------------------
+# faithful per-env port: the `cpu_baseline` ("port")
+# --------------------------------------------------------------------------
+
+class _Body(object):
+    __slots__ = ("pos", "vel", "c", "u", "size", "mass", "movable", "collide")
+
+    def __init__(self, size, movable, collide):
+        self.pos = np.zeros(2); self.vel = np.zeros(2); self.c = np.zeros(2)
+        self.u = np.zeros(2)
+        self.size = size; self.mass = 1.0; self.movable = movable; self.collide = collide
+
+
+class PortEnv(object):
+    """One formation_hd_env instance with the reference's algorithmic structure:
+    a Python object per agent/landmark, a Python loop over all entity pairs
+    (core.py:240-262), and the reward callback evaluated twice per agent per
+    step (environment.py:128,130), each evaluation doing two directed Hausdorff
+    passes (formation_hd_env.py:66).  Used only as the timed CPU baseline and as
+    an independent cross-check of the vectorised oracle."""
+
+    def __init__(self, num_agents=3, P=None, use_scipy=True):
+        self.P = P or HdParams()
+        self.N = num_agents
+        self.agents = [_Body(self.P.agent_size, True, True) for _ in range(num_agents)]
+        self.landmarks = [_Body(0.01, False, False) for _ in range(num_agents)]
+        self.t = 0
+        self.ideal_shape = np.zeros((num_agents, 2)); self.ideal_vel = np.zeros(2)
+        self._hd = None
+        if use_scipy:
+            try:
+                from scipy.spatial.distance import directed_hausdorff
+                self._hd = lambda a, b: directed_hausdorff(a, b)[0]
+            except Exception:
+                self._hd = None
+        if self._hd is None:
+            self._hd = lambda a, b: directed_hausdorff_bruteforce(a, b)[0]
+        self._rs = np.random.RandomState(1)
+
+    def seed(self, seed=None):                                  # environment.py:106-110
+        self._rs = np.random.RandomState(1 if seed is None else seed)
+
+    def reset(self):                                            # environment.py:144-156
+        self.t = 0
+        for a in self.agents:
+            a.pos = self._rs.uniform(-1, +1, 2); a.vel = np.zeros(2); a.c = np.zeros(2)
+        raw = []
+        for l in self.landmarks:
+            p = self._rs.uniform(-1, +1, 2)
+            raw.append(p); l.pos = p
+        self.ideal_shape = np.array(raw) - np.mean(raw, 0)
+        self.ideal_vel = self._rs.uniform(-1, +1, 2)
+        return [self._obs(a) for a in self.agents]
+
+    def load(self, pos, vel, ideal_shape, ideal_vel, t=0):
+        for i, a in enumerate(self.agents):
+            a.pos = np.array(pos[i], dtype=np.float64); a.vel = np.array(vel[i], dtype=np.float64)
+        self.ideal_shape = np.array(ideal_shape, dtype=np.float64)
+        self.ideal_vel = np.array(ideal_vel, dtype=np.float64)
+        self.t = t
+
+    # -- World.step ----------------------------------------------------
+    def _pair_force(self, a, b):                                # core.py:289-322
+        if (not a.collide) or (not b.collide):
+            return None, None
+        if (not a.movable) and (not b.movable):
+            return None, None
+        if a is b:
+            return None, None
+        d = a.pos - b.pos
+        dist = math.sqrt(d[0] * d[0] + d[1] * d[1])
+        k = self.P.contact_margin
+        pen = np.logaddexp(0, -(dist - (a.size + b.size)) / k) * k
+        f = self.P.contact_force * d / dist * pen
+        r = b.mass / a.mass
+        return r * f, -(1 / r) * f
+
+    def _world_step(self):
+        ents = self.agents + self.landmarks
+        force = [None] * len(ents)
+        for i, a in enumerate(self.agents):                     # core.py:228-237
+            force[i] = a.mass * a.u
+        for ia in range(len(ents)):                             # core.py:240-262
+            for ib in range(ia + 1, len(ents)):
+                fa, fb = self._pair_force(ents[ia], ents[ib])
+                if fa is not None:
+                    force[ia] = fa + (0.0 if force[ia] is None else force[ia])
+                if fb is not None:
+                    force[ib] = fb + (0.0 if force[ib] is None else force[ib])
+        for i, e in enumerate(ents):                            # core.py:264-277
+            if not e.movable:
+                continue
+            e.vel = e.vel * (1 - self.P.damping)
+            if force[i] is not None:
+                e.vel = e.vel + (force[i] / e.mass) * self.P.dt
+            e.pos = e.pos + e.vel * self.P.dt
+        for a in self.agents:                                   # core.py:279-282
+            a.c = np.zeros(2)
+
+    # -- scenario callbacks ---------------------------------------------
+    def _obs(self, me):                                         # formation_hd_env.py:38-59
+        cen = np.mean([a.pos for a in self.agents], 0) - np.mean([l.pos for l in self.landmarks], 0)
+        for l in self.landmarks:
+            l.pos = l.pos + cen
+        rel = np.array([]); comm = np.array([])
+        for o in self.agents:
+            if o is me:
+                continue
+            comm = np.append(comm, o.c)
+            rel = np.append(rel, o.pos - me.pos)
+        return np.concatenate((me.vel, rel, comm, self.ideal_shape.flatten(), self.ideal_vel))
+
+    def _reward(self, me):                                      # formation_hd_env.py:61-75
+        shp = np.array([a.pos for a in self.agents])
+        shp = shp - np.mean(shp, 0)
+        r = -max(self._hd(shp, self.ideal_shape), self._hd(self.ideal_shape, shp))
+        mv = np.mean([a.vel for a in self.agents], axis=0)
+        r -= np.linalg.norm(self.ideal_vel - mv)
+        for a in self.agents:
+            if a is not me and np.linalg.norm(a.pos - me.pos) < (a.size + me.size) / 2:
+                r -= 1
+        return r
+
+    def step(self, action_n):                                   # environment.py:113-142
+        self.t += 1
+        for a, u in zip(self.agents, action_n):
+            a.u = np.asarray(u, dtype=np.float64) * self.P.sensitivity
+        self._world_step()
+        obs_n, rew_n, done_n, info_n = [], [], [], []
+        for a in self.agents:
+            obs_n.append(self._obs(a))
+            rew_n.append([self._reward(a)])
+            done_n.append(self.t >= self.P.world_length)
+            info_n.append({"individual_reward": self._reward(a)})
+        total = np.sum(rew_n)
+        rew_n = [[total]] * self.N
+        return obs_n, rew_n, done_n, info_n

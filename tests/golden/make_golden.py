@@ -1,0 +1,300 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  It imports jc-bao/gym-formation's `formation_gym` package
+unmodified, drives seeded rollouts through the reference's own
+`make_env / env.seed / env.reset / env.step`, and stores inputs + expected
+outputs as small .npz files.  Only DATA is stored: no reference source text.
+
+Two import shims are created in a temporary directory at run time (they are not
+part of the product and do not touch any arithmetic on the hot path):
+  * `gym`   - the reference's environment.py:1-3 imports gym only for the Space
+              types (Box/Discrete/Tuple) and EnvSpec; gym is not installed here.
+  * `multiagent.{core,scenario}` - basic_formation_env.py:3-4 imports OpenAI
+              MPE, which the reference does not vendor; aliased to the
+              reference's own formation_gym.core / formation_gym.scenario
+              (the only World class that has `world_length`, which
+              environment.py:22 reads).
+
+Usage:  python tests/golden/make_golden.py        (rewrites tests/golden/*.npz)
+"""
+import os
+import sys
+import tempfile
+import textwrap
+import warnings
+
+import numpy as np
+
+REF = os.environ.get("FG_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+GYM_SHIM = textwrap.dedent('''
+    import numpy as np
+    class Env(object):
+        pass
+    class Space(object):
+        pass
+    class _Box(Space):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.shape = tuple(shape) if shape is not None else np.shape(low)
+            self.dtype = np.dtype(dtype)
+            self.low = np.full(self.shape, low, dtype=self.dtype)
+            self.high = np.full(self.shape, high, dtype=self.dtype)
+        def sample(self):
+            return np.random.uniform(self.low, self.high, self.shape).astype(self.dtype)
+    class _Discrete(Space):
+        def __init__(self, n):
+            self.n = n
+            self.shape = ()
+    class _Tuple(Space):
+        def __init__(self, spaces):
+            self.spaces = tuple(spaces)
+''')
+
+
+def _install_shims(tmp):
+    os.makedirs(os.path.join(tmp, "gym", "envs"))
+    with open(os.path.join(tmp, "gym", "__init__.py"), "w") as f:
+        f.write(GYM_SHIM + "\nfrom . import spaces\n")
+    with open(os.path.join(tmp, "gym", "spaces.py"), "w") as f:
+        f.write("from . import _Box as Box, _Discrete as Discrete, _Tuple as Tuple, Space\n")
+    with open(os.path.join(tmp, "gym", "envs", "__init__.py"), "w") as f:
+        f.write("")
+    with open(os.path.join(tmp, "gym", "envs", "registration.py"), "w") as f:
+        f.write("class EnvSpec(object):\n    pass\n")
+    sys.path.insert(0, tmp)
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+
+
+def _import_reference():
+    warnings.simplefilter("ignore")
+    import formation_gym  # the reference package
+    import formation_gym.core as rcore
+    import formation_gym.scenario as rscen
+    import types
+    ma = types.ModuleType("multiagent")
+    sys.modules["multiagent"] = ma
+    sys.modules["multiagent.core"] = rcore
+    sys.modules["multiagent.scenario"] = rscen
+    return formation_gym
+
+
+def _scenario_of(env):
+    # the Scenario instance is reachable through the bound callbacks
+    return env.reset_callback.__self__
+
+
+def _state(env):
+    pos = np.array([a.state.p_pos for a in env.world.agents], dtype=np.float64)
+    vel = np.array([a.state.p_vel for a in env.world.agents], dtype=np.float64)
+    return pos, vel
+
+
+def _hd_extras(pos, shape, thresh):
+    """Derived integer quantities of the reward (reference call site
+    formation_hd_env.py:61-75): scipy witness indices, inner argmins, counts."""
+    from scipy.spatial.distance import directed_hausdorff
+    pt = pos - np.mean(pos, 0)
+    d1, i1, j1 = directed_hausdorff(pt, shape)
+    d2, i2, j2 = directed_hausdorff(shape, pt)
+    D = np.linalg.norm(pt[:, None, :] - shape[None, :, :], axis=2)
+    near_lm = np.argmin(D, axis=1)       # per agent: nearest ideal point
+    near_ag = np.argmin(D, axis=0)       # per ideal point: nearest agent
+    PD = np.linalg.norm(pos[:, None, :] - pos[None, :, :], axis=2)
+    cnt = (PD < thresh).sum(1) - 1       # j != i (PD[i,i] = 0 < thresh)
+    # top-2 gap of each argmin (to let fp32 tests excuse genuine near-ties)
+    Ds = np.sort(D, axis=1)
+    gap_lm = Ds[:, 1] - Ds[:, 0]
+    Ds0 = np.sort(D, axis=0)
+    gap_ag = Ds0[1, :] - Ds0[0, :]
+    # smallest |dist - thresh| over pairs (near-tie excuse for counts)
+    off = np.abs(PD - thresh) + np.eye(len(pos))
+    return dict(hd=np.array([d1, d2]), hd_idx=np.array([i1, j1, i2, j2], dtype=np.int32),
+                near_lm=near_lm.astype(np.int32), near_ag=near_ag.astype(np.int32),
+                cnt=cnt.astype(np.int32), gap_lm=gap_lm, gap_ag=gap_ag,
+                cnt_margin=np.array(off.min()))
+
+
+def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None):
+    """Seeded rollout of formation_hd_env through the reference API."""
+    obs_at = set(obs_at or [1, T])
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
+    out = {k: [] for k in ("pos", "vel", "indiv", "shared", "done", "hd", "hd_idx",
+                           "near_lm", "near_ag", "cnt", "gap_lm", "gap_ag", "cnt_margin")}
+    obs_store = {t: [] for t in sorted(obs_at)}
+    pos0, vel0, shp, ivel, obs0 = [], [], [], [], []
+    for b in range(B):
+        env = fg.make_env("formation_hd_env", False, N)
+        env.seed(seed + 1000 * b)
+        o0 = env.reset()
+        sc = _scenario_of(env)
+        if crowd is not None:
+            for a in env.world.agents:
+                a.state.p_pos = a.state.p_pos * crowd
+            o0 = [env._get_obs(a) for a in env.agents]
+        p, v = _state(env)
+        pos0.append(p); vel0.append(v)
+        shp.append(np.array(sc.ideal_shape, dtype=np.float64))
+        ivel.append(np.array(sc.ideal_vel, dtype=np.float64))
+        obs0.append(np.array(o0, dtype=np.float64))
+        thresh = (env.world.agents[0].size + env.world.agents[1].size) / 2
+        rec = {k: [] for k in out}
+        for t in range(T):
+            act_n = [acts[t, b, i].astype(np.float64).copy() for i in range(N)]
+            obs_n, rew_n, done_n, info_n = env.step(act_n)
+            p, v = _state(env)
+            rec["pos"].append(p); rec["vel"].append(v)
+            rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
+            rec["shared"].append(np.array([r[0] for r in rew_n]))
+            rec["done"].append(np.array(done_n, dtype=np.bool_))
+            ex = _hd_extras(p, np.array(sc.ideal_shape), thresh)
+            for k, val in ex.items():
+                rec[k].append(val)
+            if (t + 1) in obs_at:
+                obs_store[t + 1].append(np.array(obs_n, dtype=np.float64))
+        for k in out:
+            out[k].append(np.array(rec[k]))
+    res = {k: np.stack(v, axis=1) for k, v in out.items()}   # [T,B,...]
+    res.update(acts=acts, pos0=np.array(pos0), vel0=np.array(vel0),
+               ideal_shape=np.array(shp), ideal_vel=np.array(ivel), obs0=np.array(obs0),
+               seed=np.array(seed), act_seed=np.array(act_seed),
+               crowd=np.array(-1.0 if crowd is None else crowd),
+               obs_steps=np.array(sorted(obs_at), dtype=np.int32))
+    for t, lst in obs_store.items():
+        res["obs_t%d" % t] = np.array(lst)                     # [B,N,6N]
+    return res
+
+
+def rollout_basic(fg, N, T, seed, act_seed):
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, 1, N, 2)).astype(np.float32)
+    env = fg.make_env("basic_formation_env", False, N)
+    env.seed(seed)
+    o0 = env.reset()
+    L = len(env.world.landmarks)
+    lm = np.array([l.state.p_pos for l in env.world.landmarks])
+    p0, v0 = _state(env)
+    rec = {k: [] for k in ("pos", "vel", "indiv", "shared", "done", "obs")}
+    for t in range(T):
+        act_n = [acts[t, 0, i].astype(np.float64).copy() for i in range(N)]
+        obs_n, rew_n, done_n, info_n = env.step(act_n)
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
+        rec["shared"].append(np.array([r[0] for r in rew_n]))
+        rec["done"].append(np.array(done_n, dtype=np.bool_))
+        rec["obs"].append(np.array(obs_n, dtype=np.float64))
+    res = {k: np.array(v)[:, None] for k, v in rec.items()}    # [T,1,...]
+    res.update(acts=acts, pos0=p0[None], vel0=v0[None], landmarks=lm[None],
+               obs0=np.array(o0)[None], seed=np.array(seed), act_seed=np.array(act_seed),
+               world_length=np.array(env.world_length), num_landmarks=np.array(L),
+               agent_size=np.array(env.world.agents[0].size),
+               obs_dim=np.array(env.observation_space[0].shape[0]),
+               share_obs_dim=np.array(env.share_observation_space[0].shape[0]))
+    return res
+
+
+def reset_fixture(fg, cases):
+    res = {}
+    for (seed, N) in cases:
+        env = fg.make_env("formation_hd_env", False, N)
+        env.seed(seed)
+        o0 = env.reset()
+        sc = _scenario_of(env)
+        p, v = _state(env)
+        lm = np.array([l.state.p_pos for l in env.world.landmarks])
+        key = "s%d_n%d" % (seed, N)
+        res[key + "_pos"] = p
+        res[key + "_vel"] = v
+        res[key + "_shape"] = np.array(sc.ideal_shape)
+        res[key + "_ivel"] = np.array(sc.ideal_vel)
+        res[key + "_landmarks"] = lm          # after the observation side effect (:40-44)
+        res[key + "_obs"] = np.array(o0)
+        res[key + "_obs_dim"] = np.array(env.observation_space[0].shape[0])
+        res[key + "_share_obs_dim"] = np.array(env.share_observation_space[0].shape[0])
+        res[key + "_world_length"] = np.array(env.world_length)
+    res["cases"] = np.array(cases, dtype=np.int64)
+    return res
+
+
+def shape_fixture(fg):
+    env = fg.make_env("formation_hd_env", False, 3)
+    sc = _scenario_of(env)
+    res = {}
+    for L in range(4):
+        res["layer%d" % L] = np.array(sc.generate_shape(L), dtype=np.float64).reshape(-1, 2)
+    return res
+
+
+def policy_fixture(fg, N, T, seed):
+    """ezpolicy / get_action_BFS driven closed loop (reference __init__.py:19-99)."""
+    env = fg.make_env("formation_hd_env", False, N)
+    env.seed(seed)
+    obs_n = env.reset()
+    sc = _scenario_of(env)
+    p0, v0 = _state(env)
+    rec = {k: [] for k in ("act", "pos", "vel", "shared")}
+    obs_first = np.array(obs_n)
+    for t in range(T):
+        act_n = fg.get_action_BFS(fg.ezpolicy, obs_n, 3)
+        rec["act"].append(np.array(act_n, dtype=np.float64))   # before env.step scales it in place
+        obs_n, rew_n, done_n, _ = env.step([np.array(a, dtype=np.float64) for a in act_n])
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["shared"].append(rew_n[0][0])
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, ideal_shape=np.array(sc.ideal_shape),
+               ideal_vel=np.array(sc.ideal_vel), obs0=obs_first, seed=np.array(seed))
+    # single-agent-view ezpolicy known answers on the initial observations
+    res["ez_act0"] = np.array([fg.ezpolicy(o) for o in obs_first]) if N == 3 else np.zeros(0)
+    return res
+
+
+def hausdorff_kat():
+    """scipy's own published docstring example for directed_hausdorff
+    (scipy 1.15.3 spatial/distance.py) - the only external KAT on this path."""
+    from scipy.spatial.distance import directed_hausdorff
+    u = np.array([(1.0, 0.0), (0.0, 1.0), (-1.0, 0.0), (0.0, -1.0)])
+    v = np.array([(2.0, 0.0), (0.0, 2.0), (-2.0, 0.0), (0.0, -4.0)])
+    return dict(u=u, v=v, d_uv=np.array(directed_hausdorff(u, v)[0]),
+                d_vu=np.array(directed_hausdorff(v, u)[0]))
+
+
+def main():
+    tmp = tempfile.mkdtemp(prefix="fg_shims_")
+    _install_shims(tmp)
+    fg = _import_reference()
+
+    def save(name, d):
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **d)
+        print("%-28s %8.1f kB" % (name, os.path.getsize(path) / 1024))
+
+    # formation_hd_env rollouts, default spread (few contacts) and crowded (many)
+    save("hd_n3", rollout_hd(fg, 3, 4, 25, seed=1, act_seed=11))
+    save("hd_n9", rollout_hd(fg, 9, 4, 25, seed=2, act_seed=12))
+    save("hd_n27", rollout_hd(fg, 27, 3, 25, seed=3, act_seed=13))
+    save("hd_n81", rollout_hd(fg, 81, 2, 25, seed=4, act_seed=14))
+    save("hd_n9_crowd", rollout_hd(fg, 9, 4, 25, seed=5, act_seed=15, crowd=0.15))
+    save("hd_n27_crowd", rollout_hd(fg, 27, 3, 25, seed=6, act_seed=16, crowd=0.25))
+    save("hd_n81_crowd", rollout_hd(fg, 81, 2, 12, seed=7, act_seed=17, crowd=0.3))
+    save("hd_n243", rollout_hd(fg, 243, 1, 3, seed=8, act_seed=18, obs_at=[3]))
+    # an even agent count and a non-power-of-3 one (generic-N kernel path)
+    save("hd_n4", rollout_hd(fg, 4, 3, 10, seed=21, act_seed=31))
+    save("hd_n10", rollout_hd(fg, 10, 2, 10, seed=22, act_seed=32, crowd=0.3))
+    # done flip of formation_hd_env at world_length = 100
+    save("hd_n3_done", rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
+    # config 1: basic_formation_env, N=3, incl. the done flip at step 50
+    save("basic_n3", rollout_basic(fg, 3, 52, seed=1, act_seed=20))
+    save("reset", reset_fixture(fg, [(1, 3), (7, 9), (1001, 9), (3, 27), (4, 81)]))
+    save("shapes", shape_fixture(fg))
+    save("policy_n3", policy_fixture(fg, 3, 30, seed=41))
+    save("policy_n9", policy_fixture(fg, 9, 30, seed=42))
+    save("policy_n27", policy_fixture(fg, 27, 12, seed=43))
+    save("hausdorff_kat", hausdorff_kat())
+
+
+if __name__ == "__main__":
+    main()

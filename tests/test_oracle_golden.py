@@ -1,0 +1,180 @@
+"""Pin the CPU oracle (oracle/formation_oracle.py) to the golden fixtures that
+tests/golden/make_golden.py captured from the real reference, plus scipy's
+published directed_hausdorff example.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import formation_oracle as O
+
+HD_CASES = ["hd_n3", "hd_n9", "hd_n27", "hd_n81", "hd_n9_crowd", "hd_n27_crowd",
+            "hd_n81_crowd", "hd_n243", "hd_n4", "hd_n10", "hd_n3_done"]
+TOL = 1e-12
+
+
+def _state0(g):
+    B = g["pos0"].shape[0]
+    return dict(pos=g["pos0"], vel=g["vel0"], ideal_shape=g["ideal_shape"],
+                ideal_vel=g["ideal_vel"], step=np.zeros(B, dtype=np.int32))
+
+
+@pytest.mark.parametrize("name", HD_CASES)
+def test_hd_free_running_matches_reference(golden, name):
+    g = golden(name)
+    st = _state0(g)
+    T = g["acts"].shape[0]
+    np.testing.assert_allclose(
+        O.observation_hd(st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"]),
+        g["obs0"], rtol=0, atol=TOL)
+    for t in range(T):
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64))
+        # fp64 free-running: contacts amplify 1e-16 rounding, so allow growth
+        tol = 1e-9 if "crowd" in name or name == "hd_n243" else 1e-11
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=tol)
+        np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=tol * 10)
+        np.testing.assert_array_equal(out["done"], g["done"][t])
+
+
+@pytest.mark.parametrize("name", HD_CASES)
+def test_hd_teacher_forced_step(golden, name):
+    """Each step re-seeded from the reference's own previous state."""
+    g = golden(name)
+    T = g["acts"].shape[0]
+    B = g["pos0"].shape[0]
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        st = dict(pos=prev_pos, vel=prev_vel, ideal_shape=g["ideal_shape"],
+                  ideal_vel=g["ideal_vel"], step=np.full(B, t, dtype=np.int32))
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64))
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=TOL)
+        np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=1e-11)
+        # rewards/indices from the reference's own post-step state
+        r = O.reward_hd(g["pos"][t], g["vel"][t], g["ideal_shape"], g["ideal_vel"], O.HdParams())
+        np.testing.assert_allclose(r["indiv"], g["indiv"][t], rtol=0, atol=TOL)
+        np.testing.assert_allclose(r["shared"][:, None].repeat(g["shared"].shape[2], 1),
+                                   g["shared"][t], rtol=1e-13, atol=TOL)
+        np.testing.assert_allclose(r["hd"], g["hd"][t], rtol=0, atol=TOL)
+        np.testing.assert_array_equal(r["hd_idx"], g["hd_idx"][t])
+        np.testing.assert_array_equal(r["near_lm"], g["near_lm"][t])
+        np.testing.assert_array_equal(r["near_ag"], g["near_ag"][t])
+        np.testing.assert_array_equal(r["cnt"], g["cnt"][t])
+        np.testing.assert_array_equal(out["done"], g["done"][t])
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+@pytest.mark.parametrize("name", HD_CASES)
+def test_hd_observation_layout(golden, name):
+    g = golden(name)
+    for t in g["obs_steps"]:
+        obs = O.observation_hd(g["pos"][t - 1], g["vel"][t - 1], g["ideal_shape"], g["ideal_vel"])
+        np.testing.assert_allclose(obs, g["obs_t%d" % t], rtol=0, atol=TOL)
+        N = obs.shape[1]
+        assert obs.shape[2] == 6 * N
+        assert np.all(obs[:, :, 2 * N:4 * N - 2] == 0.0)      # silent agents: comm zeros
+
+
+def test_hd_done_flips_at_world_length(golden):
+    g = golden("hd_n3_done")
+    first = np.argmax(g["done"].reshape(g["done"].shape[0], -1).any(1)) + 1
+    assert first == O.HdParams.world_length == 100
+    assert g["done"][99:].all() and not g["done"][:99].any()
+
+
+def test_basic_env_matches_reference(golden):
+    g = golden("basic_n3")
+    P = O.BasicParams()
+    assert int(g["world_length"]) == P.world_length
+    assert int(g["num_landmarks"]) == P.num_landmarks
+    assert float(g["agent_size"]) == P.agent_size
+    st = dict(pos=g["pos0"], vel=g["vel0"], landmarks=g["landmarks"], step=np.zeros(1, dtype=np.int32))
+    np.testing.assert_allclose(O.observation_basic(st["pos"], st["vel"], st["landmarks"]),
+                               g["obs0"], rtol=0, atol=TOL)
+    assert g["obs0"].shape[-1] == int(g["obs_dim"]) == 18
+    for t in range(g["acts"].shape[0]):
+        st, out = O.step_basic(st, g["acts"][t].astype(np.float64), P)
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(out["reward"][..., 0], g["shared"][t], rtol=0, atol=1e-9)
+        np.testing.assert_array_equal(out["done"], g["done"][t])
+    assert g["done"][49:].all() and not g["done"][:49].any()
+    # every agent carries the constant -1 of its self-"collision" (basic_formation_env.py:49-51)
+    assert (out["cnt"] >= 1).all()
+
+
+def test_reset_stream(golden):
+    g = golden("reset")
+    for seed, N in g["cases"]:
+        key = "s%d_n%d" % (seed, N)
+        st = O.reset_hd([seed], N)
+        np.testing.assert_array_equal(st["pos"][0], g[key + "_pos"])
+        np.testing.assert_array_equal(st["ideal_vel"][0], g[key + "_ivel"])
+        np.testing.assert_allclose(st["ideal_shape"][0], g[key + "_shape"], rtol=0, atol=1e-15)
+        assert (g[key + "_vel"] == 0).all()
+        obs = O.observation_hd(st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"])
+        np.testing.assert_allclose(obs[0], g[key + "_obs"], rtol=0, atol=1e-15)
+        assert int(g[key + "_obs_dim"]) == 6 * N
+        assert int(g[key + "_share_obs_dim"]) == 6 * N * N
+        assert int(g[key + "_world_length"]) == 100
+        # observation's side effect re-centres the landmarks on the agents (:40-44)
+        np.testing.assert_allclose(g[key + "_landmarks"].mean(0), st["pos"][0].mean(0), atol=1e-12)
+
+
+def test_generate_shape(golden):
+    g = golden("shapes")
+    for L in range(4):
+        np.testing.assert_allclose(O.generate_shape(L), g["layer%d" % L], rtol=0, atol=1e-15)
+        assert O.generate_shape(L).shape == (3 ** (L + 1), 2)
+    with pytest.raises(AssertionError):
+        O.generate_shape(4)
+
+
+def test_hausdorff_known_answer(golden):
+    g = golden("hausdorff_kat")
+    d, i, j = O.directed_hausdorff_bruteforce(g["u"], g["v"])
+    assert d == float(g["d_uv"]) == 2.23606797749979           # scipy docstring value
+    d2, _, _ = O.directed_hausdorff_bruteforce(g["v"], g["u"])
+    assert d2 == float(g["d_vu"]) == 3.0
+
+
+@pytest.mark.parametrize("name,per", [("policy_n3", 3), ("policy_n9", 3), ("policy_n27", 3)])
+def test_bfs_policy_matches_reference(golden, name, per):
+    g = golden(name)
+    N = g["pos0"].shape[0]
+    P = O.HdParams()
+    pos, vel = g["pos0"][None], g["vel0"][None]
+    for t in range(g["act"].shape[0]):
+        prev_pos = g["pos"][t - 1][None] if t else pos
+        prev_vel = g["vel"][t - 1][None] if t else vel
+        obs = O.observation_hd(prev_pos, prev_vel, g["ideal_shape"][None], g["ideal_vel"][None])[0]
+        act = np.array(O.get_action_bfs(O.ezpolicy, list(obs), per))
+        np.testing.assert_allclose(act, g["act"][t], rtol=0, atol=1e-9)
+    if N == 3:
+        ez = np.array([O.ezpolicy(o) for o in g["obs0"]])
+        np.testing.assert_allclose(ez, g["ez_act0"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["hd_n3", "hd_n9_crowd", "hd_n27_crowd"])
+def test_port_env_matches_reference(golden, name):
+    """The per-env faithful port (the timed cpu_baseline) against the fixtures."""
+    g = golden(name)
+    N = g["pos0"].shape[1]
+    for b in range(min(2, g["pos0"].shape[0])):
+        env = O.PortEnv(N)
+        env.load(g["pos0"][b], g["vel0"][b], g["ideal_shape"][b], g["ideal_vel"][b])
+        for t in range(min(10, g["acts"].shape[0])):
+            obs_n, rew_n, done_n, info_n = env.step(list(g["acts"][t, b].astype(np.float64)))
+            pos = np.array([a.pos for a in env.agents])
+            np.testing.assert_allclose(pos, g["pos"][t, b], rtol=0, atol=1e-10)
+            np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t, b],
+                                       rtol=0, atol=1e-9)
+            np.testing.assert_allclose(rew_n[0][0], g["shared"][t, b, 0], rtol=1e-12, atol=1e-9)
+            if (t + 1) in g["obs_steps"]:
+                np.testing.assert_allclose(np.array(obs_n), g["obs_t%d" % (t + 1)][b], rtol=0, atol=1e-10)
+
+
+def test_port_env_reset_stream(golden):
+    g = golden("reset")
+    env = O.PortEnv(9)
+    env.seed(7)
+    obs = env.reset()
+    np.testing.assert_allclose(np.array(obs), g["s7_n9_obs"], rtol=0, atol=1e-15)
