@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Benchmark of the formation_gym hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 1000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (MultiAgentEnv.step: _set_action ->
+World.step -> observation/reward/done for every agent) over one batch of B
+environments per GPU = one launch of the fused HIP kernel `fg_step_hd`.
+Workload (BASELINE.json configs[2], the shape the north-star target is quoted
+on): formation_hd_env, 27 agents x 4096 envs per GPU, fp32, synthetic
+random-policy rollout: env b starts from np.random.RandomState(1 + 1000 b) in
+the reference's reset draw order, actions iid U(-1,1) fp32 (seed 0, pre-staged
+in HBM), episode length 100 with device-side auto-reset.  Environments are
+independent, so N GPUs run N disjoint slices with no collective (weak scaling:
+B per GPU fixed); the only communication is the timing barrier.
+
+Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "gym-formation_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X spec peak (MI355X_MICROARCH.md); 6290 measured copy
+
+
+def _cpu_port_worker(args):
+    """One env of the faithful per-env port, `steps` steps; returns elapsed seconds."""
+    n_agents, steps, seed = args
+    import numpy as np
+    from oracle.formation_oracle import PortEnv
+    env = PortEnv(n_agents)
+    env.seed(seed)
+    env.reset()
+    acts = np.random.RandomState(seed).uniform(-1, 1, (steps, n_agents, 2))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        _, _, done, _ = env.step(list(acts[t]))
+        if all(done):
+            env.reset()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(n_agents, budget_s=12.0):
+    """The oracle's per-env port (same loop structure as the reference) on the host
+    cores: one env per process, bounded sample.  Reported baseline only."""
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 32)
+    probe = _cpu_port_worker((n_agents, 2, 12345))          # seconds for 2 steps, 1 core
+    per_step = max(probe / 2, 1e-4)
+    steps = int(max(3, min(400, budget_s / per_step)))
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        elapsed = pool.map(_cpu_port_worker, [(n_agents, steps, 1 + 1000 * r) for r in range(cores)])
+    wall = max(elapsed)
+    return {
+        "value": round(cores * steps / wall, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "sample": "%d envs x %d steps of formation_hd_env N=%d, one env per process "
+                  "(oracle.PortEnv, numpy/scipy, fp64), wall = slowest worker %.1fs; "
+                  "pool start-up excluded (%.1fs total)" % (cores, steps, n_agents, wall, time.perf_counter() - t0),
+        "agent_steps_per_s": round(cores * steps * n_agents / wall, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--agents", type=int, default=27)
+    ap.add_argument("--envs", type=int, default=4096, help="environments PER GPU")
+    ap.add_argument("--mode", choices=["step", "rollout"], default="step",
+                    help="step: one fg_step_hd launch per step; rollout: fg_rollout_hd, --chunk steps per launch")
+    ap.add_argument("--chunk", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import formation_gym
+    from formation_gym import _native
+    from oracle import formation_oracle as O      # cpu_baseline + initial-state generator only
+
+    N, B = a.agents, a.envs
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
+    # initial states: env b of rank r is global env r*B + b, seeded 1 + 1000 * global index
+    gidx = rank * B + np.arange(B)
+    st = O.reset_hd(1 + 1000 * gidx, N)
+    env.world.set_state(st["pos"], st["vel"])
+    env.scenario.set_formation(env.world, st["ideal_shape"], st["ideal_vel"])
+    env.scenario._seed = 1 + rank
+    env.world.step_count.zero_()
+
+    P = 64                                             # pre-staged action pool, cycled
+    gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
+    act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
+    out = env._out
+    bytes_per_env_step = _native.step_hd_bytes(N)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(n, start):
+        launchers = run_steps.launchers
+        for t in range(start, start + n):
+            launchers[t % P](t)
+
+    run_steps.launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=True) for i in range(P)]
+
+    def run_rollout(n, start, chunk, seq):
+        t = start
+        while t < start + n:
+            k = min(chunk, start + n - t)
+            lo = t % P
+            if lo + k > P:
+                k = P - lo
+            env.scenario.rollout_batch(env.world, act_pool[lo:lo + k], {k2: v[:k] for k2, v in seq.items()},
+                                       auto_reset=True, rng_offset=t)
+            t += k
+
+    def timed(fn, steps, warmup):
+        fn(warmup, 0)
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        fn(steps, warmup)
+        ev1.record()
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+        if world_size > 1:
+            tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall, dev_ms = float(tt[0]), float(tt[1])
+        return wall, dev_ms
+
+    seq = None
+    if a.mode == "rollout" or not a.no_extra:
+        chunk = max(1, min(a.chunk, P))
+        f = dict(dtype=torch.float32, device=dev)
+        seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
+                   indiv=torch.empty((chunk, B, N), **f),
+                   done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
+
+    if a.mode == "step":
+        wall, dev_ms = timed(run_steps, a.steps, a.warmup)
+    else:
+        wall, dev_ms = timed(lambda n, s: run_rollout(n, s, chunk, seq), a.steps, a.warmup)
+
+    extra = None
+    if not a.no_extra:
+        other = "rollout" if a.mode == "step" else "step"
+        k2 = min(a.steps, 400)
+        if other == "rollout":
+            w2, d2 = timed(lambda n, s: run_rollout(n, s, chunk, seq), k2, min(a.warmup, 40))
+        else:
+            w2, d2 = timed(run_steps, k2, min(a.warmup, 40))
+        extra = {"mode": other, "steps": k2, "env_steps_per_s": round(world_size * B * k2 / w2, 1),
+                 "ms_per_step": round(w2 * 1e3 / k2, 5),
+                 "achieved_GBps": round(bytes_per_env_step * B * k2 / (d2 * 1e-3) / 1e9, 1)}
+        if other == "rollout":
+            extra["chunk"] = chunk
+
+    pos, _ = env.world.get_state()
+    finite = bool(torch.isfinite(pos).all())
+
+    if rank == 0:
+        launches = a.steps if a.mode == "step" else None
+        achieved = bytes_per_env_step * B * a.steps / (dev_ms * 1e-3) / 1e9      # GB/s per GPU
+        cfg = _native.kernel_config(N)
+        res = {
+            "metric": "env-steps/sec", "value": round(world_size * B * a.steps / wall, 1), "unit": "env-steps/s",
+            "agent_steps_per_s": round(world_size * B * N * a.steps / wall, 1),
+            "n_gpus": world_size, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "formation_hd_env, %d agents x %d envs per GPU, random policy, "
+                                   "episode 100 with device auto-reset" % (N, B),
+                       "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
+                       "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
+                       "kernel": "fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"])},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_per_env_step * B * (1 if a.mode == "step" else chunk),
+                         "avg_launch_us": round(dev_ms * 1e3 / a.steps * (1 if a.mode == "step" else chunk), 3),
+                         "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
+            "state_finite": finite,
+        }
+        if extra:
+            res["other_mode"] = extra
+        if world_size == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(N)
+        print(json.dumps(res), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,728 @@
+// formation_hip.hip - hand-written HIP kernels (gfx950 / CDNA4, wave64) for the
+// formation_gym hot path, and the C ABI declared in include/formation_hip.h.
+//
+// What one launch of `step_kernel` does for a group of E environments held by
+// one workgroup (reference lines in /root/reference/formation_gym/):
+//   phase 1  load SoA state + actions + ideal shape of the group into LDS
+//   phase 2  World.step: action force (core.py:228-237, environment.py:216-221),
+//            all-pairs soft-contact force on PRE-step positions (core.py:240-262,
+//            :289-322), damped Euler integration (core.py:264-277)
+//   phase 3  Scenario.reward (formation_hd_env.py:61-75): centroid and mean
+//            velocity by wave shuffles, one pass over post-step pairs giving the
+//            Hausdorff row/column minima and the collision counts, env-wide
+//            max/sum by shuffles (one env never spans a wave unless N > 64)
+//   phase 4  optional vec-env auto-reset (env_wrappers.py:14-18)
+//   phase 5  Scenario.observation (formation_hd_env.py:52-59) for all N agents:
+//            the group's [E][N][6N] block is one contiguous span of global
+//            memory; every lane composes two (x,y) units from LDS and issues one
+//            16-byte store, lanes consecutive -> 1 KiB per wave-instruction.
+// Observation bytes (24 N^2 per env) dominate traffic; everything else is 53 N + 16.
+// There is no dense contraction here, hence no MFMA: the kernel is HBM-store bound.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "formation_hip.h"
+
+namespace fg {
+
+#define FG_DEV __device__ __forceinline__
+
+struct Args {
+    FgParams p;
+    int B, N, K, obs_every;
+    int do_phys, do_post;
+    float* px; float* py; float* vx; float* vy;
+    const float* act;          // [K][B][N][2]
+    float* shape;              // [B][N][2]
+    float* ivel;               // [B][2]
+    int32_t* step;             // [B]
+    float* obs;                // [slots][B][N][6N]
+    float* rew;                // [K][B][N]
+    float* indiv;              // [K][B][N] or NULL
+    uint8_t* done;             // [K][B][N] or NULL
+    int32_t* near_lm; int32_t* near_ag; int32_t* hd_idx;
+};
+
+// ---------------------------------------------------------------------------
+// reductions over the lanes of one environment
+// ---------------------------------------------------------------------------
+enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
+
+template <int OP> FG_DEV float combine(float a, float b) {
+    if (OP == R_SUM) return a + b;
+    if (OP == R_MAX) return fmaxf(a, b);
+    return fminf(a, b);
+}
+
+// G <= 64: the env occupies an aligned group of G lanes of one wave -> xor shuffles.
+// G  > 64: the env is the whole workgroup (E == 1) -> wave shuffles + LDS partials.
+template <int G, int T, int NV, int OP0, int OP1, int OP2, int OP3>
+FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
+    constexpr int W = (G <= 64) ? G : 64;
+#pragma unroll
+    for (int m = W / 2; m > 0; m >>= 1) {
+        if (NV > 0) v[0] = combine<OP0>(v[0], __shfl_xor(v[0], m, 64));
+        if (NV > 1) v[1] = combine<OP1>(v[1], __shfl_xor(v[1], m, 64));
+        if (NV > 2) v[2] = combine<OP2>(v[2], __shfl_xor(v[2], m, 64));
+        if (NV > 3) v[3] = combine<OP3>(v[3], __shfl_xor(v[3], m, 64));
+    }
+    if (G > 64) {
+        constexpr int NW = T / 64;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) scratch[wave * 4 + q] = v[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = scratch[q];
+        for (int w = 1; w < NW; ++w) {
+            if (NV > 0) v[0] = combine<OP0>(v[0], scratch[w * 4 + 0]);
+            if (NV > 1) v[1] = combine<OP1>(v[1], scratch[w * 4 + 1]);
+            if (NV > 2) v[2] = combine<OP2>(v[2], scratch[w * 4 + 2]);
+            if (NV > 3) v[3] = combine<OP3>(v[3], scratch[w * 4 + 3]);
+        }
+        __syncthreads();   // scratch is reused by the next reduction
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counter-based RNG for the device-side reset (Philox4x32-10, Salmon et al. 2011)
+// ---------------------------------------------------------------------------
+FG_DEV void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t m1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)m1; c[3] = (uint32_t)m0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
+    return (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// World.step pair force on one agent (core.py:289-322, ratio m_b/m_a = 1)
+// ---------------------------------------------------------------------------
+FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, float2 p,
+                               float cf, float kmargin, float dmin, float cutoff2) {
+    float fx = 0.0f, fy = 0.0f;
+#pragma unroll 3
+    for (int j = 0; j < N; ++j) {
+        const float2 q = pre[j];
+        const float dx = p.x - q.x, dy = p.y - q.y;
+        const float d2 = dx * dx + dy * dy;
+        // beyond dmin + 30 k the softplus penetration is < k e^-30 ~ 1e-16: skipped.
+        // d2 == 0 for two distinct agents is kept: 0/0 -> NaN as in core.py:312.
+        if (j != i && d2 < cutoff2) {
+            const float d = sqrtf(d2);
+            const float x = (dmin - d) / kmargin;
+            const float pen = kmargin * (fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))));
+            const float c = cf * pen / d;
+            fx += dx * c;
+            fy += dy * c;
+        }
+    }
+    return make_float2(fx, fy);
+}
+
+// ---------------------------------------------------------------------------
+// the fused step / rollout kernel
+//   NC  compile-time agent count (0 = run-time a.N)
+//   G   lanes reserved per environment (power of two >= N when N <= 64, else T)
+//   T   threads per workgroup;  E = T / G environments per workgroup
+//   IDX also emit the landmark-index assignments
+// LDS per env (float2 units): PRE[N] | A[3N] = post pos[N], zeros[N-1], shape[N], ivel[1] | V[N]
+// so that observation unit u >= N of any row is A[u] and unit 0 of row i is A[3N + i].
+// ---------------------------------------------------------------------------
+template <int NC, int G, int T, bool IDX>
+__global__ __launch_bounds__(T) void step_kernel(const Args a) {
+    constexpr int E = T / G;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int N = NC ? NC : a.N;
+    const int tid = threadIdx.x;
+    const int e = (G >= T) ? 0 : tid / G;
+    const int i = (G >= T) ? tid : tid % G;
+    const int b0 = blockIdx.x * E;
+    const int b = b0 + e;
+    const bool valid = (b < a.B) && (i < N);
+    const int El = min(E, a.B - b0);
+
+    float2* const env_lds = smem + e * 5 * N;
+    float2* const PRE = env_lds;
+    float2* const A = env_lds + N;
+    float2* const V = A + 3 * N;
+    float* const scratch = reinterpret_cast<float*>(smem + E * 5 * N);
+
+    const float one_minus_damp = 1.0f - a.p.damping;
+    const float dt = a.p.dt;
+    const float cutoff = a.p.dist_min + 30.0f * a.p.contact_margin;
+    const float cutoff2 = cutoff * cutoff;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const float invN = 1.0f / (float)N;
+
+    // ---- phase 1: state -> registers + LDS --------------------------------
+    float2 p = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f), s = make_float2(0.f, 0.f);
+    int t_step = 0;
+    const size_t sidx = (size_t)b * N + i;
+    if (valid) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        PRE[i] = p; A[i] = p; V[i] = v;
+        if (a.do_post) {
+            s = reinterpret_cast<const float2*>(a.shape)[sidx];
+            A[2 * N - 1 + i] = s;
+            if (i < N - 1) A[N + i] = make_float2(0.f, 0.f);
+            if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
+        }
+    }
+    if (b < a.B && a.step) t_step = a.step[b];
+    __syncthreads();
+
+    for (int k = 0; k < a.K; ++k) {
+        // ---- phase 2: World.step ------------------------------------------
+        if (a.do_phys) {
+            if (valid) {
+                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                float2 f = contact_force_on(PRE, N, i, p, a.p.contact_force, a.p.contact_margin,
+                                            a.p.dist_min, cutoff2);
+                f.x += a.p.mass * (a.p.sensitivity * u.x);
+                f.y += a.p.mass * (a.p.sensitivity * u.y);
+                v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
+                v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
+                p.x += v.x * dt;
+                p.y += v.y * dt;
+                A[i] = p; V[i] = v;
+            }
+            t_step += 1;
+            __syncthreads();
+        }
+
+        if (a.do_post) {
+            // ---- phase 3: reward -------------------------------------------
+            float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+            env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, scratch);
+            const float mx = sums[0] * invN, my = sums[1] * invN;
+            const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+            const float ptx = p.x - mx, pty = p.y - my;        // centred own position
+            const float tx = s.x + mx, ty = s.y + my;          // own ideal point, un-centred
+            float rowmin = INFINITY, colmin = INFINITY;
+            int cnt = 0, arg_lm = 0, arg_ag = 0;
+            if (valid) {
+                const float2* __restrict__ SH = A + 2 * N - 1;
+#pragma unroll 3
+                for (int j = 0; j < N; ++j) {
+                    const float2 q = A[j];
+                    const float2 sj = SH[j];
+                    const float cx = q.x - p.x, cy = q.y - p.y;
+                    const float dc = cx * cx + cy * cy;
+                    cnt += (j != i && dc < thr2) ? 1 : 0;
+                    const float rx = ptx - sj.x, ry = pty - sj.y;
+                    const float dr = rx * rx + ry * ry;        // |p~_i - s_j|^2
+                    const float qx = q.x - tx, qy = q.y - ty;
+                    const float dq = qx * qx + qy * qy;        // |p~_j - s_i|^2
+                    if (IDX) {
+                        if (dr < rowmin) { rowmin = dr; arg_lm = j; }
+                        if (dq < colmin) { colmin = dq; arg_ag = j; }
+                    } else {
+                        rowmin = fminf(rowmin, dr);
+                        colmin = fminf(colmin, dq);
+                    }
+                }
+            }
+            float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+            env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
+            const float H = sqrtf(fmaxf(red[0], red[1]));
+            const float2 iv = A[3 * N - 1];
+            const float ex = iv.x - mvx, ey = iv.y - mvy;
+            const float velterm = sqrtf(ex * ex + ey * ey);
+            const float indiv = (-H - velterm) - (float)cnt;
+            const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            const bool is_done = t_step >= a.p.world_length;
+            if (valid) {
+                const size_t o = ((size_t)k * a.B + b) * N + i;
+                if (a.rew) a.rew[o] = shared;
+                if (a.indiv) a.indiv[o] = indiv;
+                if (a.done) a.done[o] = is_done ? 1 : 0;
+            }
+            if (IDX) {
+                // scipy's witnesses: first maximiser of the row/col minima
+                float w[2] = {(valid && rowmin == red[0]) ? (float)i : 1e9f,
+                              (valid && colmin == red[1]) ? (float)i : 1e9f};
+                env_reduce<G, T, 2, R_MIN, R_MIN, R_MIN, R_MIN>(w, scratch);
+                if (valid) {
+                    if (a.near_lm) a.near_lm[sidx] = arg_lm;
+                    if (a.near_ag) a.near_ag[sidx] = arg_ag;
+                    if (a.hd_idx) {
+                        if (i == (int)w[0]) { a.hd_idx[b * 4 + 0] = i; a.hd_idx[b * 4 + 1] = arg_lm; }
+                        if (i == (int)w[1]) { a.hd_idx[b * 4 + 2] = i; a.hd_idx[b * 4 + 3] = arg_ag; }
+                    }
+                }
+            }
+
+            // ---- phase 4: vec-env auto reset --------------------------------
+            if (a.p.auto_reset) {
+                const bool mine = is_done && (b < a.B);
+                if (G > 64 ? mine : (__any(mine) != 0)) {
+                    uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
+                                     (uint32_t)((a.p.rng_offset + k) >> 32)};
+                    philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                    float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                    const float rx = raw[0], ry = raw[1];
+                    env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
+                    if (mine && valid) {
+                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_float2(0.f, 0.f);
+                        s = make_float2(rx - raw[0] * invN, ry - raw[1] * invN);
+                        A[i] = p; V[i] = v; A[2 * N - 1 + i] = s;
+                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
+                        if (i == 0) {
+                            uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
+                                              (uint32_t)((a.p.rng_offset + k) >> 32)};
+                            philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                            const float2 niv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                            A[3 * N - 1] = niv;
+                            reinterpret_cast<float2*>(a.ivel)[b] = niv;
+                        }
+                    }
+                    if (mine) t_step = 0;
+                }
+                __syncthreads();
+            }
+
+            // ---- phase 5: observations --------------------------------------
+            int slot = k;
+            bool want_obs = a.obs != nullptr;
+            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+            if (want_obs) {
+                const unsigned n3 = 3u * N;                // units per row
+                const unsigned nenv = n3 * N;              // units per env
+                const size_t U0 = ((size_t)slot * a.B + b0) * nenv;
+                const unsigned total = (unsigned)El * nenv;
+                const unsigned head = (unsigned)(U0 & 1);
+                float2* const out2 = reinterpret_cast<float2*>(a.obs) + U0;
+                auto unit = [&](unsigned q) -> float2 {
+                    const unsigned ee = (E == 1) ? 0u : q / nenv;
+                    const unsigned r = q - ee * nenv;
+                    const unsigned row = r / n3;
+                    const unsigned u = r - row * n3;
+                    const float2* AA = smem + ee * 5 * N + N;
+                    unsigned idx = u;
+                    if (u < (unsigned)N) {
+                        const unsigned j = u - 1u;
+                        idx = (u == 0u) ? (n3 + row) : (j + (j >= row ? 1u : 0u));
+                    }
+                    float2 val = AA[idx];
+                    const float2 pi = AA[row];
+                    if (u - 1u < (unsigned)(N - 1)) { val.x -= pi.x; val.y -= pi.y; }
+                    return val;
+                };
+                if (head && tid == 0) out2[0] = unit(0);
+                const unsigned npair = (total - head) >> 1;
+                float4* const out4 = reinterpret_cast<float4*>(out2 + head);
+                for (unsigned q2 = tid; q2 < npair; q2 += T) {
+                    const unsigned q = head + 2u * q2;
+                    const float2 x0 = unit(q), x1 = unit(q + 1u);
+                    out4[q2] = make_float4(x0.x, x0.y, x1.x, x1.y);
+                }
+                if (((total - head) & 1u) && tid == T - 1) out2[total - 1] = unit(total - 1);
+            }
+        }
+
+        if (k + 1 < a.K) {
+            __syncthreads();            // obs phase done reading A/V before the next step writes them
+            if (valid) PRE[i] = p;
+            __syncthreads();
+        }
+    }
+
+    // ---- state write-back ---------------------------------------------------
+    if (valid && (a.do_phys || a.p.auto_reset)) {
+        a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+    }
+    if (a.do_phys && a.step && b < a.B && i == 0) a.step[b] = t_step;
+}
+
+// ---------------------------------------------------------------------------
+// standalone masked reset (Scenario.reset_world, formation_hd_env.py:77-95)
+// ---------------------------------------------------------------------------
+template <int G, int T>
+__global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* mask) {
+    constexpr int E = T / G;
+    __shared__ float scratch[64];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const int e = (G >= T) ? 0 : tid / G;
+    const int i = (G >= T) ? tid : tid % G;
+    const int b = blockIdx.x * E + e;
+    const bool valid = (b < a.B) && (i < N);
+    const bool mine = valid && (mask == nullptr || mask[b] != 0);
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+    philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+    float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+    const float rx = raw[0], ry = raw[1];
+    env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
+    if (mine) {
+        const size_t sidx = (size_t)b * N + i;
+        const float invN = 1.0f / (float)N;
+        a.px[sidx] = u_pm1(c[0]); a.py[sidx] = u_pm1(c[1]);
+        a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
+        reinterpret_cast<float2*>(a.shape)[sidx] = make_float2(rx - raw[0] * invN, ry - raw[1] * invN);
+        if (i == 0) {
+            uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+            philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+            reinterpret_cast<float2*>(a.ivel)[b] = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+            if (a.step) a.step[b] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// basic_formation_env (BASELINE config 1): one lane per agent, one env per
+// aligned group of G lanes of a wave (N <= 64).  Observation
+// basic_formation_env.py:29-41, reward :43-52.
+// ---------------------------------------------------------------------------
+struct BasicArgs {
+    FgParams p;
+    int B, N, L, do_phys;
+    float* px; float* py; float* vx; float* vy;
+    const float* act; const float* lm; int32_t* step;
+    float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
+};
+
+template <int G, int T>
+__global__ __launch_bounds__(T) void basic_kernel(const BasicArgs a) {
+    constexpr int E = T / G;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int N = a.N, L = a.L;
+    const int tid = threadIdx.x;
+    const int e = tid / G, i = tid % G;
+    const int b = blockIdx.x * E + e;
+    const bool valid = (b < a.B) && (i < N);
+    float2* const PRE = smem + e * (2 * N + L);
+    float2* const POST = PRE + N;
+    float2* const LM = POST + N;
+    float2 p = make_float2(0.f, 0.f), v = p;
+    const size_t sidx = (size_t)b * N + i;
+    if (valid) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        PRE[i] = p; POST[i] = p;
+    }
+    if (b < a.B && i < L) LM[i] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + i];
+    for (int l = G + i; (b < a.B) && l < L; l += G) LM[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + l];
+    int t_step = (b < a.B && a.step) ? a.step[b] : 0;
+    __syncthreads();
+    if (a.do_phys) {
+        if (valid) {
+            const float cutoff = a.p.dist_min + 30.0f * a.p.contact_margin;
+            const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
+            float2 f = contact_force_on(PRE, N, i, p, a.p.contact_force, a.p.contact_margin,
+                                        a.p.dist_min, cutoff * cutoff);
+            f.x += a.p.mass * (a.p.sensitivity * u.x);
+            f.y += a.p.mass * (a.p.sensitivity * u.y);
+            v.x = v.x * (1.0f - a.p.damping) + (f.x / a.p.mass) * a.p.dt;
+            v.y = v.y * (1.0f - a.p.damping) + (f.y / a.p.mass) * a.p.dt;
+            p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
+            POST[i] = p;
+            a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+        }
+        t_step += 1;
+        __syncthreads();
+    }
+    // reward: -sum_l min_a |p_a - l|  - #{a incl. self : |p_a - p_i| < thresh}
+    float cover = 0.f;   // lane l < L holds min_a |p_a - lm_l|
+    int arg = 0;
+    for (int l0 = 0; l0 < L; l0 += G) {
+        const int l = l0 + i;
+        float best = INFINITY; int barg = 0;
+        if (b < a.B && l < L) {
+            const float2 m = LM[l];
+            for (int j = 0; j < N; ++j) {
+                const float2 q = POST[j];
+                const float dx = q.x - m.x, dy = q.y - m.y;
+                const float d2 = dx * dx + dy * dy;
+                if (d2 < best) { best = d2; barg = j; }
+            }
+            cover += sqrtf(best);
+            if (a.near_ag) a.near_ag[(size_t)b * L + l] = barg;
+        }
+    }
+    (void)arg;
+    float red[1] = {cover};
+    float scratch_dummy[1];
+    env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch_dummy);
+    int cnt = 0;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    if (valid) for (int j = 0; j < N; ++j) {
+        const float2 q = POST[j];
+        const float dx = q.x - p.x, dy = q.y - p.y;
+        cnt += (dx * dx + dy * dy < thr2) ? 1 : 0;           // self included (:49-51)
+    }
+    float cs[1] = {(float)cnt};
+    env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch_dummy);
+    const bool is_done = t_step >= a.p.world_length;
+    const int D = 4 + 2 * L + 4 * (N - 1);
+    if (valid) {
+        a.rew[sidx] = (float)(-(double)N * (double)red[0] - (double)cs[0]);
+        if (a.indiv) a.indiv[sidx] = -red[0] - (float)cnt;
+        if (a.done) a.done[sidx] = is_done ? 1 : 0;
+        float2* o = reinterpret_cast<float2*>(a.obs + sidx * D);
+        o[0] = v; o[1] = p;
+        for (int l = 0; l < L; ++l) { const float2 m = LM[l]; o[2 + l] = make_float2(m.x - p.x, m.y - p.y); }
+        int w = 2 + L;
+        for (int j = 0; j < N; ++j) if (j != i) { const float2 q = POST[j]; o[w++] = make_float2(q.x - p.x, q.y - p.y); }
+        for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
+    }
+    if (a.do_phys && a.step && b < a.B && i == 0) a.step[b] = t_step;
+}
+
+// ---------------------------------------------------------------------------
+// host side: geometry selection, validation, launches
+// ---------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+
+static int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+struct Geometry { int G, T, E, lds; };
+
+static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+static bool geometry_for(int N, Geometry* g) {
+    if (N < 2 || N > FG_MAX_AGENTS) return false;
+    if (N <= 64) {
+        g->G = pow2ceil(N) < 4 ? 4 : pow2ceil(N);
+        g->T = 64;
+        if (N == 27) { int t = env_int("FG_T27", 128); g->T = (t == 64 || t == 128 || t == 256) ? t : 128; }
+    } else {
+        g->G = g->T = pow2ceil(N) < 128 ? 128 : pow2ceil(N);
+    }
+    g->E = g->T / g->G;
+    g->lds = g->E * 5 * N * (int)sizeof(float2) + 64 * 4 * (int)sizeof(float);
+    return true;
+}
+
+template <int NC, int G, int T>
+static hipError_t launch_cfg(const Args& a, bool idx, int grid, int lds, hipStream_t st) {
+    if (idx) hipLaunchKernelGGL((step_kernel<NC, G, T, true>), dim3(grid), dim3(T), lds, st, a);
+    else     hipLaunchKernelGGL((step_kernel<NC, G, T, false>), dim3(grid), dim3(T), lds, st, a);
+    return hipGetLastError();
+}
+
+static int launch_step(const Args& a, hipStream_t st) {
+    Geometry g;
+    if (!geometry_for(a.N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const bool idx = a.near_lm || a.near_ag || a.hd_idx;
+    const int grid = (a.B + g.E - 1) / g.E;
+    hipError_t err = hipSuccess;
+    const int N = a.N;
+    if (N == 3) err = launch_cfg<3, 4, 64>(a, idx, grid, g.lds, st);
+    else if (N == 9) err = launch_cfg<9, 16, 64>(a, idx, grid, g.lds, st);
+    else if (N == 27 && g.T == 64) err = launch_cfg<27, 32, 64>(a, idx, grid, g.lds, st);
+    else if (N == 27 && g.T == 128) err = launch_cfg<27, 32, 128>(a, idx, grid, g.lds, st);
+    else if (N == 27 && g.T == 256) err = launch_cfg<27, 32, 256>(a, idx, grid, g.lds, st);
+    else if (N == 81) err = launch_cfg<81, 128, 128>(a, idx, grid, g.lds, st);
+    else if (N == 243) err = launch_cfg<243, 256, 256>(a, idx, grid, g.lds, st);
+    else if (g.G == 4) err = launch_cfg<0, 4, 64>(a, idx, grid, g.lds, st);
+    else if (g.G == 8) err = launch_cfg<0, 8, 64>(a, idx, grid, g.lds, st);
+    else if (g.G == 16) err = launch_cfg<0, 16, 64>(a, idx, grid, g.lds, st);
+    else if (g.G == 32) err = launch_cfg<0, 32, 64>(a, idx, grid, g.lds, st);
+    else if (g.G == 64) err = launch_cfg<0, 64, 64>(a, idx, grid, g.lds, st);
+    else if (g.G == 128) err = launch_cfg<0, 128, 128>(a, idx, grid, g.lds, st);
+    else if (g.G == 256) err = launch_cfg<0, 256, 256>(a, idx, grid, g.lds, st);
+    else if (g.G == 512) err = launch_cfg<0, 512, 512>(a, idx, grid, g.lds, st);
+    else err = launch_cfg<0, 1024, 1024>(a, idx, grid, g.lds, st);
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+static int check_params(const FgParams* p) {
+    if (!p) return fail(FG_ERR_BAD_ARG, "params is NULL%s");
+    if (!(p->mass > 0.f) || !(p->contact_margin > 0.f) || !(p->dt > 0.f))
+        return fail(FG_ERR_BAD_ARG, "params: mass, contact_margin and dt must be > 0%s");
+    return FG_OK;
+}
+
+}  // namespace fg
+
+using namespace fg;
+
+extern "C" {
+
+int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+const char* fg_last_error(void) { return g_err; }
+
+int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes) {
+    Geometry g;
+    if (!geometry_for(N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    if (threads) *threads = g.T;
+    if (envs_per_wg) *envs_per_wg = g.E;
+    if (lds_bytes) *lds_bytes = g.lds;
+    return FG_OK;
+}
+
+int64_t fg_step_hd_bytes(int N) { return 24LL * N * N + 53LL * N + 16LL; }
+
+int fg_step_hd(const FgParams* params, int B, int N,
+               float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+               const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+               float* obs, float* reward, float* indiv_reward, uint8_t* done,
+               int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !act || !ideal_shape || !ideal_vel || !step || !obs || !reward)
+        return fail(FG_ERR_BAD_ARG, "fg_step_hd: a required pointer is NULL%s");
+    if (((uintptr_t)obs & 15u) || ((uintptr_t)act & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, act/ideal_shape/ideal_vel 8-byte aligned%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 1;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
+    a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
+    a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
+    a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
+    return launch_step(a, (hipStream_t)stream);
+}
+
+int fg_physics_step(const FgParams* params, int B, int N,
+                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                    const float* act, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !act)
+        return fail(FG_ERR_BAD_ARG, "fg_physics_step: a required pointer is NULL%s");
+    if ((uintptr_t)act & 7u) return fail(FG_ERR_ALIGNMENT, "act must be 8-byte aligned%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 0;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
+    return launch_step(a, (hipStream_t)stream);
+}
+
+int fg_observe_hd(const FgParams* params, int B, int N,
+                  const float* pos_x, const float* pos_y, const float* vel_x, const float* vel_y,
+                  const float* ideal_shape, const float* ideal_vel, const int32_t* step,
+                  float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                  int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
+        return fail(FG_ERR_BAD_ARG, "fg_observe_hd: a required pointer is NULL%s");
+    if (!obs && !reward) return fail(FG_ERR_BAD_ARG, "fg_observe_hd: obs and reward both NULL%s");
+    if (((uintptr_t)obs & 15u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, ideal_shape/ideal_vel 8-byte aligned%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 0; a.do_post = 1;
+    a.px = const_cast<float*>(pos_x); a.py = const_cast<float*>(pos_y);
+    a.vx = const_cast<float*>(vel_x); a.vy = const_cast<float*>(vel_y);
+    a.shape = const_cast<float*>(ideal_shape); a.ivel = const_cast<float*>(ideal_vel);
+    a.step = const_cast<int32_t*>(step);
+    a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
+    a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
+    return launch_step(a, (hipStream_t)stream);
+}
+
+int fg_rollout_hd(const FgParams* params, int B, int N, int K,
+                  float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                  const float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
+                  float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                  int obs_every, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0 || K <= 0) return fail(FG_ERR_BAD_ARG, "B and K must be > 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !act_seq || !ideal_shape || !ideal_vel || !step || !reward_seq)
+        return fail(FG_ERR_BAD_ARG, "fg_rollout_hd: a required pointer is NULL%s");
+    if (((uintptr_t)obs_seq & 15u) || ((uintptr_t)act_seq & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "obs_seq must be 16-byte, act_seq/ideal_shape/ideal_vel 8-byte aligned%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.B = B; a.N = N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+    a.do_phys = 1; a.do_post = 1;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
+    a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
+    a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
+    return launch_step(a, (hipStream_t)stream);
+}
+
+int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
+                float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                float* ideal_shape, float* ideal_vel, int32_t* step, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    Geometry g;
+    if (!geometry_for(N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
+        return fail(FG_ERR_BAD_ARG, "fg_reset_hd: a required pointer is NULL%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.B = B; a.N = N;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y;
+    a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
+    hipStream_t st = (hipStream_t)stream;
+    const int G = N <= 64 ? g.G : g.G;
+    int grid;
+#define FG_RESET(GG, TT) grid = (B + (TT / GG) - 1) / (TT / GG); \
+    hipLaunchKernelGGL((reset_kernel<GG, TT>), dim3(grid), dim3(TT), 0, st, a, mask)
+    if (G == 4) { FG_RESET(4, 64); } else if (G == 8) { FG_RESET(8, 64); }
+    else if (G == 16) { FG_RESET(16, 64); } else if (G == 32) { FG_RESET(32, 64); }
+    else if (G == 64) { FG_RESET(64, 64); } else if (G == 128) { FG_RESET(128, 128); }
+    else if (G == 256) { FG_RESET(256, 256); } else if (G == 512) { FG_RESET(512, 512); }
+    else { FG_RESET(1024, 1024); }
+#undef FG_RESET
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "reset launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
+                  float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                  const float* act, const float* landmarks, int32_t* step,
+                  float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                  int32_t* near_ag, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0 || L <= 0) return fail(FG_ERR_BAD_ARG, "B and L must be > 0%s");
+    if (N < 2 || N > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "basic_formation_env kernel needs 2 <= N <= 64%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || !reward || (do_physics && !act))
+        return fail(FG_ERR_BAD_ARG, "fg_step_basic: a required pointer is NULL%s");
+    if (((uintptr_t)obs & 7u) || ((uintptr_t)landmarks & 7u) || (act && ((uintptr_t)act & 7u)))
+        return fail(FG_ERR_ALIGNMENT, "obs/landmarks/act must be 8-byte aligned%s");
+    BasicArgs a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.B = B; a.N = N; a.L = L; a.do_phys = do_physics ? 1 : 0;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act; a.lm = landmarks; a.step = step;
+    a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
+    const int G = pow2ceil(N) < 4 ? 4 : pow2ceil(N);
+    const int E = 64 / G;
+    const int grid = (B + E - 1) / E;
+    const int lds = E * (2 * N + L) * (int)sizeof(float2);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 4) hipLaunchKernelGGL((basic_kernel<4, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 8) hipLaunchKernelGGL((basic_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 16) hipLaunchKernelGGL((basic_kernel<16, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 32) hipLaunchKernelGGL((basic_kernel<32, 64>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((basic_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "basic launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,121 @@
+"""ctypes binding of libformation_hip.so (C ABI: include/formation_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a GPU
+entry point fails, an exception is raised.  Pointers handed to the library are
+`tensor.data_ptr()` of PyTorch-ROCm tensors; launches go to torch's current HIP
+stream so torch events and stream semantics apply.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
+BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
+
+ABI_VERSION = 1
+
+FG_OK = 0
+FG_ERR_BAD_ARG = -1
+FG_ERR_UNSUPPORTED_N = -2
+FG_ERR_ALIGNMENT = -3
+FG_ERR_HIP = -4
+
+
+class FgParams(ctypes.Structure):
+    """Mirror of `struct FgParams` (include/formation_hip.h)."""
+    _fields_ = [
+        ("dt", ctypes.c_float),
+        ("damping", ctypes.c_float),
+        ("contact_force", ctypes.c_float),
+        ("contact_margin", ctypes.c_float),
+        ("sensitivity", ctypes.c_float),
+        ("mass", ctypes.c_float),
+        ("dist_min", ctypes.c_float),
+        ("collide_thresh", ctypes.c_float),
+        ("world_length", ctypes.c_int32),
+        ("auto_reset", ctypes.c_int32),
+        ("seed", ctypes.c_uint64),
+        ("rng_offset", ctypes.c_uint64),
+    ]
+
+
+class FormationHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libformation_hip: status %d: %s" % (code, msg))
+        self.code = code
+
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_PP = ctypes.POINTER(FgParams)
+
+# name -> (restype, argtypes); every symbol include/formation_hip.h declares
+SIGNATURES = {
+    "fg_abi_version": (_I, []),
+    "fg_last_error": (ctypes.c_char_p, []),
+    "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "fg_step_hd_bytes": (ctypes.c_int64, [_I]),
+    "fg_step_hd": (_I, [_PP, _I, _I] + [_P] * 16),
+    "fg_physics_step": (_I, [_PP, _I, _I] + [_P] * 6),
+    "fg_observe_hd": (_I, [_PP, _I, _I] + [_P] * 15),
+    "fg_rollout_hd": (_I, [_PP, _I, _I, _I] + [_P] * 12 + [_I, _P]),
+    "fg_reset_hd": (_I, [_PP, _I, _I] + [_P] * 9),
+    "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP library in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["bash", BUILD_SCRIPT])
+    return LIB_PATH
+
+
+def load():
+    """Load the library, set prototypes, check the ABI version.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FormationHipError(
+            FG_ERR_HIP, "%s not found - run gym-formation_amd/csrc/build.sh "
+            "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fg_abi_version() != ABI_VERSION:
+        raise FormationHipError(FG_ERR_BAD_ARG, "ABI version mismatch: library %d, binding %d"
+                                % (lib.fg_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != FG_OK:
+        raise FormationHipError(code, load().fg_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def kernel_config(n):
+    t, e, l = _I(), _I(), _I()
+    check(load().fg_kernel_config(int(n), ctypes.byref(t), ctypes.byref(e), ctypes.byref(l)))
+    return {"threads": t.value, "envs_per_wg": e.value, "lds_bytes": l.value}
+
+
+def step_hd_bytes(n):
+    return int(load().fg_step_hd_bytes(int(n)))

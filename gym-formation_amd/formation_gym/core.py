@@ -1,0 +1,269 @@
+"""Batched physics core: the MI355X-native counterpart of reference
+formation_gym/core.py.
+
+The reference keeps one Python object graph per environment, each agent holding
+`np.ndarray(2,)` float64 state (core.py:4-24, :45-109), and `World.step()`
+(core.py:206-225) is a pile of Python loops.  Here a `World` holds B independent
+environments as structure-of-arrays float32 tensors on the GPU:
+
+    pos_x, pos_y, vel_x, vel_y   [B, N]      agent state (SoA, env-major)
+    action_u                     [B, N, 2]   raw physical action (scaled in-kernel)
+    step_count                   [B] int32   MultiAgentEnv.current_step per env
+    landmark_pos                 [B, L, 2]   landmark positions (visual / basic env)
+
+`World.step()` launches the hand-written HIP kernel through the C ABI
+(`fg_physics_step`).  Entity / Agent / Landmark objects are lightweight
+descriptors (size, collide, movable, ...) whose `.state.p_pos` etc. are views of
+the batched tensors, so scenario code written against the reference's names
+keeps working.
+"""
+import numpy as np
+import torch
+
+from . import _native
+
+
+class EntityState(object):
+    """Physical state of one entity across all B envs (core.py:4-9)."""
+
+    def __init__(self, world=None, kind=None, index=None):
+        self._world = world
+        self._kind = kind
+        self._index = index
+
+    @property
+    def p_pos(self):
+        w, i = self._world, self._index
+        if self._kind == "agent":
+            return torch.stack((w.pos_x[:, i], w.pos_y[:, i]), dim=-1)
+        return w.landmark_pos[:, i]
+
+    @p_pos.setter
+    def p_pos(self, value):
+        w, i = self._world, self._index
+        value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+        if self._kind == "agent":
+            w.pos_x[:, i] = value[..., 0]
+            w.pos_y[:, i] = value[..., 1]
+        else:
+            w.landmark_pos[:, i] = value
+
+    @property
+    def p_vel(self):
+        w, i = self._world, self._index
+        if self._kind == "agent":
+            return torch.stack((w.vel_x[:, i], w.vel_y[:, i]), dim=-1)
+        return torch.zeros((w.num_envs, 2), dtype=torch.float32, device=w.device)
+
+    @p_vel.setter
+    def p_vel(self, value):
+        w, i = self._world, self._index
+        if self._kind != "agent":
+            return
+        value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+        w.vel_x[:, i] = value[..., 0]
+        w.vel_y[:, i] = value[..., 1]
+
+
+class AgentState(EntityState):
+    """Adds the communication utterance `c` (core.py:12-16).  All scenarios of
+    the reference set `silent=True`, so `c` is identically zero (core.py:281-282)."""
+
+    @property
+    def c(self):
+        w = self._world
+        return torch.zeros((w.num_envs, w.dim_c), dtype=torch.float32, device=w.device)
+
+
+class Action(object):
+    """Physical action `u` and communication action `c` (core.py:19-24)."""
+
+    def __init__(self, world=None, index=None):
+        self._world = world
+        self._index = index
+        self.c = None
+
+    @property
+    def u(self):
+        return self._world.action_u[:, self._index]
+
+    @u.setter
+    def u(self, value):
+        w = self._world
+        w.action_u[:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+
+
+class Wall(object):
+    """Wall description (core.py:27-41).  No BASELINE scenario creates walls
+    (world.walls == []); kept for API completeness, not simulated yet."""
+
+    def __init__(self, orient="H", axis_pos=0.0, endpoints=(-1, 1), width=0.1, hard=True):
+        self.orient = orient
+        self.axis_pos = axis_pos
+        self.endpoints = np.array(endpoints)
+        self.width = width
+        self.hard = hard
+        self.color = np.array([0.0, 0.0, 0.0])
+
+
+class Entity(object):
+    """Properties of a physical world entity (core.py:45-75); identical for all B envs."""
+
+    def __init__(self):
+        self.i = 0
+        self.name = ""
+        self.size = 0.050
+        self.movable = False
+        self.collide = True
+        self.ghost = False
+        self.density = 25.0
+        self.color = None
+        self.max_speed = None
+        self.accel = None
+        self.state = EntityState()
+        self.initial_mass = 1.0
+        self.channel = None
+
+    @property
+    def mass(self):
+        return self.initial_mass
+
+
+class Landmark(Entity):
+    def __init__(self):
+        super(Landmark, self).__init__()
+
+
+class Agent(Entity):
+    """core.py:83-109."""
+
+    def __init__(self):
+        super(Agent, self).__init__()
+        self.adversary = False
+        self.dummy = False
+        self.movable = True
+        self.silent = False
+        self.blind = False
+        self.u_noise = None
+        self.c_noise = None
+        self.u_range = 1.0
+        self.state = AgentState()
+        self.action = Action()
+        self.action_callback = None
+        self.goal = None
+
+
+class World(object):
+    """B independent multi-agent worlds stepped in lock-step on one GPU.
+
+    Constants and their reference defaults: core.py:113-139."""
+
+    def __init__(self, world_length=50, num_envs=1, device=None):
+        self.agents = []
+        self.landmarks = []
+        self.walls = []
+        self.dim_c = 0
+        self.dim_p = 2
+        self.dim_color = 3
+        self.dt = 0.1
+        self.damping = 0.25
+        self.contact_force = 1e+2
+        self.contact_margin = 1e-3
+        self.cache_dists = False
+        self.world_length = world_length
+        self.world_step = 0
+        self.num_agents = 0
+        self.num_landmarks = 0
+        # batched extension
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        self.pos_x = self.pos_y = self.vel_x = self.vel_y = None
+        self.action_u = None
+        self.step_count = None
+        self.landmark_pos = None
+        self.scenario = None
+
+    # ---- reference-compatible views --------------------------------------
+    @property
+    def entities(self):
+        return self.agents + self.landmarks
+
+    @property
+    def policy_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is None]
+
+    @property
+    def scripted_agents(self):
+        return [agent for agent in self.agents if agent.action_callback is not None]
+
+    # ---- storage ----------------------------------------------------------
+    def allocate(self):
+        """Create the SoA state tensors once agents/landmarks are defined."""
+        if self.device.type != "cuda":
+            raise RuntimeError("formation_gym (MI355X-native) needs a CUDA/HIP device; got %s. "
+                               "There is no CPU fallback for the hot path." % self.device)
+        _native.load()
+        B, N, L = self.num_envs, len(self.agents), len(self.landmarks)
+        f = dict(dtype=torch.float32, device=self.device)
+        self.pos_x = torch.zeros((B, N), **f)
+        self.pos_y = torch.zeros((B, N), **f)
+        self.vel_x = torch.zeros((B, N), **f)
+        self.vel_y = torch.zeros((B, N), **f)
+        self.action_u = torch.zeros((B, N, 2), **f)
+        self.step_count = torch.zeros((B,), dtype=torch.int32, device=self.device)
+        self.landmark_pos = torch.zeros((B, max(L, 1), 2), **f)
+        self.num_agents, self.num_landmarks = N, L
+        for i, a in enumerate(self.agents):
+            a.i = i
+            a.state = AgentState(self, "agent", i)
+            a.action = Action(self, i)
+        for i, l in enumerate(self.landmarks):
+            l.i = N + i
+            l.state = EntityState(self, "landmark", i)
+
+    def set_state(self, pos=None, vel=None):
+        """Upload [B,N,2] positions / velocities (any array-like) into the SoA tensors."""
+        if pos is not None:
+            pos = torch.as_tensor(np.asarray(pos), dtype=torch.float32).to(self.device)
+            self.pos_x.copy_(pos[..., 0]); self.pos_y.copy_(pos[..., 1])
+        if vel is not None:
+            vel = torch.as_tensor(np.asarray(vel), dtype=torch.float32).to(self.device)
+            self.vel_x.copy_(vel[..., 0]); self.vel_y.copy_(vel[..., 1])
+
+    def get_state(self):
+        """(pos[B,N,2], vel[B,N,2]) as new tensors."""
+        return (torch.stack((self.pos_x, self.pos_y), -1), torch.stack((self.vel_x, self.vel_y), -1))
+
+    # ---- physics ------------------------------------------------------------
+    def native_params(self, sensitivity=5.0, collide_thresh=0.0, auto_reset=False, seed=0, rng_offset=0):
+        """FgParams for the C ABI from this world's constants (uniform agents)."""
+        a0 = self.agents[0]
+        sizes = {a.size for a in self.agents}
+        masses = {a.mass for a in self.agents}
+        if len(sizes) != 1 or len(masses) != 1:
+            raise NotImplementedError("kernels assume identical agent size and mass")
+        for a in self.agents:
+            if a.max_speed is not None or a.u_noise or not a.movable or not a.collide:
+                raise NotImplementedError("max_speed / u_noise / immovable or ghost agents are not "
+                                          "reachable from the reference's make_env and not built")
+        if self.walls:
+            raise NotImplementedError("walls are inactive in every reference scenario and not built")
+        sens = a0.accel if a0.accel is not None else sensitivity     # environment.py:218-220
+        return _native.FgParams(
+            dt=self.dt, damping=self.damping, contact_force=self.contact_force,
+            contact_margin=self.contact_margin, sensitivity=sens, mass=a0.mass,
+            dist_min=a0.size + a0.size, collide_thresh=collide_thresh,
+            world_length=int(self.world_length), auto_reset=1 if auto_reset else 0,
+            seed=int(seed), rng_offset=int(rng_offset))
+
+    def step(self, sensitivity=5.0):
+        """World.step (core.py:206-225) for all envs: action force, all-pairs
+        contact force, integration - one HIP launch.  `action_u` holds the RAW
+        action; environment.py:216-221's sensitivity scaling happens in-kernel."""
+        self.world_step += 1
+        p = self.native_params(sensitivity=sensitivity)
+        lib = _native.load()
+        _native.check(lib.fg_physics_step(
+            p, self.num_envs, len(self.agents),
+            self.pos_x.data_ptr(), self.pos_y.data_ptr(), self.vel_x.data_ptr(), self.vel_y.data_ptr(),
+            self.action_u.data_ptr(), _native.current_stream()))

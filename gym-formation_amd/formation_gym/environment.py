@@ -1,0 +1,218 @@
+"""MultiAgentEnv: the env shell of reference formation_gym/environment.py
+(:11-236), driving B environments per call on one MI355X.
+
+Drop-in surface kept: constructor signature, `seed`, `reset`, `step`,
+`action_space[]`, `observation_space[]`, `share_observation_space[]`,
+`num_agents`, `agents`, `world`, `world_length`, `current_step`, `num_envs`,
+`shared_reward`.
+
+Two calling conventions for `step`:
+  * reference style - `action_n` is a list of N arrays of shape (2,) (num_envs
+    must be 1): returns `(obs_n, reward_n, done_n, info_n)` exactly shaped like
+    the reference (lists of float64 arrays / [float] / bool / dict) and, like the
+    reference (environment.py:216-221), scales the caller's arrays in place and
+    rejects plain Python lists;
+  * batched - `action_n` is a float32 tensor [B, N, 2] on the device: returns
+    device tensors obs [B,N,6N], reward [B,N,1], done [B,N] (bool) and
+    info = {'individual_reward': [B,N]}.  These are views of buffers that the
+    next `step` overwrites.
+Either way ONE fused HIP launch does `_set_action` (x N), `world.step()` and the
+N observation / 2N reward / N done callbacks of environment.py:113-142.
+"""
+import numpy as np
+import torch
+
+from . import spaces
+
+cam_range = 2
+
+
+class MultiAgentEnv(object):
+    metadata = {'render.modes': ['human', 'rgb_array']}
+
+    def __init__(self, world, reset_callback=None, reward_callback=None,
+                 observation_callback=None, info_callback=None,
+                 done_callback=None, post_step_callback=None,
+                 shared_viewer=True, discrete_action=False):
+        self.world = world
+        self.world_length = self.world.world_length
+        self.current_step = 0
+        self.agents = self.world.policy_agents
+        self.num_agents = len(world.policy_agents)
+        self.reset_callback = reset_callback
+        self.reward_callback = reward_callback
+        self.observation_callback = observation_callback
+        self.info_callback = info_callback
+        self.done_callback = done_callback
+        self.post_step_callback = post_step_callback
+        self.num_envs = world.num_envs
+        self.scenario = world.scenario
+        if self.scenario is None:
+            raise ValueError("world.scenario is not set: make_world() must attach the Scenario "
+                             "that owns the batched kernels")
+        if discrete_action:
+            raise NotImplementedError("discrete action modes (environment.py:194-210) are unreachable "
+                                      "through make_env and not built")
+        self.discrete_action_space = False
+        self.discrete_action_input = False
+        self.force_discrete_action = False
+        self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
+        self.time = 0
+        self.auto_reset = False           # vec-env worker semantics, see vec_env.py
+        self._rng_offset = 0
+
+        # spaces (environment.py:55-96)
+        self.action_space = []
+        self.observation_space = []
+        obs_dim = self.scenario.obs_dim(world)
+        share_obs_dim = 0
+        for agent in self.agents:
+            if not agent.silent:
+                raise NotImplementedError("non-silent agents do not occur in the reference scenarios")
+            self.action_space.append(spaces.Box(low=-agent.u_range, high=+agent.u_range,
+                                                shape=(world.dim_p,), dtype=np.float32))
+            share_obs_dim += obs_dim
+            self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf,
+                                                     shape=(obs_dim,), dtype=np.float32))
+        self.share_observation_space = [spaces.Box(low=-np.inf, high=+np.inf, shape=(share_obs_dim,),
+                                                   dtype=np.float32) for _ in range(self.num_agents)]
+
+        B, N = self.num_envs, self.num_agents
+        dev = world.device
+        f = dict(dtype=torch.float32, device=dev)
+        self._out = dict(
+            obs=torch.empty((B, N, obs_dim), **f),
+            reward=torch.empty((B, N), **f),
+            indiv=torch.empty((B, N), **f),
+            done=torch.zeros((B, N), dtype=torch.uint8, device=dev),
+        )
+        self._act = torch.zeros((B, N, 2), **f)
+        self.shared_viewer = shared_viewer
+        self.viewers = [None]
+
+    # ------------------------------------------------------------------ seed
+    def seed(self, seed=None):
+        """environment.py:106-110 (default seed 1)."""
+        self.scenario.seed(seed)
+
+    def enable_assignments(self, on=True):
+        """Also emit the landmark-index assignments (nearest ideal point per
+        agent, nearest agent per ideal point, Hausdorff witness pairs) each step."""
+        B, N = self.num_envs, self.num_agents
+        dev = self.world.device
+        if on:
+            self._out["near_lm"] = torch.zeros((B, N), dtype=torch.int32, device=dev)
+            self._out["near_ag"] = torch.zeros((B, N), dtype=torch.int32, device=dev)
+            self._out["hd_idx"] = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+        else:
+            for k in ("near_lm", "near_ag", "hd_idx"):
+                self._out.pop(k, None)
+
+    # ------------------------------------------------------------------ step
+    def step(self, action_n):
+        self.current_step += 1
+        self.agents = self.world.policy_agents
+        batched = torch.is_tensor(action_n)
+        if batched:
+            act = action_n
+            if act.shape != self._act.shape:
+                raise ValueError("batched action must have shape %s, got %s"
+                                 % (tuple(self._act.shape), tuple(act.shape)))
+            if act.dtype != torch.float32 or act.device != self._act.device or not act.is_contiguous():
+                self._act.copy_(act)
+                act = self._act
+        else:
+            act = self._stage_reference_actions(action_n)
+        self._rng_offset += 1
+        self.scenario.step_batch(self.world, act, self._out, auto_reset=self.auto_reset,
+                                 rng_offset=self._rng_offset)
+        self.world.world_step += 1
+        if self.post_step_callback is not None:
+            self.post_step_callback(self.world)
+        if batched:
+            return self._batched_result()
+        return self._reference_result()
+
+    def _stage_reference_actions(self, action_n):
+        """environment.py:121-122,187-236 for the continuous path, B == 1."""
+        if self.num_envs != 1:
+            raise ValueError("a list of per-agent actions needs num_envs == 1; pass a [B,N,2] tensor")
+        if len(action_n) != self.num_agents:
+            raise ValueError("expected %d agent actions, got %d" % (self.num_agents, len(action_n)))
+        host = np.empty((1, self.num_agents, 2), dtype=np.float32)
+        for i, (a, agent) in enumerate(zip(action_n, self.agents)):
+            if isinstance(a, (list, tuple)):
+                # the reference fails at `agent.action.u *= sensitivity` (:221)
+                raise TypeError("can't multiply sequence by non-int of type 'float'")
+            a = a if isinstance(a, np.ndarray) else np.asarray(a)
+            host[0, i] = a[0:2]
+            sens = agent.accel if agent.accel is not None else 5.0
+            a[0:2] *= sens            # the reference scales the caller's array in place (:216,:221)
+        self._act.copy_(torch.from_numpy(host))
+        return self._act
+
+    def _batched_result(self):
+        o = self._out
+        rew = o["reward"].unsqueeze(-1)
+        if not self.shared_reward:
+            rew = o["indiv"].unsqueeze(-1)
+        return o["obs"], rew, o["done"].bool(), {"individual_reward": o["indiv"]}
+
+    def _reference_result(self):
+        o = self._out
+        obs = o["obs"][0].double().cpu().numpy()
+        indiv = o["indiv"][0].double().cpu().numpy()
+        shared = float(o["reward"][0, 0].double().cpu())
+        done = bool(o["done"][0, 0].cpu())
+        N = self.num_agents
+        obs_n = [obs[i] for i in range(N)]
+        if self.shared_reward:
+            reward_n = [[shared]] * N                     # :136-138
+        else:
+            reward_n = [[float(indiv[i])] for i in range(N)]
+        done_n = [done] * N
+        info_n = [{'individual_reward': float(indiv[i])} for i in range(N)]
+        return obs_n, reward_n, done_n, info_n
+
+    # ----------------------------------------------------------------- reset
+    def reset(self, batched=None):
+        """environment.py:144-156.  Returns a list of N float64 arrays when
+        num_envs == 1 (reference style) unless batched=True; else obs [B,N,D]."""
+        self.current_step = 0
+        self.reset_callback(self.world)
+        self.agents = self.world.policy_agents
+        self.scenario.observe_batch(self.world, self._out)
+        if batched is None:
+            batched = self.num_envs != 1
+        if batched:
+            return self._out["obs"]
+        obs = self._out["obs"][0].double().cpu().numpy()
+        return [obs[i] for i in range(self.num_agents)]
+
+    # ---------------------------------------------------- per-agent callbacks
+    def _get_info(self, agent):
+        if self.info_callback is None:
+            return {}
+        return self.info_callback(agent, self.world)
+
+    def _get_obs(self, agent):
+        if self.observation_callback is None:
+            return np.zeros(0)
+        return self.observation_callback(agent, self.world)
+
+    def _get_done(self, agent):
+        if self.done_callback is None:
+            return self.current_step >= self.world_length
+        return self.done_callback(agent, self.world)
+
+    def _get_reward(self, agent):
+        if self.reward_callback is None:
+            return 0.0
+        return self.reward_callback(agent, self.world)
+
+    def render(self, mode='human', close=False):
+        raise NotImplementedError("the pyglet renderer of the reference (environment.py:243-393) "
+                                  "is out of scope for the MI355X hot path")
+
+    def close(self):
+        pass

@@ -1,0 +1,229 @@
+"""formation_hd_env: Hausdorff-distance formation task (reference
+formation_gym/envs/formation_hd_env.py), MI355X-native.
+
+Same plugin surface (`class Scenario(BaseScenario)` with make_world /
+reset_world / observation / reward / benchmark_data / is_collision /
+generate_shape).  The arithmetic of observation (:38-59), reward (:61-75) and
+the env shell's done (environment.py:172-178) runs inside the fused HIP kernel
+`fg_step_hd`; the per-agent callbacks return that agent's slice.
+"""
+import numpy as np
+import torch
+
+from formation_gym import _native
+from formation_gym.core import World, Agent, Landmark
+from formation_gym.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self, num_agents=3, episode_length=100, num_envs=1, device=None):
+        world = World(num_envs=num_envs, device=device)
+        world.world_length = episode_length
+        world.dim_c = 2
+        world.collaborative = True
+        self.num_agents = num_agents
+        world.agents = [Agent() for _ in range(num_agents)]
+        for i, agent in enumerate(world.agents):
+            agent.name = 'agent %d' % i
+            agent.collide = True
+            agent.silent = True
+            agent.size = 0.03
+        world.landmarks = [Landmark() for _ in range(num_agents)]
+        for i, landmark in enumerate(world.landmarks):
+            landmark.name = 'landmarks %d' % i
+            landmark.collide = False
+            landmark.movable = False
+            landmark.size = 0.01
+        world.allocate()
+        world.scenario = self
+        B, N = world.num_envs, num_agents
+        f = dict(dtype=torch.float32, device=world.device)
+        self.ideal_shape = torch.zeros((B, N, 2), **f)     # Scenario attribute, as in :86-93
+        self.ideal_vel = torch.zeros((B, 2), **f)          # :95
+        self._rngs = None
+        self._seed = 1
+        self._cache = None
+        self.reset_world(world)
+        return world
+
+    # ---- RNG: the reference draws from the global legacy MT19937 ----------
+    def seed(self, seed=None):
+        """env.seed(s) (environment.py:106-110).  Env b gets RandomState(s + 1000 b),
+        the per-worker convention of train/maddpg-v2/main.py:19-30; b = 0 is the
+        reference's single env."""
+        self._seed = 1 if seed is None else int(seed)
+        self._rngs = None
+
+    def _streams(self, B):
+        if self._rngs is None or len(self._rngs) != B:
+            self._rngs = [np.random.RandomState(self._seed + 1000 * b) for b in range(B)]
+        return self._rngs
+
+    def reset_world(self, world, env_mask=None):
+        """:77-95 - N agent positions, N landmark positions, one ideal velocity,
+        each U(-1,1)^2, drawn in that order from each env's own stream; the
+        ideal shape is the centred landmark set."""
+        B, N = world.num_envs, len(world.agents)
+        rngs = self._streams(B)
+        idx = range(B) if env_mask is None else [b for b in range(B) if env_mask[b]]
+        pos, vel = world.get_state()
+        pos = pos.cpu().numpy().astype(np.float64); vel = vel.cpu().numpy().astype(np.float64)
+        shape = self.ideal_shape.cpu().numpy().astype(np.float64)
+        ivel = self.ideal_vel.cpu().numpy().astype(np.float64)
+        lm = world.landmark_pos.cpu().numpy().astype(np.float64)
+        for b in idx:
+            rs = rngs[b]
+            pos[b] = rs.uniform(-1, +1, (N, 2))
+            vel[b] = 0.0
+            raw = rs.uniform(-1, +1, (N, 2))
+            shape[b] = raw - raw.mean(0)
+            lm[b] = raw
+            ivel[b] = rs.uniform(-1, +1, 2)
+        world.set_state(pos, vel)
+        self.ideal_shape.copy_(torch.as_tensor(shape, dtype=torch.float32))
+        self.ideal_vel.copy_(torch.as_tensor(ivel, dtype=torch.float32))
+        world.landmark_pos.copy_(torch.as_tensor(lm, dtype=torch.float32))
+        if env_mask is None:
+            world.step_count.zero_()
+        else:
+            m = torch.as_tensor(np.asarray(env_mask, dtype=bool), device=world.device)
+            world.step_count.masked_fill_(m, 0)
+        self._cache = None
+
+    def set_formation(self, world, ideal_shape=None, ideal_vel=None):
+        """Upload explicit ideal shapes [B,N,2] / velocities [B,2] (parity tests, curricula)."""
+        if ideal_shape is not None:
+            self.ideal_shape.copy_(torch.as_tensor(np.asarray(ideal_shape), dtype=torch.float32))
+        if ideal_vel is not None:
+            self.ideal_vel.copy_(torch.as_tensor(np.asarray(ideal_vel), dtype=torch.float32))
+        self._cache = None
+
+    # ---- batched protocol ----------------------------------------------------
+    def obs_dim(self, world):
+        return 6 * len(world.agents)
+
+    def params(self, world, auto_reset=False, rng_offset=0):
+        a0 = world.agents[0]
+        return world.native_params(collide_thresh=(a0.size + a0.size) / 2,   # :121
+                                   auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
+
+    def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
+        lib = _native.load()
+        _native.check(lib.fg_step_hd(
+            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            act.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+            world.step_count.data_ptr(),
+            out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+            _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
+            _native.ptr(out.get("hd_idx")), _native.current_stream()))
+        self._cache = out
+
+    def bind_step(self, world, act, out, auto_reset=False):
+        """Resolve every pointer once and return `launch(rng_offset)`: the per-call
+        host work is one ctypes call (rollout loops, bench.py)."""
+        lib = _native.load()
+        p = self.params(world, auto_reset, 0)
+        args = (world.num_envs, len(world.agents),
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                act.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+                world.step_count.data_ptr(),
+                out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
+                _native.ptr(out.get("hd_idx")), _native.current_stream())
+        fn = lib.fg_step_hd
+        keep = (act, out)
+
+        def launch(rng_offset=0):
+            p.rng_offset = rng_offset
+            rc = fn(p, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        self._cache = None
+        return launch
+
+    def observe_batch(self, world, out):
+        lib = _native.load()
+        _native.check(lib.fg_observe_hd(
+            self.params(world), world.num_envs, len(world.agents),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
+            _native.ptr(out.get("obs")), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
+            _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
+            _native.ptr(out.get("hd_idx")), _native.current_stream()))
+        self._cache = out
+
+    def rollout_batch(self, world, act_seq, out, obs_every=1, auto_reset=False, rng_offset=0):
+        """K steps in one launch; act_seq [K,B,N,2], out tensors carry a leading K."""
+        lib = _native.load()
+        K = act_seq.shape[0]
+        _native.check(lib.fg_rollout_hd(
+            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents), K,
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+            world.step_count.data_ptr(),
+            _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+            _native.ptr(out.get("done")), int(obs_every), _native.current_stream()))
+        self._cache = None
+
+    def reset_device(self, world, mask=None, rng_offset=0):
+        """Throughput-mode reset on the GPU (counter RNG, distributional parity only)."""
+        lib = _native.load()
+        _native.check(lib.fg_reset_hd(
+            self.params(world, rng_offset=rng_offset), world.num_envs, len(world.agents), _native.ptr(mask),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
+            _native.current_stream()))
+        self._cache = None
+
+    # ---- per-agent callbacks (reference signature) -----------------------------
+    def _fresh(self, world):
+        if self._cache is None:
+            B, N = world.num_envs, len(world.agents)
+            f = dict(dtype=torch.float32, device=world.device)
+            out = dict(obs=torch.empty((B, N, 6 * N), **f), reward=torch.empty((B, N), **f),
+                       indiv=torch.empty((B, N), **f))
+            self.observe_batch(world, out)
+        return self._cache
+
+    def observation(self, agent, world):
+        """:38-59 for `agent` in every env -> [B, 6N].  Also applies the
+        reference's side effect of re-centring the landmarks on the agents (:40-44)."""
+        out = self._fresh(world)
+        cen = torch.stack((world.pos_x.mean(1), world.pos_y.mean(1)), -1) - world.landmark_pos.mean(1)
+        world.landmark_pos += cen[:, None, :]
+        return out["obs"][:, agent.i]
+
+    def reward(self, agent, world):
+        """:61-75 individual reward of `agent` in every env -> [B]."""
+        return self._fresh(world)["indiv"][:, agent.i]
+
+    def benchmark_data(self, agent, world):
+        """:97-117."""
+        rew = self.reward(agent, world)
+        pos, _ = world.get_state()
+        d = (pos - pos[:, agent.i:agent.i + 1]).norm(dim=-1)
+        collisions = (d < world.agents[0].size).sum(1)          # self included, as in :101-104
+        dl = (pos[:, :, None, :] - world.landmark_pos[:, None, :, :]).norm(dim=-1).min(1).values
+        return {'reward': rew, 'collisions': collisions, 'min_dists': dl.sum(1),
+                'occupied_landmarks': (dl < 0.1).sum(1)}
+
+    def is_collision(self, agent1, agent2):
+        """:119-121 -> bool [B]."""
+        dist = (agent1.state.p_pos - agent2.state.p_pos).norm(dim=-1)
+        return dist < (agent1.size + agent2.size) / 2
+
+    def generate_shape(self, layer, layer_shapes=None):
+        """:123-139 default hierarchical target shape, [3, ..., 3, 2] nested like the reference."""
+        table = np.array([
+            [[0, -1], [0.5, 0], [0, 1]],
+            [[0, 1.6], [-1, 0], [1, 0]],
+            [[1.5, 0], [0, 0], [-1.5, 0]],
+            [[0, 0.6], [1, 0], [-1, 0]],
+        ]) if layer_shapes is None else np.asarray(layer_shapes)
+        assert layer < table.shape[0], 'Layer shape is not enough!'
+        if layer == 0:
+            return table[0]
+        inner = self.generate_shape(layer - 1, layer_shapes)
+        return np.array([table[layer][i] + inner * 0.45 for i in range(table.shape[1])])

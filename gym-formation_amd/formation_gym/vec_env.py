@@ -1,0 +1,55 @@
+"""Vectorised-env adapter with the semantics RL callers of the reference get
+from `SubprocVecEnv` / `DummyVecEnv` (train/maddpg-v2/utils/env_wrappers.py:9-128):
+`step` auto-resets an environment whose agents are all done and returns the
+RESET observation together with the pre-reset reward/done; results are stacked
+`(B, N, ...)`.  There the batch is one OS process per env talking over a Pipe;
+here it is the batch dimension of one fused HIP launch, and the reset happens
+inside that launch (counter RNG) or, in parity mode, on the host from each env's
+own legacy MT19937 stream (seed + 1000 * rank, train/maddpg-v2/main.py:19-30).
+"""
+import torch
+
+
+class FormationVecEnv(object):
+    def __init__(self, env, reset_mode="device"):
+        if reset_mode not in ("device", "host"):
+            raise ValueError("reset_mode must be 'device' or 'host'")
+        self.env = env
+        self.reset_mode = reset_mode
+        self.num_envs = env.num_envs
+        self.num_agents = env.num_agents
+        self.observation_space = env.observation_space
+        self.action_space = env.action_space
+        self.agent_types = ['agent' for _ in env.agents]        # env_wrappers.py:33-34
+        env.auto_reset = reset_mode == "device"
+        self.ts = torch.zeros(self.num_envs, dtype=torch.int64)
+
+    def get_spaces(self):
+        return self.observation_space, self.action_space
+
+    def reset(self):
+        return self.env.reset(batched=True)
+
+    def step(self, actions):
+        """actions [B, N, 2] -> obs [B,N,D], rews [B,N,1], dones [B,N] (bool), infos dict."""
+        obs, rew, done, info = self.env.step(actions)
+        if self.reset_mode == "host":
+            mask = done.all(dim=1)
+            if bool(mask.any()):
+                # keep the pre-reset reward/done; replace obs of finished envs by reset obs
+                rew, done = rew.clone(), done.clone()
+                info = {k: v.clone() for k, v in info.items()}
+                self.env.scenario.reset_world(self.env.world, env_mask=mask.cpu().numpy())
+                self.env.scenario.observe_batch(self.env.world, {"obs": self.env._out["obs"]})
+                obs = self.env._out["obs"]
+        return obs, rew, done, info
+
+    def step_async(self, actions):
+        self._pending = self.step(actions)
+
+    def step_wait(self):
+        out, self._pending = self._pending, None
+        return out
+
+    def close(self):
+        self.env.close()

@@ -1,0 +1,155 @@
+/*
+ * formation_hip.h - C ABI of libformation_hip.so, the MI355X (gfx950) native
+ * implementation of the formation_gym hot path.
+ *
+ * The reference (jc-bao/gym-formation) is pure Python and has no FFI; its
+ * boundary for this path is the plugin API
+ *     formation_gym.make_env(...)                 formation_gym/__init__.py:6-17
+ *     MultiAgentEnv.reset() / .step(action_n)     formation_gym/environment.py:113-156
+ *     Scenario.{reset_world,observation,reward}   formation_gym/envs/formation_hd_env.py:38-95
+ *     World.step()                                formation_gym/core.py:206-225
+ * Each entry point below names the reference interface it replaces.  The host
+ * side that binds them through ctypes is gym-formation_amd/formation_gym/_native.py;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
+ *     (e.g. torch.Tensor.data_ptr()); the library allocates nothing persistent
+ *     and keeps no pointer after a call returns.
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*, NULL = the default stream); no device synchronisation inside, so
+ *     every entry point may be captured into a hipGraph.
+ *   - return value: FG_OK (0) or a negative FgStatus; nothing throws or exits.
+ *     fg_last_error() returns a thread-local description of the last failure.
+ *   - layouts are env-major and contiguous.  B = number of independent
+ *     environments (the data-parallel unit), N = agents per environment.
+ *       pos_x,pos_y,vel_x,vel_y  float [B][N]     structure-of-arrays agent state
+ *       act                      float [B][N][2]  raw actions (scaled by `sensitivity` inside)
+ *       ideal_shape              float [B][N][2]  Scenario.ideal_shape (already centred)
+ *       ideal_vel                float [B][2]     Scenario.ideal_vel
+ *       step                     int32 [B]        MultiAgentEnv.current_step per env
+ *       obs                      float [B][N][6N] (16-byte aligned base)
+ *       reward                   float [B][N]     shared reward, broadcast to every agent
+ *       indiv_reward             float [B][N]     info_n[i]['individual_reward']   (may be NULL)
+ *       done                     uint8 [B][N]     current_step >= world_length
+ *       near_lm, near_ag         int32 [B][N]     landmark-index assignments        (may be NULL)
+ *       hd_idx                   int32 [B][4]     Hausdorff witness indices         (may be NULL)
+ */
+#ifndef FORMATION_HIP_H_
+#define FORMATION_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FG_ABI_VERSION 1
+#define FG_MAX_AGENTS 1024
+
+typedef enum FgStatus {
+    FG_OK = 0,
+    FG_ERR_BAD_ARG = -1,        /* NULL pointer, B <= 0, K <= 0, bad params            */
+    FG_ERR_UNSUPPORTED_N = -2,  /* N < 2 or N > FG_MAX_AGENTS                          */
+    FG_ERR_ALIGNMENT = -3,      /* obs base not 16-byte aligned                        */
+    FG_ERR_HIP = -4             /* a HIP runtime call failed (see fg_last_error)       */
+} FgStatus;
+
+/* Physics / scenario constants.  Field -> reference source:
+ *   dt              core.py:125            damping         core.py:127
+ *   contact_force   core.py:129            contact_margin  core.py:130
+ *   sensitivity     environment.py:218-221 mass            core.py:69,73-75
+ *   dist_min        core.py:307 (size_a + size_b, force contact distance)
+ *   collide_thresh  formation_hd_env.py:121 ((size_a+size_b)/2) or
+ *                   basic_formation_env.py:91 (size_a+size_b)
+ *   world_length    formation_hd_env.py:13,16 / core.py:113
+ *   auto_reset      0: like the reference env (caller resets);
+ *                   1: vec-env worker semantics, train/maddpg-v2/utils/env_wrappers.py:14-18
+ *                      (when done: re-initialise the env on device and return the RESET
+ *                      observation together with the pre-reset reward/done)
+ *   seed, rng_offset  counter-RNG key / per-call offset for the device-side reset
+ *                   (distributional parity with formation_hd_env.py:77-95 only)          */
+typedef struct FgParams {
+    float dt;
+    float damping;
+    float contact_force;
+    float contact_margin;
+    float sensitivity;
+    float mass;
+    float dist_min;
+    float collide_thresh;
+    int32_t world_length;
+    int32_t auto_reset;
+    uint64_t seed;
+    uint64_t rng_offset;
+} FgParams;
+
+/* library / diagnostics --------------------------------------------------- */
+int fg_abi_version(void);
+const char* fg_last_error(void);
+/* Launch geometry the library will use for N agents: threads per workgroup,
+ * environments per workgroup, dynamic LDS bytes.  Returns FgStatus. */
+int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes);
+/* Algorithmic bytes per env-step of fg_step_hd (24 N^2 + 53 N + 16). */
+int64_t fg_step_hd_bytes(int N);
+
+/* MultiAgentEnv.step for formation_hd_env, all B envs, ONE fused launch:
+ * _set_action (environment.py:187-236) -> World.step (core.py:206-225:
+ * apply_action_force :228-237, apply_environment_force :240-262 with
+ * get_entity_collision_force :289-322, integrate_state :264-277,
+ * update_agent_state :279-286) -> Scenario.observation / reward / done for every
+ * agent (formation_hd_env.py:38-75, environment.py:126-138,172-178).
+ * State (pos/vel/step, and ideal_shape/ideal_vel when auto_reset) is updated in place. */
+int fg_step_hd(const FgParams* params, int B, int N,
+               float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+               const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+               float* obs, float* reward, float* indiv_reward, uint8_t* done,
+               int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream);
+
+/* World.step only (core.py:206-225) incl. the action scaling of
+ * environment.py:216-221; for per-stage parity tests.  Updates pos/vel in place. */
+int fg_physics_step(const FgParams* params, int B, int N,
+                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                    const float* act, void* stream);
+
+/* Scenario.observation + Scenario.reward + _get_done on the CURRENT state, no
+ * physics and no step increment (formation_hd_env.py:38-75; what env.reset()
+ * returns, environment.py:154-155).  reward/indiv_reward/done may be NULL. */
+int fg_observe_hd(const FgParams* params, int B, int N,
+                  const float* pos_x, const float* pos_y, const float* vel_x, const float* vel_y,
+                  const float* ideal_shape, const float* ideal_vel, const int32_t* step,
+                  float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                  int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream);
+
+/* K consecutive env.step calls in ONE launch (the caller's rollout loop,
+ * test.py:17-28 / train/maddpg-v2/main.py:77-91) with pre-staged actions.
+ *   act_seq [K][B][N][2]; obs_seq [K][B][N][6N]; reward_seq, indiv_seq [K][B][N];
+ *   done_seq [K][B][N].  If obs_every > 1 only steps k with (k+1) % obs_every == 0
+ *   write an observation (into slot k / obs_every); rewards/dones are always written. */
+int fg_rollout_hd(const FgParams* params, int B, int N, int K,
+                  float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                  const float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
+                  float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                  int obs_every, void* stream);
+
+/* Scenario.reset_world on device for the envs whose mask byte is non-zero
+ * (mask NULL = all), counter-based RNG (formation_hd_env.py:77-95 draw
+ * distribution: pos ~ U(-1,1)^2, vel = 0, ideal_shape = centred U(-1,1)^2,
+ * ideal_vel ~ U(-1,1)^2, step = 0). */
+int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
+                float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                float* ideal_shape, float* ideal_vel, int32_t* step, void* stream);
+
+/* MultiAgentEnv.step for basic_formation_env (BASELINE config 1):
+ * same physics; observation basic_formation_env.py:29-41, reward :43-52.
+ *   landmarks float [B][L][2]; obs float [B][N][4 + 2L + 4(N-1)]. */
+int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
+                  float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                  const float* act, const float* landmarks, int32_t* step,
+                  float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                  int32_t* near_ag, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FORMATION_HIP_H_ */

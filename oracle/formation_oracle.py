@@ -200,7 +200,12 @@ def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64):
     i2 = colmin.argmax(1); j2 = near_ag[np.arange(B), i2]      # (shape idx, agent idx)
     Ds = np.sort(D, axis=2); Ds0 = np.sort(D, axis=1)
     off = np.abs(PD - thr) + np.eye(N)[None]
-    return dict(indiv=indiv, shared=shared, hd=np.stack([h1, h2], 1),
+    rs = np.sort(rowmin, 1); cs = np.sort(colmin, 1)
+    ar = np.arange(B)
+    # margin by which the witness indices are determined (max side and its inner argmin)
+    hd_gap = np.stack([np.minimum(rs[:, -1] - rs[:, -2], (Ds[:, :, 1] - Ds[:, :, 0])[ar, i1]),
+                       np.minimum(cs[:, -1] - cs[:, -2], (Ds0[:, 1, :] - Ds0[:, 0, :])[ar, i2])], 1)
+    return dict(indiv=indiv, shared=shared, hd=np.stack([h1, h2], 1), hd_gap=hd_gap,
                 hd_idx=np.stack([i1, j1, i2, j2], 1).astype(np.int32),
                 near_lm=near_lm.astype(np.int32), near_ag=near_ag.astype(np.int32),
                 cnt=cnt.astype(np.int32), gap_lm=Ds[:, :, 1] - Ds[:, :, 0],

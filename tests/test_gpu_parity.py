@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path (through the C ABI and the Python env shell)
+against the golden fixtures captured from the reference and against the CPU
+oracle.  Run with `pytest -m gpu` on an MI355X.
+
+Tolerances (BASELINE.json north_star): 1e-5 abs in fp32 for state, observations
+and individual rewards, checked PER STEP with the state re-seeded from the
+reference (teacher forcing) and free-running over a short horizon - stiff
+contact springs make longer fp32 trajectories diverge chaotically (SURVEY.md
+7.3 H1).  The shared reward is a sum of N individual rewards (|r| up to ~270 at
+N=243, fp32 ulp 3e-5), so it is checked at 1e-5 relative + 1e-5 abs (H2).
+done masks are bit-exact; landmark-index assignments are bit-exact except
+where the reference's own top-2 gap is < 1e-6 (a genuine fp32 near-tie, H5).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import formation_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+HD_CASES = ["hd_n3", "hd_n9", "hd_n27", "hd_n81", "hd_n9_crowd", "hd_n27_crowd",
+            "hd_n81_crowd", "hd_n243", "hd_n4", "hd_n10"]
+
+
+def _make(N, B, scenario="formation_hd_env"):
+    import formation_gym
+    return formation_gym.make_env(scenario, False, N, num_envs=B, device="cuda:0")
+
+
+def _load(env, pos, vel, shape, ivel, step):
+    env.world.set_state(pos, vel)
+    env.scenario.set_formation(env.world, shape, ivel)
+    env.world.step_count.copy_(torch.as_tensor(np.asarray(step, dtype=np.int32)))
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _check_indices(got, want, gap, what):
+    bad = got != want
+    if bad.any():
+        assert (gap[bad] < 1e-6).all(), "%s mismatch away from a near-tie" % what
+
+
+@pytest.mark.parametrize("name", HD_CASES)
+def test_step_teacher_forced(golden, name):
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    env.enable_assignments(True)
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        _load(env, prev_pos, prev_vel, g["ideal_shape"], g["ideal_vel"], np.full(B, t))
+        act = torch.as_tensor(g["acts"][t]).cuda()
+        obs, rew, done, info = env.step(act)
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL * 10)
+        # rewards are functions of the post-step state; compare on the GPU's own state
+        # against the oracle evaluated on that same fp32 state ...
+        r = O.reward_hd(_np(pos), _np(vel), g["ideal_shape"].astype(np.float32).astype(np.float64),
+                        g["ideal_vel"].astype(np.float32).astype(np.float64), O.HdParams())
+        margin_ok = r["cnt_margin"] > 1e-6
+        ind = _np(info["individual_reward"])
+        np.testing.assert_allclose(ind[margin_ok], r["indiv"][margin_ok], rtol=0, atol=ATOL)
+        # ... and against the reference's numbers where no collision count sits on the edge
+        ref_ok = g["cnt_margin"][t] > 1e-5
+        np.testing.assert_allclose(ind[ref_ok], g["indiv"][t][ref_ok], rtol=0, atol=5 * ATOL)
+        np.testing.assert_allclose(_np(rew)[ref_ok, :, 0], g["shared"][t][ref_ok], rtol=1e-5, atol=5 * ATOL)
+        assert rew.shape == (B, N, 1) and done.shape == (B, N) and done.dtype == torch.bool
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+        _check_indices(env._out["near_lm"].cpu().numpy(), r["near_lm"], r["gap_lm"], "near_lm")
+        _check_indices(env._out["near_ag"].cpu().numpy(), r["near_ag"], r["gap_ag"], "near_ag")
+        hd = env._out["hd_idx"].cpu().numpy()
+        tie = r["hd_gap"].min(1) < 1e-6
+        np.testing.assert_array_equal(hd[~tie], r["hd_idx"][~tie])
+        if (t + 1) in g["obs_steps"]:
+            want = O.observation_hd(_np(pos), _np(vel), g["ideal_shape"], g["ideal_vel"])
+            np.testing.assert_allclose(_np(obs), want, rtol=0, atol=2e-7)       # same fp32 state
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=2 * ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+@pytest.mark.parametrize("name", ["hd_n3", "hd_n9", "hd_n27", "hd_n81", "hd_n27_crowd", "hd_n4"])
+def test_free_running_short_horizon(golden, name):
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    H = 8 if "crowd" in name else 10
+    for t in range(min(H, T)):
+        env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        tol = (2e-4 if "crowd" in name else 2e-5)        # contacts amplify fp32 rounding (H1)
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=tol)
+    assert (env.world.step_count.cpu().numpy() == min(H, T)).all()
+
+
+def test_done_flips_at_world_length(golden):
+    g = golden("hd_n3_done")
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    for t in range(T):
+        _, _, done, _ = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])     # bit-exact
+    assert env.world_length == 100
+
+
+@pytest.mark.parametrize("N,B", [(9, 7), (27, 5), (81, 3), (10, 6), (100, 2)])
+def test_split_stages_equal_fused(N, B):
+    """fg_physics_step + fg_observe_hd == fg_step_hd, bit for bit."""
+    rs = np.random.RandomState(N)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    st["pos"] *= 0.3
+    act = torch.as_tensor(rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)).cuda()
+    fused = _make(N, B); _load(fused, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    split = _make(N, B); _load(split, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    obs, rew, done, info = fused.step(act)
+    split.world.action_u.copy_(act)
+    split.world.step()
+    out = dict(obs=torch.empty_like(obs), reward=torch.empty((B, N), device="cuda"),
+               indiv=torch.empty((B, N), device="cuda"))
+    split.scenario.observe_batch(split.world, out)
+    for a, b in zip(fused.world.get_state(), split.world.get_state()):
+        assert torch.equal(a, b)
+    assert torch.equal(obs, out["obs"])
+    assert torch.equal(rew[..., 0], out["reward"])
+    assert torch.equal(info["individual_reward"], out["indiv"])
+    # per-agent plugin callbacks return that agent's slice
+    ag = fused.agents[N // 2]
+    assert torch.equal(fused._get_obs(ag), obs[:, ag.i])
+    assert torch.equal(fused._get_reward(ag), info["individual_reward"][:, ag.i])
+
+
+@pytest.mark.parametrize("N,B,K", [(9, 10, 6), (27, 6, 5), (81, 2, 4), (243, 2, 3)])
+def test_rollout_equals_single_steps(N, B, K):
+    rs = np.random.RandomState(100 + N)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    st["pos"] *= 0.4
+    acts = torch.as_tensor(rs.uniform(-1, 1, (K, B, N, 2)).astype(np.float32)).cuda()
+    a = _make(N, B); _load(a, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    b = _make(N, B); _load(b, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    out = dict(obs=torch.empty((K, B, N, 6 * N), device="cuda"), reward=torch.empty((K, B, N), device="cuda"),
+               indiv=torch.empty((K, B, N), device="cuda"),
+               done=torch.zeros((K, B, N), dtype=torch.uint8, device="cuda"))
+    b.scenario.rollout_batch(b.world, acts, out)
+    for k in range(K):
+        obs, rew, done, info = a.step(acts[k])
+        assert torch.equal(obs, out["obs"][k])
+        assert torch.equal(rew[..., 0], out["reward"][k])
+        assert torch.equal(info["individual_reward"], out["indiv"][k])
+        assert torch.equal(done, out["done"][k].bool())
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    assert torch.equal(a.world.step_count, b.world.step_count)
+    # obs_every: only every 2nd observation is written
+    c = _make(N, B); _load(c, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    out2 = dict(obs=torch.zeros((K // 2, B, N, 6 * N), device="cuda"), reward=torch.empty((K, B, N), device="cuda"))
+    c.scenario.rollout_batch(c.world, acts, out2, obs_every=2)
+    for s in range(K // 2):
+        assert torch.equal(out2["obs"][s], out["obs"][2 * s + 1])
+    assert torch.equal(out2["reward"], out["reward"])
+
+
+@pytest.mark.parametrize("N,B", [(27, 4096), (9, 4096), (81, 256), (243, 96), (3, 1000)])
+def test_full_size_against_oracle_and_invariants(N, B):
+    """BASELINE-size batches: fp64 oracle on every env + size-independent properties."""
+    seeds = 1 + 1000 * np.arange(B)
+    st = O.reset_hd(seeds, N)
+    rs = np.random.RandomState(0)
+    act = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+    env = _make(N, B)
+    _load(env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    obs, rew, done, info = env.step(torch.as_tensor(act).cuda())
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    st32 = dict(st, pos=f32(st["pos"]), ideal_shape=f32(st["ideal_shape"]), ideal_vel=f32(st["ideal_vel"]))
+    chunk = 64 if N >= 81 else 1024
+    pos, vel = (_np(x) for x in env.world.get_state())
+    ind = _np(info["individual_reward"]); shared = _np(rew)[..., 0]; o = _np(obs)
+    for s in range(0, B, chunk):
+        sl = slice(s, min(B, s + chunk))
+        sub = {k: v[sl] for k, v in st32.items()}
+        new, out = O.step_hd(sub, act[sl].astype(np.float64))
+        np.testing.assert_allclose(pos[sl], new["pos"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(vel[sl], new["vel"], rtol=0, atol=10 * ATOL)
+        ok = out["cnt_margin"] > 1e-5
+        np.testing.assert_allclose(ind[sl][ok], out["indiv"][ok], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(shared[sl][ok], out["reward"][ok][..., 0], rtol=1e-5, atol=ATOL)
+        np.testing.assert_allclose(o[sl], out["obs"], rtol=0, atol=2 * ATOL)
+    # invariants
+    assert not done.any()
+    np.testing.assert_allclose(ind.sum(1), shared[:, 0], rtol=2e-6, atol=1e-4)   # shared = sum of individuals
+    assert (shared == shared[:, :1]).all()                                      # broadcast to every agent
+    assert (o[:, :, 2 * N:4 * N - 2] == 0).all()                                # comm block
+    assert (o[:, :, 4 * N - 2:6 * N - 2] == f32(st["ideal_shape"]).reshape(B, 1, 2 * N)).all()
+    assert (o[:, :, 6 * N - 2:] == f32(st["ideal_vel"])[:, None]).all()
+    assert (o[:, :, 0:2] == vel).all()
+    # antisymmetry of the relative-position block: obs_i[j] = -obs_j[i]
+    i, j = 0, N - 1
+    np.testing.assert_array_equal(o[:, i, 2 + 2 * (j - 1):4 + 2 * (j - 1)], -o[:, j, 2 + 2 * i:4 + 2 * i])
+    # batch independence: the same envs in a smaller batch give bit-identical results
+    nb = min(B, 37)
+    env2 = _make(N, nb)
+    _load(env2, st["pos"][:nb], st["vel"][:nb], st["ideal_shape"][:nb], st["ideal_vel"][:nb], st["step"][:nb])
+    obs2, rew2, _, info2 = env2.step(torch.as_tensor(act[:nb]).cuda())
+    assert torch.equal(obs2, obs[:nb]) and torch.equal(rew2, rew[:nb])
+    assert torch.equal(info2["individual_reward"], info["individual_reward"][:nb])
+
+
+def test_reference_style_api_single_env(golden):
+    """num_envs == 1: list-in / list-out exactly like the reference."""
+    g = golden("hd_n9")
+    import formation_gym
+    env = formation_gym.make_env("formation_hd_env", benchmark=False, num_agents=9)
+    assert env.num_envs == 1 and env.num_agents == 9 and env.world_length == 100
+    assert env.observation_space[0].shape == (54,) and env.share_observation_space[0].shape == (486,)
+    assert env.action_space[0].shape == (2,) and env.action_space[0].sample().dtype == np.float32
+    env.seed(int(g["seed"]))
+    obs_n = env.reset()
+    assert isinstance(obs_n, list) and len(obs_n) == 9 and obs_n[0].shape == (54,) and obs_n[0].dtype == np.float64
+    np.testing.assert_allclose(np.array(obs_n), g["obs0"][0], rtol=0, atol=ATOL)   # same MT19937 stream
+    for t in range(5):
+        act_n = [g["acts"][t, 0, i].astype(np.float64).copy() for i in range(9)]
+        keep = [a.copy() for a in act_n]
+        obs_n, rew_n, done_n, info_n = env.step(act_n)
+        np.testing.assert_allclose(np.array(act_n), 5.0 * np.array(keep))          # scaled in place
+        np.testing.assert_allclose(np.array([x['individual_reward'] for x in info_n]), g["indiv"][t, 0], atol=5 * ATOL)
+        assert rew_n[0] == rew_n[8] and isinstance(rew_n[0], list)
+        np.testing.assert_allclose(rew_n[0][0], g["shared"][t, 0, 0], rtol=1e-5, atol=ATOL)
+        assert done_n == [False] * 9
+    with pytest.raises(TypeError):
+        env.step([[0.0, 0.0]] * 9)                                                # lists rejected like the reference
+
+
+def test_seeded_reset_matches_reference_stream(golden):
+    g = golden("reset")
+    import formation_gym
+    for seed, N in g["cases"]:
+        env = formation_gym.make_env("formation_hd_env", False, int(N), num_envs=2, device="cuda:0")
+        env.seed(int(seed))
+        obs = env.reset()
+        key = "s%d_n%d" % (seed, N)
+        np.testing.assert_allclose(_np(obs[0]), g[key + "_obs"], rtol=0, atol=1e-6)
+        # env 1 uses seed + 1000 (worker convention); (1, 9)+1000 = (1001, 9) is also a fixture
+        if (seed + 1000, N) in [tuple(c) for c in g["cases"]]:
+            np.testing.assert_allclose(_np(obs[1]), g["s%d_n%d_obs" % (seed + 1000, N)], rtol=0, atol=1e-6)
+
+
+def test_basic_formation_env(golden):
+    g = golden("basic_n3")
+    env = _make(3, 1, "basic_formation_env")
+    assert env.world_length == 50 and env.observation_space[0].shape == (18,)
+    env.world.set_state(g["pos0"], g["vel0"])
+    env.world.landmark_pos.copy_(torch.as_tensor(g["landmarks"], dtype=torch.float32))
+    env.world.step_count.zero_()
+    out = {"obs": env._out["obs"], "reward": env._out["reward"]}
+    env.scenario.observe_batch(env.world, out)
+    np.testing.assert_allclose(_np(out["obs"]), g["obs0"], rtol=0, atol=ATOL)
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(g["acts"].shape[0]):
+        env.world.set_state(prev_pos, prev_vel)
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(info["individual_reward"]), g["indiv"][t], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=1e-5, atol=2 * ATOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+def test_auto_reset_vec_env_semantics():
+    """Device-side reset: reset obs with pre-reset reward/done, fresh state in range."""
+    from formation_gym.vec_env import FormationVecEnv
+    N, B = 9, 64
+    env = _make(N, B)
+    env.seed(3)
+    venv = FormationVecEnv(env, reset_mode="device")
+    venv.reset()
+    env.world.step_count.fill_(98)
+    act = torch.zeros((B, N, 2), device="cuda")
+    obs, rew, done, info = venv.step(act)
+    assert not done.any()
+    shape_before = env.scenario.ideal_shape.clone()
+    obs, rew, done, info = venv.step(act)
+    assert done.all()                                         # pre-reset done
+    assert (env.world.step_count == 0).all()
+    pos, vel = env.world.get_state()
+    assert (vel == 0).all() and (pos.abs() <= 1).all() and pos.std() > 0.4
+    assert not torch.equal(shape_before, env.scenario.ideal_shape)
+    np.testing.assert_allclose(_np(env.scenario.ideal_shape.mean(1)), 0, atol=1e-6)
+    want = O.observation_hd(_np(pos), _np(vel), _np(env.scenario.ideal_shape), _np(env.scenario.ideal_vel))
+    np.testing.assert_allclose(_np(obs), want, rtol=0, atol=1e-6)    # obs is the RESET observation
+    assert torch.isfinite(rew).all()
+    # envs differ from each other and from the next reset
+    assert pos[0].ne(pos[1]).any()
+    env.world.step_count.fill_(99)
+    venv.step(act)
+    pos2, _ = env.world.get_state()
+    assert pos2.ne(pos).any()
+
+
+def test_host_reset_vec_env_parity_mode():
+    from formation_gym.vec_env import FormationVecEnv
+    N, B = 3, 4
+    env = _make(N, B)
+    env.seed(11)
+    venv = FormationVecEnv(env, reset_mode="host")
+    venv.reset()
+    env.world.step_count[1] = 99
+    obs, rew, done, info = venv.step(torch.zeros((B, N, 2), device="cuda"))
+    assert done[1].all() and not done[0].any()
+    assert int(env.world.step_count[1]) == 0 and int(env.world.step_count[0]) == 1
+    # env 1 continued its own MT19937 stream: second draw block of RandomState(11 + 1000)
+    rs = np.random.RandomState(11 + 1000); rs.uniform(-1, 1, (2 * N + 1, 2))
+    want = rs.uniform(-1, 1, (N, 2))
+    pos, _ = env.world.get_state()
+    np.testing.assert_allclose(_np(pos[1]), want, atol=1e-6)
+
+
+def test_nan_on_coincident_agents_like_reference():
+    """core.py:312: two agents at the same point -> 0/0 -> NaN state."""
+    N, B = 3, 2
+    env = _make(N, B)
+    pos = np.array([[[0.1, 0.1], [0.1, 0.1], [0.5, 0.5]], [[0.0, 0.0], [0.3, 0.3], [0.6, 0.6]]])
+    _load(env, pos, np.zeros((B, N, 2)), np.zeros((B, N, 2)), np.zeros((B, 2)), np.zeros(B))
+    env.step(torch.zeros((B, N, 2), device="cuda"))
+    p, _ = env.world.get_state()
+    assert torch.isnan(p[0, 0]).all() and torch.isnan(p[0, 1]).all() and torch.isfinite(p[0, 2]).all()
+    assert torch.isfinite(p[1]).all()
+
+
+def test_bfs_policy_closed_loop_on_device():
+    """The built-in hierarchical controller, batched on the GPU, reduces the formation error."""
+    import formation_gym
+    N, B = 9, 32
+    env = _make(N, B)
+    env.seed(5)
+    obs = env.reset()
+    first = None
+    for t in range(60):
+        act = formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3).float().contiguous()
+        obs, rew, done, info = env.step(act)
+        if first is None:
+            first = rew[:, 0, 0].clone()
+    assert (rew[:, 0, 0] > first).float().mean() > 0.9
