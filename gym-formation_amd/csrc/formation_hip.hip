@@ -29,11 +29,12 @@
 namespace fg {
 
 #define FG_DEV __device__ __forceinline__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Args {
     FgParams p;
     int B, N, K, obs_every;
-    int do_phys, do_post;
+    int do_phys, do_post, nt_store;
     float* px; float* py; float* vx; float* vy;
     const float* act;          // [K][B][N][2]
     float* shape;              // [B][N][2]
@@ -64,10 +65,10 @@ FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
     constexpr int W = (G <= 64) ? G : 64;
 #pragma unroll
     for (int m = W / 2; m > 0; m >>= 1) {
-        if (NV > 0) v[0] = combine<OP0>(v[0], __shfl_xor(v[0], m, 64));
-        if (NV > 1) v[1] = combine<OP1>(v[1], __shfl_xor(v[1], m, 64));
-        if (NV > 2) v[2] = combine<OP2>(v[2], __shfl_xor(v[2], m, 64));
-        if (NV > 3) v[3] = combine<OP3>(v[3], __shfl_xor(v[3], m, 64));
+        if constexpr (NV > 0) v[0] = combine<OP0>(v[0], __shfl_xor(v[0], m, 64));
+        if constexpr (NV > 1) v[1] = combine<OP1>(v[1], __shfl_xor(v[1], m, 64));
+        if constexpr (NV > 2) v[2] = combine<OP2>(v[2], __shfl_xor(v[2], m, 64));
+        if constexpr (NV > 3) v[3] = combine<OP3>(v[3], __shfl_xor(v[3], m, 64));
     }
     if (G > 64) {
         constexpr int NW = T / 64;
@@ -80,10 +81,10 @@ FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) v[q] = scratch[q];
         for (int w = 1; w < NW; ++w) {
-            if (NV > 0) v[0] = combine<OP0>(v[0], scratch[w * 4 + 0]);
-            if (NV > 1) v[1] = combine<OP1>(v[1], scratch[w * 4 + 1]);
-            if (NV > 2) v[2] = combine<OP2>(v[2], scratch[w * 4 + 2]);
-            if (NV > 3) v[3] = combine<OP3>(v[3], scratch[w * 4 + 3]);
+            if constexpr (NV > 0) v[0] = combine<OP0>(v[0], scratch[w * 4 + 0]);
+            if constexpr (NV > 1) v[1] = combine<OP1>(v[1], scratch[w * 4 + 1]);
+            if constexpr (NV > 2) v[2] = combine<OP2>(v[2], scratch[w * 4 + 2]);
+            if constexpr (NV > 3) v[3] = combine<OP3>(v[3], scratch[w * 4 + 3]);
         }
         __syncthreads();   // scratch is reused by the next reduction
     }
@@ -135,26 +136,27 @@ FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, flo
 // ---------------------------------------------------------------------------
 // the fused step / rollout kernel
 //   NC  compile-time agent count (0 = run-time a.N)
-//   G   lanes reserved per environment (power of two >= N when N <= 64, else T)
-//   T   threads per workgroup;  E = T / G environments per workgroup
+//   G   lanes reserved per environment for the per-agent phases (power of two >= N)
+//   T   threads per workgroup (>= E * G); ALL T threads stream observations
+//   E   environments per workgroup
 //   IDX also emit the landmark-index assignments
 // LDS per env (float2 units): PRE[N] | A[3N] = post pos[N], zeros[N-1], shape[N], ivel[1] | V[N]
 // so that observation unit u >= N of any row is A[u] and unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-template <int NC, int G, int T, bool IDX>
+template <int NC, int G, int T, int E, bool IDX>
 __global__ __launch_bounds__(T) void step_kernel(const Args a) {
-    constexpr int E = T / G;
+    static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int N = NC ? NC : a.N;
     const int tid = threadIdx.x;
-    const int e = (G >= T) ? 0 : tid / G;
-    const int i = (G >= T) ? tid : tid % G;
+    const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
+    const int i = (E == 1) ? tid : tid % G;
     const int b0 = blockIdx.x * E;
     const int b = b0 + e;
-    const bool valid = (b < a.B) && (i < N);
+    const bool valid = (e < E) && (b < a.B) && (i < N);
     const int El = min(E, a.B - b0);
 
-    float2* const env_lds = smem + e * 5 * N;
+    float2* const env_lds = smem + (e < E ? e : 0) * 5 * N;
     float2* const PRE = env_lds;
     float2* const A = env_lds + N;
     float2* const V = A + 3 * N;
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
         }
     }
-    if (b < a.B && a.step) t_step = a.step[b];
+    if (e < E && b < a.B && a.step) t_step = a.step[b];
     __syncthreads();
 
     for (int k = 0; k < a.K; ++k) {
@@ -301,37 +303,48 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             bool want_obs = a.obs != nullptr;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
-                const unsigned n3 = 3u * N;                // units per row
-                const unsigned nenv = n3 * N;              // units per env
+                const unsigned n3 = 3u * N;                // (x,y) units per row
+                const unsigned nenv = n3 * N;              // units per env = N rows
                 const size_t U0 = ((size_t)slot * a.B + b0) * nenv;
                 const unsigned total = (unsigned)El * nenv;
-                const unsigned head = (unsigned)(U0 & 1);
+                const unsigned head = (unsigned)(U0 & 1);  // region start not 16-byte aligned
                 float2* const out2 = reinterpret_cast<float2*>(a.obs) + U0;
-                auto unit = [&](unsigned q) -> float2 {
-                    const unsigned ee = (E == 1) ? 0u : q / nenv;
-                    const unsigned r = q - ee * nenv;
-                    const unsigned row = r / n3;
-                    const unsigned u = r - row * n3;
+                // unit (rp, u): rp = e*N + row is the row index inside the group, u the unit in
+                // the row.  Branch-free so that the LDS reads of several units overlap.
+                auto unit = [&](unsigned rp, unsigned u) -> float2 {
+                    const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
+                    const unsigned row = rp - ee * N;
                     const float2* AA = smem + ee * 5 * N + N;
-                    unsigned idx = u;
-                    if (u < (unsigned)N) {
-                        const unsigned j = u - 1u;
-                        idx = (u == 0u) ? (n3 + row) : (j + (j >= row ? 1u : 0u));
-                    }
+                    const unsigned j = u - 1u;
+                    const bool is_delta = j < (unsigned)(N - 1);
+                    unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
+                    idx = (u == 0u) ? n3 + row : idx;
                     float2 val = AA[idx];
                     const float2 pi = AA[row];
-                    if (u - 1u < (unsigned)(N - 1)) { val.x -= pi.x; val.y -= pi.y; }
+                    val.x -= is_delta ? pi.x : 0.0f;
+                    val.y -= is_delta ? pi.y : 0.0f;
                     return val;
                 };
-                if (head && tid == 0) out2[0] = unit(0);
+                if (head && tid == 0) out2[0] = unit(0u, 0u);
                 const unsigned npair = (total - head) >> 1;
-                float4* const out4 = reinterpret_cast<float4*>(out2 + head);
+                f32x4* const out4 = reinterpret_cast<f32x4*>(out2 + head);
+                const unsigned du = (2u * T) % n3, drow = (2u * T) / n3;
+                unsigned q = head + 2u * tid;
+                unsigned rp = q / n3;
+                unsigned u = q - rp * n3;
+#pragma unroll 2
                 for (unsigned q2 = tid; q2 < npair; q2 += T) {
-                    const unsigned q = head + 2u * q2;
-                    const float2 x0 = unit(q), x1 = unit(q + 1u);
-                    out4[q2] = make_float4(x0.x, x0.y, x1.x, x1.y);
+                    unsigned u1 = u + 1u, rp1 = rp;
+                    if (u1 == n3) { u1 = 0u; rp1 += 1u; }
+                    const float2 x0 = unit(rp, u), x1 = unit(rp1, u1);
+                    const f32x4 w = {x0.x, x0.y, x1.x, x1.y};
+                    if (a.nt_store) __builtin_nontemporal_store(w, &out4[q2]);
+                    else out4[q2] = w;
+                    u += du; rp += drow;
+                    if (u >= n3) { u -= n3; rp += 1u; }
                 }
-                if (((total - head) & 1u) && tid == T - 1) out2[total - 1] = unit(total - 1);
+                if (((total - head) & 1u) && tid == T - 1)
+                    out2[total - 1] = unit((total - 1) / n3, (total - 1) % n3);
             }
         }
 
@@ -497,55 +510,63 @@ struct Geometry { int G, T, E, lds; };
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-static int env_int(const char* name, int dflt) {
-    const char* s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
-}
-
-static bool geometry_for(int N, Geometry* g) {
-    if (N < 2 || N > FG_MAX_AGENTS) return false;
-    if (N <= 64) {
-        g->G = pow2ceil(N) < 4 ? 4 : pow2ceil(N);
-        g->T = 64;
-        if (N == 27) { int t = env_int("FG_T27", 128); g->T = (t == 64 || t == 128 || t == 256) ? t : 128; }
-    } else {
-        g->G = g->T = pow2ceil(N) < 128 ? 128 : pow2ceil(N);
-    }
-    g->E = g->T / g->G;
-    g->lds = g->E * 5 * N * (int)sizeof(float2) + 64 * 4 * (int)sizeof(float);
-    return true;
-}
-
-template <int NC, int G, int T>
-static hipError_t launch_cfg(const Args& a, bool idx, int grid, int lds, hipStream_t st) {
-    if (idx) hipLaunchKernelGGL((step_kernel<NC, G, T, true>), dim3(grid), dim3(T), lds, st, a);
-    else     hipLaunchKernelGGL((step_kernel<NC, G, T, false>), dim3(grid), dim3(T), lds, st, a);
+template <int NC, int G, int T, int E, bool IDX>
+static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX>), dim3(grid), dim3(T), lds, st, a);
     return hipGetLastError();
 }
 
-static int launch_step(const Args& a, hipStream_t st) {
+using LaunchFn = hipError_t (*)(const Args&, int, int, hipStream_t);
+struct Variant { int NC, G, T, E; LaunchFn plain, idx; };
+#define FG_VARIANT(NC, G, T, E) {NC, G, T, E, &launch_v<NC, G, T, E, false>, &launch_v<NC, G, T, E, true>}
+
+// The first entry of a given NC is the default; the others are selectable with
+// FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
+static const Variant kVariants[] = {
+    FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8), FG_VARIANT(3, 4, 128, 16),
+    FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 4), FG_VARIANT(9, 16, 128, 8),
+    FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
+    FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 256, 4), FG_VARIANT(27, 32, 512, 4),
+    FG_VARIANT(81, 128, 128, 1), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
+    FG_VARIANT(243, 256, 256, 1), FG_VARIANT(243, 256, 512, 1),
+    FG_VARIANT(0, 4, 64, 16), FG_VARIANT(0, 8, 64, 8), FG_VARIANT(0, 16, 64, 4), FG_VARIANT(0, 32, 128, 4),
+    FG_VARIANT(0, 64, 128, 2), FG_VARIANT(0, 128, 128, 1), FG_VARIANT(0, 256, 256, 1),
+    FG_VARIANT(0, 512, 512, 1), FG_VARIANT(0, 1024, 1024, 1),
+};
+
+static const Variant* variant_for(int N) {
+    if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
+    int want_t = 0, want_e = 0;
+    if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
+    const Variant* dflt = nullptr;
+    for (const Variant& v : kVariants) {
+        if (v.NC != N) continue;
+        if (!dflt) dflt = &v;
+        if (v.T == want_t && v.E == want_e) return &v;
+    }
+    if (dflt) return dflt;
+    const int G = N <= 64 ? (pow2ceil(N) < 4 ? 4 : pow2ceil(N)) : (pow2ceil(N) < 128 ? 128 : pow2ceil(N));
+    for (const Variant& v : kVariants)
+        if (v.NC == 0 && v.G == G) return &v;
+    return nullptr;
+}
+
+static bool geometry_for(int N, Geometry* g) {
+    const Variant* v = variant_for(N);
+    if (!v) return false;
+    g->G = v->G; g->T = v->T; g->E = v->E;
+    g->lds = v->E * 5 * N * (int)sizeof(float2) + 16 * 4 * (int)sizeof(float);
+    return true;
+}
+
+static int launch_step(Args a, hipStream_t st) {
     Geometry g;
-    if (!geometry_for(a.N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const Variant* v = variant_for(a.N);
+    if (!v || !geometry_for(a.N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
     const int grid = (a.B + g.E - 1) / g.E;
-    hipError_t err = hipSuccess;
-    const int N = a.N;
-    if (N == 3) err = launch_cfg<3, 4, 64>(a, idx, grid, g.lds, st);
-    else if (N == 9) err = launch_cfg<9, 16, 64>(a, idx, grid, g.lds, st);
-    else if (N == 27 && g.T == 64) err = launch_cfg<27, 32, 64>(a, idx, grid, g.lds, st);
-    else if (N == 27 && g.T == 128) err = launch_cfg<27, 32, 128>(a, idx, grid, g.lds, st);
-    else if (N == 27 && g.T == 256) err = launch_cfg<27, 32, 256>(a, idx, grid, g.lds, st);
-    else if (N == 81) err = launch_cfg<81, 128, 128>(a, idx, grid, g.lds, st);
-    else if (N == 243) err = launch_cfg<243, 256, 256>(a, idx, grid, g.lds, st);
-    else if (g.G == 4) err = launch_cfg<0, 4, 64>(a, idx, grid, g.lds, st);
-    else if (g.G == 8) err = launch_cfg<0, 8, 64>(a, idx, grid, g.lds, st);
-    else if (g.G == 16) err = launch_cfg<0, 16, 64>(a, idx, grid, g.lds, st);
-    else if (g.G == 32) err = launch_cfg<0, 32, 64>(a, idx, grid, g.lds, st);
-    else if (g.G == 64) err = launch_cfg<0, 64, 64>(a, idx, grid, g.lds, st);
-    else if (g.G == 128) err = launch_cfg<0, 128, 128>(a, idx, grid, g.lds, st);
-    else if (g.G == 256) err = launch_cfg<0, 256, 256>(a, idx, grid, g.lds, st);
-    else if (g.G == 512) err = launch_cfg<0, 512, 512>(a, idx, grid, g.lds, st);
-    else err = launch_cfg<0, 1024, 1024>(a, idx, grid, g.lds, st);
+    if (const char* s = getenv("FG_NT")) a.nt_store = atoi(s);
+    const hipError_t err = (idx ? v->idx : v->plain)(a, grid, g.lds, st);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
@@ -678,7 +699,7 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     hipStream_t st = (hipStream_t)stream;
-    const int G = N <= 64 ? g.G : g.G;
+    const int G = g.G;
     int grid;
 #define FG_RESET(GG, TT) grid = (B + (TT / GG) - 1) / (TT / GG); \
     hipLaunchKernelGGL((reset_kernel<GG, TT>), dim3(grid), dim3(TT), 0, st, a, mask)
