@@ -106,9 +106,11 @@ def main():
 
     N, B = a.agents, a.envs
     env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
-    # initial states: env b of rank r is global env r*B + b, seeded 1 + 1000 * global index
-    gidx = rank * B + np.arange(B)
-    st = O.reset_hd(1 + 1000 * gidx, N)
+    # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
+    # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
+    from formation_gym import sharding
+    lo, hi = sharding.env_slice(B * world_size, rank, world_size)
+    st = O.reset_hd(sharding.global_seeds(1, lo, hi), N)
     env.world.set_state(st["pos"], st["vel"])
     env.scenario.set_formation(env.world, st["ideal_shape"], st["ideal_vel"])
     env.scenario._seed = 1 + rank

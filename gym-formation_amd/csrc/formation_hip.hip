@@ -523,10 +523,10 @@ struct Variant { int NC, G, T, E; LaunchFn plain, idx; };
 // The first entry of a given NC is the default; the others are selectable with
 // FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
 static const Variant kVariants[] = {
-    FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8), FG_VARIANT(3, 4, 128, 16),
-    FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 4), FG_VARIANT(9, 16, 128, 8),
-    FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
-    FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 256, 4), FG_VARIANT(27, 32, 512, 4),
+    FG_VARIANT(3, 4, 128, 16), FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8),
+    FG_VARIANT(9, 16, 128, 4), FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 8),
+    FG_VARIANT(27, 32, 256, 4), FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
+    FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 512, 4),
     FG_VARIANT(81, 128, 128, 1), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
     FG_VARIANT(243, 256, 256, 1), FG_VARIANT(243, 256, 512, 1),
     FG_VARIANT(0, 4, 64, 16), FG_VARIANT(0, 8, 64, 8), FG_VARIANT(0, 16, 64, 4), FG_VARIANT(0, 32, 128, 4),

@@ -1,0 +1,51 @@
+"""Multi-GPU sharding of the environment batch.
+
+Environments never interact (the reference itself runs them in separate
+processes: train/maddpg-v2/utils/env_wrappers.py:40-56), so the batch is cut
+into contiguous slices, one process per GPU, and every rank runs the same
+kernels on its slice.  No data-path collective exists; `torch.distributed` is
+used only for the timing barrier / max and for an optional host-side gather of
+small per-env results.  Per-env seeds follow the global env index
+(`seed + 1000 * b`, train/maddpg-v2/main.py:19-30), so results do not depend on
+the number of GPUs.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def env_slice(global_envs, rank, world_size):
+    """Contiguous [lo, hi) slice of the global env index range owned by `rank`
+    (sizes differ by at most one)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, rem = divmod(int(global_envs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def global_seeds(seed, lo, hi):
+    """Reset-stream seed of every env in [lo, hi): seed + 1000 * global_index."""
+    return int(seed) + 1000 * np.arange(lo, hi, dtype=np.int64)
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a python float over all ranks (the bench's slowest-rank time)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def gather_host(local, dst=0):
+    """Host-side gather of a per-env tensor [b_local, ...] to rank `dst`, in global
+    env order.  Returns the concatenation on `dst`, None elsewhere."""
+    local = local.detach().cpu()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    bucket = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(local, bucket, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    return torch.cat(bucket, dim=0)

@@ -1,0 +1,116 @@
+"""C-ABI checks that need no GPU: the library builds and loads, exports every
+symbol include/formation_hip.h declares, the ctypes mirror of FgParams has the
+C layout, and argument validation returns the documented status codes before
+any launch.  Also: the product path fails loudly without a GPU / library."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from formation_gym import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "formation_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _native.build()
+    return _native.load()
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fg_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    names = _declared_symbols()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+        assert n in _native.SIGNATURES, "ctypes binding lacks %s" % n
+    assert sorted(_native.SIGNATURES) == names
+
+
+def test_abi_version_and_struct_layout(lib):
+    assert lib.fg_abi_version() == _native.ABI_VERSION == 1
+    text = open(HEADER).read()
+    assert "#define FG_ABI_VERSION 1" in text
+    body = re.search(r"typedef struct FgParams \{(.*?)\} FgParams;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(float|int32_t|uint64_t)\s+(\w+);", body)
+    ctype = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint64_t": ctypes.c_uint64}
+    assert [(n, ctype[t]) for t, n in fields] == list(_native.FgParams._fields_)
+    assert ctypes.sizeof(_native.FgParams) == 8 * 4 + 2 * 4 + 2 * 8
+
+
+def test_algorithmic_bytes_and_geometry(lib):
+    for n, want in [(9, 2437), (27, 18943), (81, 161773), (243, 1430071)]:
+        assert _native.step_hd_bytes(n) == want == 24 * n * n + 53 * n + 16
+    for n in (3, 4, 9, 10, 27, 64, 65, 81, 243, 1024):
+        cfg = _native.kernel_config(n)
+        assert cfg["threads"] % 64 == 0 and cfg["threads"] <= 1024 and cfg["envs_per_wg"] >= 1
+        assert cfg["lds_bytes"] <= 160 * 1024
+    with pytest.raises(_native.FormationHipError) as e:
+        _native.kernel_config(1025)
+    assert e.value.code == _native.FG_ERR_UNSUPPORTED_N
+
+
+def _params(**kw):
+    d = dict(dt=0.1, damping=0.25, contact_force=100.0, contact_margin=1e-3, sensitivity=5.0, mass=1.0,
+             dist_min=0.06, collide_thresh=0.03, world_length=100, auto_reset=0, seed=0, rng_offset=0)
+    d.update(kw)
+    return _native.FgParams(**d)
+
+
+def test_argument_validation_before_any_launch(lib):
+    buf = np.zeros(4096, dtype=np.float32)
+    p = buf.ctypes.data          # host pointer: validation must reject before it is ever used
+    P = _params()
+    ok_ptrs = [p] * 16
+    assert lib.fg_step_hd(P, 0, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG                 # B <= 0
+    assert b"B must be" in lib.fg_last_error()
+    assert lib.fg_step_hd(P, 4, 2, *ok_ptrs) == _native.FG_ERR_UNSUPPORTED_N           # obs needs N >= 3
+    assert lib.fg_step_hd(P, 4, 2000, *ok_ptrs) == _native.FG_ERR_UNSUPPORTED_N
+    null_obs = list(ok_ptrs); null_obs[8] = None
+    assert lib.fg_step_hd(P, 4, 9, *null_obs) == _native.FG_ERR_BAD_ARG                # required pointer
+    mis = list(ok_ptrs); mis[8] = p + 4
+    assert lib.fg_step_hd(P, 4, 9, *mis) == _native.FG_ERR_ALIGNMENT                   # obs 16-byte aligned
+    assert b"aligned" in lib.fg_last_error()
+    assert lib.fg_step_hd(None, 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_hd(_params(mass=0.0), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_physics_step(P, 4, 1, *([p] * 6)) == _native.FG_ERR_UNSUPPORTED_N
+    assert lib.fg_observe_hd(P, 4, 9, p, p, p, p, p, p, p, None, None, None, None, None, None, None, None) \
+        == _native.FG_ERR_BAD_ARG                                                      # nothing to write
+    assert lib.fg_rollout_hd(P, 4, 9, 0, *([p] * 12), 1, None) == _native.FG_ERR_BAD_ARG   # K <= 0
+    assert lib.fg_reset_hd(P, 4, 5000, *([p] * 9)) == _native.FG_ERR_UNSUPPORTED_N
+    assert lib.fg_step_basic(P, 4, 100, 3, 1, *([p] * 13)) == _native.FG_ERR_UNSUPPORTED_N
+    with pytest.raises(_native.FormationHipError):
+        _native.check(lib.fg_step_hd(P, 0, 9, *ok_ptrs))
+
+
+def test_no_cpu_fallback(monkeypatch):
+    import formation_gym
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            formation_gym.make_env("formation_hd_env", False, 3, device="cpu")
+    with pytest.raises(FileNotFoundError):
+        formation_gym.make_env("no_such_scenario", False, 3)
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libformation_hip.so")
+    with pytest.raises(_native.FormationHipError, match="no CPU fallback"):
+        _native.load()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gym-formation_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, "%s mentions the oracle" % f

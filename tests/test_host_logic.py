@@ -1,0 +1,41 @@
+"""Host-side logic that needs no GPU: spaces, scenario plugin loading, the
+reference-style action staging rules."""
+import numpy as np
+import pytest
+
+import formation_gym
+from formation_gym import spaces
+
+
+def test_box_space_mirrors_gym():
+    b = spaces.Box(low=-1.0, high=+1.0, shape=(2,), dtype=np.float32)
+    b.seed(0)
+    s = b.sample()
+    assert s.shape == (2,) and s.dtype == np.float32 and b.contains(s)
+    assert not b.contains(np.array([2.0, 0.0], dtype=np.float32))
+    o = spaces.Box(low=-np.inf, high=+np.inf, shape=(54,), dtype=np.float32)
+    assert o.shape == (54,) and np.isinf(o.low).all()
+    assert spaces.Discrete(5).contains(4) and not spaces.Discrete(5).contains(5)
+    assert len(spaces.Tuple([b, o]).sample()) == 2
+
+
+def test_scenario_plugins_load_by_name_and_path():
+    import os
+    sc = formation_gym.load_scenario("formation_hd_env")
+    assert hasattr(sc, "make_world") and hasattr(sc, "reset_world")
+    assert hasattr(sc, "observation") and hasattr(sc, "reward") and hasattr(sc, "benchmark_data")
+    path = os.path.join(os.path.dirname(formation_gym.__file__), "envs", "basic_formation_env.py")
+    assert type(formation_gym.load_scenario(path)).__name__ == "Scenario"
+    # generate_shape needs no device: same nesting as the reference (3, ..., 3, 2)
+    g = sc.generate_shape(2)
+    assert g.shape == (3, 3, 3, 2)
+    with pytest.raises(AssertionError):
+        sc.generate_shape(4)
+
+
+def test_generate_shape_matches_reference(golden):
+    sc = formation_gym.load_scenario("formation_hd_env")
+    g = golden("shapes")
+    for L in range(4):
+        np.testing.assert_allclose(np.asarray(sc.generate_shape(L), dtype=np.float64).reshape(-1, 2),
+                                   g["layer%d" % L], rtol=0, atol=1e-15)
