@@ -14,4 +14,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH >
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH > "$OUT/pmc_write.log" 2>&1
 cd - > /dev/null
+# 3. un-profiled bench line of the same build (never compare profiled with un-profiled timings)
+python3 bench.py --steps 1000 --warmup 100 > "$OUT/bench.json" 2> "$OUT/bench.err"
 find "$OUT" -name '*.csv' | head -20

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (run_profile.sh) into a small JSON + markdown
+summary that is committed under profiles/.
+
+  python profiles/summarize.py gpurun_out/prof_<tag> profiles/<tag>
+
+HBM traffic follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are
+in KiB and collected in separate passes; on gfx950 FETCH_SIZE reports half of a
+wide coalesced read stream, so the read side is doubled (this kernel's loads are
+4/8 bytes per lane, for which the guide says the factor is uncalibrated - reads
+are 3 % of the bytes here, so the uncertainty is < 2 % of the total)."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def main(src, dst):
+    out = {"source": os.path.basename(src)}
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
+    kernels = []
+    if stats:
+        for r in csv.DictReader(open(stats[0])):
+            if "fg::" in r["Name"]:
+                kernels.append({"name": r["Name"], "calls": int(r["Calls"]),
+                                "avg_us": float(r["AverageNs"]) / 1e3, "min_us": float(r["MinNs"]) / 1e3,
+                                "max_us": float(r["MaxNs"]) / 1e3, "pct": float(r["Percentage"])})
+    out["kernel_stats"] = kernels
+    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
+    if trace:
+        rows = [r for r in csv.DictReader(open(trace[0])) if "fg::step_kernel" in r["Kernel_Name"]]
+        if rows:
+            r = rows[-1]
+            out["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
+                                                 "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size") if k in r}
+            ts = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+            gaps = sorted(b[0] - a[1] for a, b in zip(ts, ts[1:]))
+            if gaps:
+                out["median_gap_between_launches_us"] = gaps[len(gaps) // 2] / 1e3
+    for kind, name in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = glob.glob(os.path.join(src, "pmc_" + kind, "*", "*_counter_collection.csv"))
+        if not f:
+            continue
+        vals = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
+                      if "fg::step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name)
+        if vals:
+            out[name + "_KiB_per_launch_median"] = vals[len(vals) // 2]
+    if "FETCH_SIZE_KiB_per_launch_median" in out and "WRITE_SIZE_KiB_per_launch_median" in out:
+        out["hbm_traffic_bytes_per_launch"] = int(1024 * (2 * out["FETCH_SIZE_KiB_per_launch_median"]
+                                                          + out["WRITE_SIZE_KiB_per_launch_median"]))
+    bench = os.path.join(src, "bench.json")
+    if os.path.exists(bench):
+        lines = [l for l in open(bench).read().strip().splitlines() if l.startswith("{")]
+        if lines:
+            out["bench"] = json.loads(lines[-1])
+    with open(dst + ".json", "w") as f:
+        json.dump(out, f, indent=1)
+    with open(dst + ".md", "w") as f:
+        f.write("# rocprofv3 summary: %s\n\n" % out["source"])
+        f.write("command: `bash profiles/run_profile.sh <tag>` = rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and\n"
+                "--pmc WRITE_SIZE in separate passes, each around `python3 bench.py --steps 300 --warmup 50\n"
+                "--no-cpu-baseline --no-extra` (27 agents x 4096 envs), then an un-profiled bench run.\n\n")
+        f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
+        for k in kernels:
+            f.write("| `%s` | %d | %.2f | %.2f | %.2f | %.1f |\n" % (k["name"], k["calls"], k["avg_us"], k["min_us"], k["max_us"], k["pct"]))
+        f.write("\n")
+        for k, v in out.items():
+            if k not in ("kernel_stats", "bench", "source"):
+                f.write("- %s: %s\n" % (k, v))
+        if "bench" in out:
+            b = out["bench"]
+            f.write("\nun-profiled bench line of the same build: value %.4g %s, ms/step %.5f, roofline %s\n"
+                    % (b["value"], b["unit"], b["ms_per_step"], json.dumps(b["roofline"])))
+    print(open(dst + ".md").read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
