@@ -30,6 +30,7 @@ namespace fg {
 
 #define FG_DEV __device__ __forceinline__
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LDS_PER_AGENT = 6;   // float2 slots per agent per env: PRE | A[3N] | V | NV
 
 struct Args {
     FgParams p;
@@ -134,6 +135,107 @@ FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, flo
 }
 
 // ---------------------------------------------------------------------------
+// observation row writer (specialised N): every wave streams whole rows.
+// A row is [v_i | p_j - p_i (j != i) | zeros | ideal_shape | ideal_vel] = 3N (x,y) units.
+//  * units N..3N-1 are identical for every row of an env: each lane loads its share ONCE
+//    into registers and then only stores (one 8-byte store per 64 units per row);
+//  * units 0..N-1: lane u keeps p_{u-1} and p_u in registers; per row it reads p_row (or
+//    -v_row on lane u = 0) from LDS, selects by (u-1 >= row), subtracts, stores.
+// ~3 vector instructions per 512-byte wave store instead of ~25 for a flat decode.
+// Waves of the workgroup split the E*N rows: whole envs per wave when E >= #waves, else
+// rows of one env round-robin over the waves that share it.
+// ---------------------------------------------------------------------------
+// value select (never a pointer select: that would go through scratch + flat loads)
+FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
+    const float2 t = p[c ? idx_if_true : 0];
+    return make_float2(c ? t.x : 0.0f, c ? t.y : 0.0f);
+}
+
+template <int NC, int T, int E>
+FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__ out_env0, int El) {
+    constexpr int N = NC;
+    constexpr int NW = T / 64;
+    constexpr int WPE = (E >= NW) ? 1 : NW / E;             // waves sharing one env
+    constexpr int ESTEP = (E >= NW) ? NW : 1;               // env stride of one wave
+    static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int row0 = (E >= NW) ? 0 : w % WPE;
+    constexpr unsigned ROWU = 3u * N;                       // units per row
+    for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
+        const float2* __restrict__ AA = smem + ee * LDS_PER_AGENT * N + N;
+        float2* __restrict__ out = out_env0 + (size_t)ee * (ROWU * N);
+        if constexpr (N <= 64) {
+            // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
+            // whole block, then the static part (zeros | ideal_shape | ideal_vel, the same for every
+            // row: register-resident) of the same rows follows at once, so that the cache lines a
+            // row shares with its neighbours are completed back to back.
+            constexpr int RW = 64 / N;
+            const int rsub = lane / N, u = lane - rsub * N;
+            const bool act = rsub < RW;
+            const float2 zero = make_float2(0.f, 0.f);
+            const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
+            const float2 Pu = lds_if(act && u >= 1, AA, u);
+            const int xoff = (u == 0) ? 4 * N : 0;          // lane u = 0 reads -v_row (NV = A + 4N)
+            constexpr int CS = (2 * N + 63) / 64;           // 64-unit chunks of the static part
+            constexpr int RS = (2 * N <= 64) ? 64 / (2 * N) : 1;   // rows per static store
+            const int ssub = (2 * N <= 64) ? lane / (2 * N) : 0;
+            const int sidx = (2 * N <= 64) ? lane - ssub * 2 * N : lane;
+            float2 sv[CS];
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+                sv[c] = lds_if(ssub < RS && sidx + 64 * c < 2 * N, AA, N + sidx + 64 * c);
+#pragma unroll 2
+            for (int rb = row0; rb < N; rb += RW * WPE) {
+                const int r = rb + rsub * WPE;
+                if (act && r < N) {
+                    const float2 x = AA[xoff + r];
+                    const float2 c = (u - 1 >= r) ? Pu : Pm;
+                    out[(unsigned)r * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+                }
+#pragma unroll
+                for (int k0 = 0; k0 < RW; k0 += RS) {
+                    const int rs = rb + (k0 + ssub) * WPE;
+                    if (ssub < RS && k0 + ssub < RW && rs < N) {
+#pragma unroll
+                        for (int c = 0; c < CS; ++c)
+                            if (sidx + 64 * c < 2 * N) out[(unsigned)rs * ROWU + (unsigned)(N + sidx + 64 * c)] = sv[c];
+                    }
+                }
+            }
+        } else {
+            // ---- N > 64: one row per iteration, register-cached chunks of 64 units ----
+            constexpr int CD = (N + 63) / 64, CS = (2 * N + 63) / 64;
+            const float2 zero = make_float2(0.f, 0.f);
+            float2 Pm[CD], Pu[CD], sv[CS];
+#pragma unroll
+            for (int c = 0; c < CD; ++c) {
+                const int u = lane + 64 * c;
+                Pm[c] = lds_if(u >= 1 && u < N, AA, u - 1);
+                Pu[c] = lds_if(u >= 1 && u < N, AA, u);
+            }
+#pragma unroll
+            for (int c = 0; c < CS; ++c) sv[c] = lds_if(lane + 64 * c < 2 * N, AA, N + lane + 64 * c);
+#pragma unroll 2
+            for (int r = row0; r < N; r += WPE) {
+                const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
+                const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
+                float2* __restrict__ orow = out + (unsigned)r * ROWU;
+#pragma unroll
+                for (int c = 0; c < CD; ++c) {
+                    const int u = lane + 64 * c;
+                    const float2 x = (c == 0) ? x0 : xp;
+                    const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
+                    if (u < N) orow[u] = make_float2(cc.x - x.x, cc.y - x.y);
+                }
+#pragma unroll
+                for (int c = 0; c < CS; ++c)
+                    if (lane + 64 * c < 2 * N) orow[N + lane + 64 * c] = sv[c];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // the fused step / rollout kernel
 //   NC  compile-time agent count (0 = run-time a.N)
 //   G   lanes reserved per environment for the per-agent phases (power of two >= N)
@@ -143,7 +245,7 @@ FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, flo
 // LDS per env (float2 units): PRE[N] | A[3N] = post pos[N], zeros[N-1], shape[N], ivel[1] | V[N]
 // so that observation unit u >= N of any row is A[u] and unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-template <int NC, int G, int T, int E, bool IDX>
+template <int NC, int G, int T, int E, bool IDX, bool FLAT>
 __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -153,14 +255,16 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     const int i = (E == 1) ? tid : tid % G;
     const int b0 = blockIdx.x * E;
     const int b = b0 + e;
-    const bool valid = (e < E) && (b < a.B) && (i < N);
+    const bool env_ok = (e < E) && (b < a.B);     // this thread's lane group owns a live env
+    const bool valid = env_ok && (i < N);
     const int El = min(E, a.B - b0);
 
-    float2* const env_lds = smem + (e < E ? e : 0) * 5 * N;
+    float2* const env_lds = smem + (e < E ? e : 0) * LDS_PER_AGENT * N;
     float2* const PRE = env_lds;
     float2* const A = env_lds + N;
     float2* const V = A + 3 * N;
-    float* const scratch = reinterpret_cast<float*>(smem + E * 5 * N);
+    float2* const NV = A + 4 * N;             // -velocity, read by the row writer
+    float* const scratch = reinterpret_cast<float*>(smem + E * LDS_PER_AGENT * N);
 
     const float one_minus_damp = 1.0f - a.p.damping;
     const float dt = a.p.dt;
@@ -176,7 +280,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     if (valid) {
         p = make_float2(a.px[sidx], a.py[sidx]);
         v = make_float2(a.vx[sidx], a.vy[sidx]);
-        PRE[i] = p; A[i] = p; V[i] = v;
+        PRE[i] = p; A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
         if (a.do_post) {
             s = reinterpret_cast<const float2*>(a.shape)[sidx];
             A[2 * N - 1 + i] = s;
@@ -184,7 +288,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
         }
     }
-    if (e < E && b < a.B && a.step) t_step = a.step[b];
+    if (env_ok && a.step) t_step = a.step[b];
     __syncthreads();
 
     for (int k = 0; k < a.K; ++k) {
@@ -200,7 +304,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
                 p.x += v.x * dt;
                 p.y += v.y * dt;
-                A[i] = p; V[i] = v;
+                A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
             }
             t_step += 1;
             __syncthreads();
@@ -270,7 +374,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
 
             // ---- phase 4: vec-env auto reset --------------------------------
             if (a.p.auto_reset) {
-                const bool mine = is_done && (b < a.B);
+                const bool mine = is_done && env_ok;
                 if (G > 64 ? mine : (__any(mine) != 0)) {
                     uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
                                      (uint32_t)((a.p.rng_offset + k) >> 32)};
@@ -282,7 +386,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                         p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
                         v = make_float2(0.f, 0.f);
                         s = make_float2(rx - raw[0] * invN, ry - raw[1] * invN);
-                        A[i] = p; V[i] = v; A[2 * N - 1 + i] = s;
+                        A[i] = p; V[i] = v; NV[i] = v; A[2 * N - 1 + i] = s;
                         reinterpret_cast<float2*>(a.shape)[sidx] = s;
                         if (i == 0) {
                             uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
@@ -302,7 +406,11 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             int slot = k;
             bool want_obs = a.obs != nullptr;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
-            if (want_obs) {
+            if (want_obs && NC > 0 && !FLAT) {
+                if constexpr (NC > 0 && !FLAT)
+                    write_obs_rows<NC, T, E>(smem, reinterpret_cast<float2*>(a.obs) +
+                                             ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El);
+            } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows
                 const size_t U0 = ((size_t)slot * a.B + b0) * nenv;
@@ -314,7 +422,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 auto unit = [&](unsigned rp, unsigned u) -> float2 {
                     const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
                     const unsigned row = rp - ee * N;
-                    const float2* AA = smem + ee * 5 * N + N;
+                    const float2* AA = smem + ee * LDS_PER_AGENT * N + N;
                     const unsigned j = u - 1u;
                     const bool is_delta = j < (unsigned)(N - 1);
                     unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
@@ -359,7 +467,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     if (valid && (a.do_phys || a.p.auto_reset)) {
         a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
     }
-    if (a.do_phys && a.step && b < a.B && i == 0) a.step[b] = t_step;
+    if (a.do_phys && a.step && env_ok && i == 0) a.step[b] = t_step;
 }
 
 // ---------------------------------------------------------------------------
@@ -510,15 +618,16 @@ struct Geometry { int G, T, E, lds; };
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int NC, int G, int T, int E, bool IDX>
+template <int NC, int G, int T, int E, bool IDX, bool FLAT>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX>), dim3(grid), dim3(T), lds, st, a);
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, FLAT>), dim3(grid), dim3(T), lds, st, a);
     return hipGetLastError();
 }
 
 using LaunchFn = hipError_t (*)(const Args&, int, int, hipStream_t);
-struct Variant { int NC, G, T, E; LaunchFn plain, idx; };
-#define FG_VARIANT(NC, G, T, E) {NC, G, T, E, &launch_v<NC, G, T, E, false>, &launch_v<NC, G, T, E, true>}
+struct Variant { int NC, G, T, E, flat; LaunchFn plain, idx; };
+#define FG_VARIANT(NC, G, T, E) {NC, G, T, E, (NC) == 0, &launch_v<NC, G, T, E, false, (NC) == 0>, &launch_v<NC, G, T, E, true, (NC) == 0>}
+#define FG_VARIANT_FLAT(NC, G, T, E) {NC, G, T, E, 1, &launch_v<NC, G, T, E, false, true>, &launch_v<NC, G, T, E, true, true>}
 
 // The first entry of a given NC is the default; the others are selectable with
 // FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
@@ -529,6 +638,9 @@ static const Variant kVariants[] = {
     FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 512, 4),
     FG_VARIANT(81, 128, 128, 1), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
     FG_VARIANT(243, 256, 256, 1), FG_VARIANT(243, 256, 512, 1),
+    // flat float4 writer kept for A/B runs (FG_FLAT=1)
+    FG_VARIANT_FLAT(27, 32, 256, 4), FG_VARIANT_FLAT(27, 32, 128, 4), FG_VARIANT_FLAT(9, 16, 128, 4),
+    FG_VARIANT_FLAT(81, 128, 128, 1), FG_VARIANT_FLAT(243, 256, 256, 1),
     FG_VARIANT(0, 4, 64, 16), FG_VARIANT(0, 8, 64, 8), FG_VARIANT(0, 16, 64, 4), FG_VARIANT(0, 32, 128, 4),
     FG_VARIANT(0, 64, 128, 2), FG_VARIANT(0, 128, 128, 1), FG_VARIANT(0, 256, 256, 1),
     FG_VARIANT(0, 512, 512, 1), FG_VARIANT(0, 1024, 1024, 1),
@@ -536,11 +648,12 @@ static const Variant kVariants[] = {
 
 static const Variant* variant_for(int N) {
     if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
-    int want_t = 0, want_e = 0;
+    int want_t = 0, want_e = 0, want_flat = 0;
     if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
+    if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
     for (const Variant& v : kVariants) {
-        if (v.NC != N) continue;
+        if (v.NC != N || v.flat != want_flat) continue;
         if (!dflt) dflt = &v;
         if (v.T == want_t && v.E == want_e) return &v;
     }
@@ -555,7 +668,7 @@ static bool geometry_for(int N, Geometry* g) {
     const Variant* v = variant_for(N);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
-    g->lds = v->E * 5 * N * (int)sizeof(float2) + 16 * 4 * (int)sizeof(float);
+    g->lds = v->E * LDS_PER_AGENT * N * (int)sizeof(float2) + 16 * 4 * (int)sizeof(float);
     return true;
 }
 
