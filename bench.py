@@ -82,6 +82,7 @@ def main():
                     help="step: one fg_step_hd launch per step; rollout: fg_rollout_hd, --chunk steps per launch")
     ap.add_argument("--chunk", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true", help="tuning aid: episodes never reset")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
     a = ap.parse_args()
 
@@ -133,7 +134,7 @@ def main():
         for t in range(start, start + n):
             launchers[t % P](t)
 
-    run_steps.launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=True) for i in range(P)]
+    run_steps.launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=not a.no_auto_reset) for i in range(P)]
 
     def run_rollout(n, start, chunk, seq):
         t = start
@@ -143,7 +144,7 @@ def main():
             if lo + k > P:
                 k = P - lo
             env.scenario.rollout_batch(env.world, act_pool[lo:lo + k], {k2: v[:k] for k2, v in seq.items()},
-                                       auto_reset=True, rng_offset=t)
+                                       auto_reset=not a.no_auto_reset, rng_offset=t)
             t += k
 
     def timed(fn, steps, warmup):

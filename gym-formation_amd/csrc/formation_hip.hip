@@ -30,7 +30,23 @@ namespace fg {
 
 #define FG_DEV __device__ __forceinline__
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int LDS_PER_AGENT = 6;   // float2 slots per agent per env: PRE | A[3N] | V | NV
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS block of one environment, in floats:
+//   float2 tables  A[3N] = post pos[N] | zeros[N-1] | ideal_shape[N] | ideal_vel[1],  V[N],  NV[N] = -V
+//                  (what the observation writers read: unit u >= N of any row is A[u])
+//   float arrays   QX QY (pre-step pos)  PX PY (post-step pos)  SX SY (ideal shape), each padded
+//                  to NP = N rounded up to 4 with a far-away sentinel, read two agents at a time
+//                  (ds_read_b64) by the packed-math pair loops
+__host__ __device__ constexpr int npad(int n) { return (n + 3) & ~3; }
+__host__ __device__ constexpr int env_block_floats(int n) { return 10 * n + 6 * npad(n); }
+FG_DEV float2* env_tables(float2* smem, int ee, int n) {
+    return reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + ee * env_block_floats(n));
+}
+FG_DEV const float2* env_tables(const float2* smem, int ee, int n) {
+    return reinterpret_cast<const float2*>(reinterpret_cast<const float*>(smem) + ee * env_block_floats(n));
+}
+constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances stay finite (2e36)
 
 struct Args {
     FgParams p;
@@ -135,6 +151,80 @@ FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, flo
 }
 
 // ---------------------------------------------------------------------------
+// pair loops, two partner agents per iteration with packed fp32 math (v_pk_*_f32)
+// ---------------------------------------------------------------------------
+// World.step contact force on agent i (core.py:289-322): sum over j != i on PRE-step positions.
+FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __restrict__ QY, int NP,
+                                   int i, float2 p, float cf, float kmargin, float dmin, float cutoff2) {
+    float fx = 0.0f, fy = 0.0f;
+    const f32x2 px = {p.x, p.x}, py = {p.y, p.y};
+    const float inv_k = 1.0f / kmargin;
+    auto add = [&](float dx, float dy, float d2) {
+        // Hardware transcendentals (v_sqrt/v_exp/v_log/v_rcp, ~1 ulp): the contact branch is
+        // taken by about half of all wave iterations at uniform-random density, so its length
+        // sets the physics time.  Relative force error ~3e-7 (|f| <= 6) -> < 2e-8 on positions.
+        // d2 == 0 for two distinct agents is kept: 0 * inf -> NaN as in core.py:312.
+        const float d = __builtin_amdgcn_sqrtf(d2);
+        const float x = (dmin - d) * inv_k;
+        const float pen = kmargin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+        const float c = cf * pen * __builtin_amdgcn_rcpf(d);
+        fx += dx * c;
+        fy += dy * c;
+    };
+#pragma unroll 2
+    for (int j = 0; j < NP; j += 2) {
+        const f32x2 qx = *reinterpret_cast<const f32x2*>(QX + j);
+        const f32x2 qy = *reinterpret_cast<const f32x2*>(QY + j);
+        const f32x2 dx = px - qx, dy = py - qy;
+        const f32x2 d2 = dx * dx + dy * dy;
+        // beyond the cutoff the softplus penetration is below fp32 resolution of the force: skipped
+        const bool n0 = (d2.x < cutoff2) && (j != i);
+        const bool n1 = (d2.y < cutoff2) && (j + 1 != i);
+        if (n0 || n1) {
+            if (n0) add(dx.x, dy.x, d2.x);
+            if (n1) add(dx.y, dy.y, d2.y);
+        }
+    }
+    return make_float2(fx, fy);
+}
+
+// Scenario.reward inner pass for agent i / ideal point i (formation_hd_env.py:61-75):
+//   rowmin = min_j |p~_i - s_j|^2,  colmin = min_j |p~_j - s_i|^2,  cnt = #{j != i : |p_j - p_i| < thr}
+template <bool IDX>
+FG_DEV void reward_pass_packed(const float* __restrict__ PX, const float* __restrict__ PY,
+                               const float* __restrict__ SX, const float* __restrict__ SY, int NP,
+                               float2 p, float ptx, float pty, float tx, float ty, float thr2,
+                               float& rowmin, float& colmin, int& cnt, int& arg_lm, int& arg_ag) {
+    const f32x2 px = {p.x, p.x}, py = {p.y, p.y};
+    const f32x2 ptx2 = {ptx, ptx}, pty2 = {pty, pty}, tx2 = {tx, tx}, ty2 = {ty, ty};
+    int c = -1;                                    // the self pair (distance 0) is counted below
+#pragma unroll 2
+    for (int j = 0; j < NP; j += 2) {
+        const f32x2 qx = *reinterpret_cast<const f32x2*>(PX + j);
+        const f32x2 qy = *reinterpret_cast<const f32x2*>(PY + j);
+        const f32x2 sx = *reinterpret_cast<const f32x2*>(SX + j);
+        const f32x2 sy = *reinterpret_cast<const f32x2*>(SY + j);
+        const f32x2 cx = qx - px, cy = qy - py;
+        const f32x2 dc = cx * cx + cy * cy;
+        c += (dc.x < thr2 ? 1 : 0) + (dc.y < thr2 ? 1 : 0);
+        const f32x2 rx = ptx2 - sx, ry = pty2 - sy;
+        const f32x2 dr = rx * rx + ry * ry;
+        const f32x2 ux = qx - tx2, uy = qy - ty2;
+        const f32x2 dq = ux * ux + uy * uy;
+        if (IDX) {
+            if (dr.x < rowmin) { rowmin = dr.x; arg_lm = j; }
+            if (dr.y < rowmin) { rowmin = dr.y; arg_lm = j + 1; }
+            if (dq.x < colmin) { colmin = dq.x; arg_ag = j; }
+            if (dq.y < colmin) { colmin = dq.y; arg_ag = j + 1; }
+        } else {
+            rowmin = fminf(fminf(rowmin, dr.x), dr.y);
+            colmin = fminf(fminf(colmin, dq.x), dq.y);
+        }
+    }
+    cnt = c + (thr2 > 0.0f ? 0 : 1);               // thr == 0: not even the self pair was counted
+}
+
+// ---------------------------------------------------------------------------
 // observation row writer (specialised N): every wave streams whole rows.
 // A row is [v_i | p_j - p_i (j != i) | zeros | ideal_shape | ideal_vel] = 3N (x,y) units.
 //  * units N..3N-1 are identical for every row of an env: each lane loads its share ONCE
@@ -152,7 +242,8 @@ FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
 }
 
 template <int NC, int T, int E>
-FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__ out_env0, int El) {
+FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__ out_env0, int El, int parts) {
+    // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
     constexpr int N = NC;
     constexpr int NW = T / 64;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;             // waves sharing one env
@@ -162,7 +253,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
     const int row0 = (E >= NW) ? 0 : w % WPE;
     constexpr unsigned ROWU = 3u * N;                       // units per row
     for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
-        const float2* __restrict__ AA = smem + ee * LDS_PER_AGENT * N + N;
+        const float2* __restrict__ AA = env_tables(smem, ee, N);
         float2* __restrict__ out = out_env0 + (size_t)ee * (ROWU * N);
         if constexpr (N <= 64) {
             // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
@@ -187,7 +278,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
 #pragma unroll 2
             for (int rb = row0; rb < N; rb += RW * WPE) {
                 const int r = rb + rsub * WPE;
-                if (act && r < N) {
+                if ((parts & 1) && act && r < N) {
                     const float2 x = AA[xoff + r];
                     const float2 c = (u - 1 >= r) ? Pu : Pm;
                     out[(unsigned)r * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
@@ -195,7 +286,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
 #pragma unroll
                 for (int k0 = 0; k0 < RW; k0 += RS) {
                     const int rs = rb + (k0 + ssub) * WPE;
-                    if (ssub < RS && k0 + ssub < RW && rs < N) {
+                    if ((parts & 2) && ssub < RS && k0 + ssub < RW && rs < N) {
 #pragma unroll
                         for (int c = 0; c < CS; ++c)
                             if (sidx + 64 * c < 2 * N) out[(unsigned)rs * ROWU + (unsigned)(N + sidx + 64 * c)] = sv[c];
@@ -225,12 +316,83 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
                     const int u = lane + 64 * c;
                     const float2 x = (c == 0) ? x0 : xp;
                     const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
-                    if (u < N) orow[u] = make_float2(cc.x - x.x, cc.y - x.y);
+                    if ((parts & 1) && u < N) orow[u] = make_float2(cc.x - x.x, cc.y - x.y);
                 }
 #pragma unroll
                 for (int c = 0; c < CS; ++c)
-                    if (lane + 64 * c < 2 * N) orow[N + lane + 64 * c] = sv[c];
+                    if ((parts & 2) && lane + 64 * c < 2 * N) orow[N + lane + 64 * c] = sv[c];
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-tiled observation writer (N <= 32): a wave composes RT consecutive rows of one env in
+// its own LDS tile with the register-cached scheme of write_obs_rows (ds_write_b64), then
+// streams the tile out as ONE contiguous span: ds_read_b128 + global_store_dwordx4, lanes
+// consecutive, 1 KiB per wave instruction, so almost every 128-byte line is written by a
+// single store request.  The tile sits in LDS at the same 16-byte phase as its destination
+// (tiles of an odd N start 8 bytes off every other time), so both sides of the copy are
+// naturally aligned.  Only the issuing wave touches its tile: LDS operations of one wave
+// complete in order, no barrier is needed.
+// ---------------------------------------------------------------------------
+template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 + 1) & ~1; }
+
+template <int NC, int T, int E, int RT>
+FG_DEV void write_obs_tiled(const float2* __restrict__ smem, float2* __restrict__ tiles,
+                            float2* __restrict__ out_env0, size_t unit0, int El) {
+    constexpr int N = NC;
+    constexpr int NW = T / 64;
+    constexpr int WPE = (E >= NW) ? 1 : NW / E;
+    static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
+    static_assert(N <= 32 && N % RT == 0, "tiled writer: N <= 32, RT divides N");
+    constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float2* __restrict__ tile0 = tiles + w * tile_units<NC, RT>();
+    constexpr int RW = 64 / N;
+    const int rsub = lane / N, u = lane - rsub * N;
+    const bool act = rsub < RW;
+    const int xoff = (u == 0) ? 4 * N : 0;
+    constexpr int RS = 64 / (2 * N);
+    const int ssub = lane / (2 * N), sidx = lane - ssub * 2 * N;
+    for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? NW : E)) {
+        const float2* __restrict__ AA = env_tables(smem, ee, N);
+        const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
+        const float2 Pu = lds_if(act && u >= 1, AA, u);
+        const float2 sv = lds_if(ssub < RS, AA, N + sidx);
+        for (int r0 = ((E >= NW) ? 0 : w % WPE) * RT; r0 < N; r0 += RT * WPE) {
+            const size_t U = unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
+            const unsigned par = (unsigned)(U & 1);
+            float2* __restrict__ img = tile0 + par;
+            // ---- compose RT rows ----
+#pragma unroll
+            for (int rb = 0; rb < RT; rb += RW) {
+                const int rl = rb + rsub;
+                if (act && rl < RT) {
+                    const int r = r0 + rl;
+                    const float2 x = AA[xoff + r];
+                    const float2 c = (u - 1 >= r) ? Pu : Pm;
+                    img[(unsigned)rl * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < RT; rb += RS) {
+                const int rl = rb + ssub;
+                if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
+            }
+            // ---- stream the tile ----
+            float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
+            if (par && lane == 0) out[0] = img[0];
+            constexpr unsigned NPMAX = TU >> 1;
+            const unsigned npair = (TU - par) >> 1;
+            const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(img + par);
+            f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
+#pragma unroll
+            for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
+                const unsigned q = q0 + lane;
+                if (q < npair) dst4[q] = src4[q];
+            }
+            if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
         }
     }
 }
@@ -242,11 +404,11 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
 //   T   threads per workgroup (>= E * G); ALL T threads stream observations
 //   E   environments per workgroup
 //   IDX also emit the landmark-index assignments
-// LDS per env (float2 units): PRE[N] | A[3N] = post pos[N], zeros[N-1], shape[N], ivel[1] | V[N]
-// so that observation unit u >= N of any row is A[u] and unit 0 of row i is A[3N + i].
+// LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-template <int NC, int G, int T, int E, bool IDX, bool FLAT>
+template <int NC, int G, int T, int E, bool IDX, int WR>
 __global__ __launch_bounds__(T) void step_kernel(const Args a) {
+    constexpr bool FLAT = (WR == 1);
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int N = NC ? NC : a.N;
@@ -259,16 +421,22 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     const bool valid = env_ok && (i < N);
     const int El = min(E, a.B - b0);
 
-    float2* const env_lds = smem + (e < E ? e : 0) * LDS_PER_AGENT * N;
-    float2* const PRE = env_lds;
-    float2* const A = env_lds + N;
+    const int NP = npad(N);
+    float2* const A = env_tables(smem, e < E ? e : 0, N);
     float2* const V = A + 3 * N;
     float2* const NV = A + 4 * N;             // -velocity, read by the row writer
-    float* const scratch = reinterpret_cast<float*>(smem + E * LDS_PER_AGENT * N);
+    float* const QX = reinterpret_cast<float*>(A + 5 * N);
+    float* const QY = QX + NP;
+    float* const PX = QY + NP;
+    float* const PY = PX + NP;
+    float* const SX = PY + NP;
+    float* const SY = SX + NP;
+    float* const scratch = reinterpret_cast<float*>(env_tables(smem, E, N));
+    volatile int* const reset_flag = reinterpret_cast<volatile int*>(scratch) + 64;   // 2 ints after the 16x4 reduction partials
 
     const float one_minus_damp = 1.0f - a.p.damping;
     const float dt = a.p.dt;
-    const float cutoff = a.p.dist_min + 30.0f * a.p.contact_margin;
+    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;   // force beyond: < 1e2 k e^-18 ~ 1.5e-9
     const float cutoff2 = cutoff * cutoff;
     const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
     const float invN = 1.0f / (float)N;
@@ -280,24 +448,32 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
     if (valid) {
         p = make_float2(a.px[sidx], a.py[sidx]);
         v = make_float2(a.vx[sidx], a.vy[sidx]);
-        PRE[i] = p; A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+        A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+        QX[i] = p.x; QY[i] = p.y; PX[i] = p.x; PY[i] = p.y;
         if (a.do_post) {
             s = reinterpret_cast<const float2*>(a.shape)[sidx];
             A[2 * N - 1 + i] = s;
+            SX[i] = s.x; SY[i] = s.y;
             if (i < N - 1) A[N + i] = make_float2(0.f, 0.f);
             if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
         }
+    } else if (env_ok && i < NP) {              // sentinel partners of the packed pair loops
+        QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
     }
     if (env_ok && a.step) t_step = a.step[b];
+    if (tid < 2) reset_flag[tid] = 0;
     __syncthreads();
 
     for (int k = 0; k < a.K; ++k) {
+        int slot = k;
+        bool want_obs = a.do_post && a.obs != nullptr;
+        if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
         // ---- phase 2: World.step ------------------------------------------
         if (a.do_phys) {
             if (valid) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
-                float2 f = contact_force_on(PRE, N, i, p, a.p.contact_force, a.p.contact_margin,
-                                            a.p.dist_min, cutoff2);
+                float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                                                a.p.dist_min, cutoff2);
                 f.x += a.p.mass * (a.p.sensitivity * u.x);
                 f.y += a.p.mass * (a.p.sensitivity * u.y);
                 v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
@@ -305,8 +481,13 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 p.x += v.x * dt;
                 p.y += v.y * dt;
                 A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+                PX[i] = p.x; PY[i] = p.y;
             }
             t_step += 1;
+            // The barrier that publishes the post-step tables also carries one bit per group:
+            // "some env of this workgroup finishes its episode in this step" (auto-reset only),
+            // so the common no-reset step pays no extra barrier later.
+            if (a.p.auto_reset && env_ok && i == 0 && t_step >= a.p.world_length) reset_flag[k & 1] = 1;
             __syncthreads();
         }
 
@@ -320,28 +501,9 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             const float tx = s.x + mx, ty = s.y + my;          // own ideal point, un-centred
             float rowmin = INFINITY, colmin = INFINITY;
             int cnt = 0, arg_lm = 0, arg_ag = 0;
-            if (valid) {
-                const float2* __restrict__ SH = A + 2 * N - 1;
-#pragma unroll 3
-                for (int j = 0; j < N; ++j) {
-                    const float2 q = A[j];
-                    const float2 sj = SH[j];
-                    const float cx = q.x - p.x, cy = q.y - p.y;
-                    const float dc = cx * cx + cy * cy;
-                    cnt += (j != i && dc < thr2) ? 1 : 0;
-                    const float rx = ptx - sj.x, ry = pty - sj.y;
-                    const float dr = rx * rx + ry * ry;        // |p~_i - s_j|^2
-                    const float qx = q.x - tx, qy = q.y - ty;
-                    const float dq = qx * qx + qy * qy;        // |p~_j - s_i|^2
-                    if (IDX) {
-                        if (dr < rowmin) { rowmin = dr; arg_lm = j; }
-                        if (dq < colmin) { colmin = dq; arg_ag = j; }
-                    } else {
-                        rowmin = fminf(rowmin, dr);
-                        colmin = fminf(colmin, dq);
-                    }
-                }
-            }
+            if (valid)
+                reward_pass_packed<IDX>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
+                                        rowmin, colmin, cnt, arg_lm, arg_ag);
             float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
             const float H = sqrtf(fmaxf(red[0], red[1]));
@@ -373,7 +535,8 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             }
 
             // ---- phase 4: vec-env auto reset --------------------------------
-            if (a.p.auto_reset) {
+            if (a.p.auto_reset && reset_flag[k & 1] != 0) {          // workgroup-uniform
+                if (tid == 0) reset_flag[(k + 1) & 1] = 0;
                 const bool mine = is_done && env_ok;
                 if (G > 64 ? mine : (__any(mine) != 0)) {
                     uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
@@ -387,6 +550,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                         v = make_float2(0.f, 0.f);
                         s = make_float2(rx - raw[0] * invN, ry - raw[1] * invN);
                         A[i] = p; V[i] = v; NV[i] = v; A[2 * N - 1 + i] = s;
+                        PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
                         reinterpret_cast<float2*>(a.shape)[sidx] = s;
                         if (i == 0) {
                             uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
@@ -403,13 +567,15 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
             }
 
             // ---- phase 5: observations --------------------------------------
-            int slot = k;
-            bool want_obs = a.obs != nullptr;
-            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs && NC > 0 && !FLAT) {
-                if constexpr (NC > 0 && !FLAT)
+                if constexpr (NC > 0 && WR == 0)
                     write_obs_rows<NC, T, E>(smem, reinterpret_cast<float2*>(a.obs) +
-                                             ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El);
+                                             ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El, 3);
+                if constexpr (NC > 0 && WR >= 2) {
+                    const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                    float2* tiles = env_tables(smem, E, N) + 36;            // after env blocks + 72 floats of scratch
+                    write_obs_tiled<NC, T, E, WR - 2 + 1>(smem, tiles, reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+                }
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows
@@ -422,7 +588,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 auto unit = [&](unsigned rp, unsigned u) -> float2 {
                     const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
                     const unsigned row = rp - ee * N;
-                    const float2* AA = smem + ee * LDS_PER_AGENT * N + N;
+                    const float2* AA = env_tables(smem, (int)ee, N);
                     const unsigned j = u - 1u;
                     const bool is_delta = j < (unsigned)(N - 1);
                     unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
@@ -458,7 +624,7 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
 
         if (k + 1 < a.K) {
             __syncthreads();            // obs phase done reading A/V before the next step writes them
-            if (valid) PRE[i] = p;
+            if (valid) { QX[i] = p.x; QY[i] = p.y; }
             __syncthreads();
         }
     }
@@ -618,16 +784,18 @@ struct Geometry { int G, T, E, lds; };
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int NC, int G, int T, int E, bool IDX, bool FLAT>
+template <int NC, int G, int T, int E, bool IDX, int WR>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, FLAT>), dim3(grid), dim3(T), lds, st, a);
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR>), dim3(grid), dim3(T), lds, st, a);
     return hipGetLastError();
 }
 
 using LaunchFn = hipError_t (*)(const Args&, int, int, hipStream_t);
-struct Variant { int NC, G, T, E, flat; LaunchFn plain, idx; };
-#define FG_VARIANT(NC, G, T, E) {NC, G, T, E, (NC) == 0, &launch_v<NC, G, T, E, false, (NC) == 0>, &launch_v<NC, G, T, E, true, (NC) == 0>}
-#define FG_VARIANT_FLAT(NC, G, T, E) {NC, G, T, E, 1, &launch_v<NC, G, T, E, false, true>, &launch_v<NC, G, T, E, true, true>}
+// wr: observation writer 0 = register-cached rows, 1 = flat decode (run-time N), 1 + RT = LDS tiles of RT rows
+struct Variant { int NC, G, T, E, wr; LaunchFn plain, idx; };
+#define FG_VARIANT_W(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W>, &launch_v<NC, G, T, E, true, W>}
+#define FG_VARIANT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, ((NC) == 0 ? 1 : 0))
+#define FG_VARIANT_FLAT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, 1)
 
 // The first entry of a given NC is the default; the others are selectable with
 // FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
@@ -641,6 +809,11 @@ static const Variant kVariants[] = {
     // flat float4 writer kept for A/B runs (FG_FLAT=1)
     FG_VARIANT_FLAT(27, 32, 256, 4), FG_VARIANT_FLAT(27, 32, 128, 4), FG_VARIANT_FLAT(9, 16, 128, 4),
     FG_VARIANT_FLAT(81, 128, 128, 1), FG_VARIANT_FLAT(243, 256, 256, 1),
+    // LDS-tiled writer, RT rows per tile (FG_FLAT = 1 + RT)
+    FG_VARIANT_W(27, 32, 256, 4, 4), FG_VARIANT_W(27, 32, 128, 4, 4), FG_VARIANT_W(27, 32, 128, 2, 4), FG_VARIANT_W(27, 32, 64, 2, 4),
+    FG_VARIANT_W(27, 32, 256, 4, 10), FG_VARIANT_W(27, 32, 128, 4, 10), FG_VARIANT_W(27, 32, 128, 2, 10), FG_VARIANT_W(27, 32, 64, 2, 10),
+    FG_VARIANT_W(27, 32, 256, 2, 10), FG_VARIANT_W(27, 32, 256, 2, 4),
+    FG_VARIANT_W(9, 16, 128, 4, 10), FG_VARIANT_W(9, 16, 64, 4, 10),
     FG_VARIANT(0, 4, 64, 16), FG_VARIANT(0, 8, 64, 8), FG_VARIANT(0, 16, 64, 4), FG_VARIANT(0, 32, 128, 4),
     FG_VARIANT(0, 64, 128, 2), FG_VARIANT(0, 128, 128, 1), FG_VARIANT(0, 256, 256, 1),
     FG_VARIANT(0, 512, 512, 1), FG_VARIANT(0, 1024, 1024, 1),
@@ -653,7 +826,7 @@ static const Variant* variant_for(int N) {
     if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
     for (const Variant& v : kVariants) {
-        if (v.NC != N || v.flat != want_flat) continue;
+        if (v.NC != N || v.wr != want_flat) continue;
         if (!dflt) dflt = &v;
         if (v.T == want_t && v.E == want_e) return &v;
     }
@@ -668,7 +841,8 @@ static bool geometry_for(int N, Geometry* g) {
     const Variant* v = variant_for(N);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
-    g->lds = v->E * LDS_PER_AGENT * N * (int)sizeof(float2) + 16 * 4 * (int)sizeof(float);
+    g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
+    if (v->wr >= 2) g->lds += (v->T / 64) * ((3 * N * (v->wr - 1) + 3) & ~1) * (int)sizeof(float2);
     return true;
 }
 
