@@ -75,18 +75,43 @@ template <int OP> FG_DEV float combine(float a, float b) {
     return fminf(a, b);
 }
 
-// G <= 64: the env occupies an aligned group of G lanes of one wave -> xor shuffles.
-// G  > 64: the env is the whole workgroup (E == 1) -> wave shuffles + LDS partials.
+// Cross-lane partner fetch for a butterfly reduction step, without going through the LDS
+// crossbar (ds_bpermute costs ~100 cycles of latency per step): DPP quad permutes and row
+// mirrors inside a 16-lane row, v_permlane16/32_swap across rows (gfx950).  STEP 4 and 8 use
+// mirrors instead of xor: any pairing of disjoint halves that already hold their own totals
+// gives the same reduction.
+template <int STEP, int OP> FG_DEV float bfly(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    if constexpr (STEP >= 16) {
+        // v_permlane{16,32}_swap(v, v) returns the two row / half sets side by side:
+        // {rows 0,0,2,2 | rows 1,1,3,3} resp. {low,low | high,high}; combining them IS the step
+        const auto sw = (STEP == 16) ? __builtin_amdgcn_permlane16_swap(iv, iv, false, false)
+                                     : __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+        return combine<OP>(__builtin_bit_cast(float, (int)sw[0]), __builtin_bit_cast(float, (int)sw[1]));
+    } else {
+        constexpr int CTRL = (STEP == 1) ? 0xB1      // quad_perm [1,0,3,2]
+                           : (STEP == 2) ? 0x4E      // quad_perm [2,3,0,1]
+                           : (STEP == 4) ? 0x141     // row_half_mirror
+                                         : 0x140;    // row_mirror
+        const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+        return combine<OP>(v, __builtin_bit_cast(float, r));
+    }
+}
+
+// G <= 64: the env occupies an aligned group of G lanes of one wave -> in-register butterfly.
+// G  > 64: the env is the whole workgroup (E == 1) -> wave butterfly + LDS partials.
 template <int G, int T, int NV, int OP0, int OP1, int OP2, int OP3>
 FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
     constexpr int W = (G <= 64) ? G : 64;
-#pragma unroll
-    for (int m = W / 2; m > 0; m >>= 1) {
-        if constexpr (NV > 0) v[0] = combine<OP0>(v[0], __shfl_xor(v[0], m, 64));
-        if constexpr (NV > 1) v[1] = combine<OP1>(v[1], __shfl_xor(v[1], m, 64));
-        if constexpr (NV > 2) v[2] = combine<OP2>(v[2], __shfl_xor(v[2], m, 64));
-        if constexpr (NV > 3) v[3] = combine<OP3>(v[3], __shfl_xor(v[3], m, 64));
+#define FG_STEP(S)                                                                   \
+    if constexpr (W > S) {                                                           \
+        if constexpr (NV > 0) v[0] = bfly<S, OP0>(v[0]);           \
+        if constexpr (NV > 1) v[1] = bfly<S, OP1>(v[1]);           \
+        if constexpr (NV > 2) v[2] = bfly<S, OP2>(v[2]);           \
+        if constexpr (NV > 3) v[3] = bfly<S, OP3>(v[3]);           \
     }
+    FG_STEP(1) FG_STEP(2) FG_STEP(4) FG_STEP(8) FG_STEP(16) FG_STEP(32)
+#undef FG_STEP
     if (G > 64) {
         constexpr int NW = T / 64;
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
