@@ -32,6 +32,21 @@ for _p in (ROOT, PKG):
 HBM_PEAK_GBPS = 8000.0          # MI355X spec peak (MI355X_MICROARCH.md); 6290 measured copy
 
 
+def measured_traffic(n_agents, envs):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary for this workload
+    (profiles/*_<N>x<B>.json, made by profiles/run_profile.sh + summarize.py), else None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%dx%d.json" % (n_agents, envs)))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if "hbm_traffic_bytes_per_launch" in d:
+            best = (d["hbm_traffic_bytes_per_launch"], os.path.basename(f))
+    return best
+
+
 def _cpu_port_worker(args):
     """One env of the faithful per-env port, `steps` steps; returns elapsed seconds."""
     n_agents, steps, seed = args
@@ -210,7 +225,9 @@ def main():
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
                        "kernel": "fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"])},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": (measured_traffic(N, B) or (None, None))[0] if a.mode == "step" else None,
+                         "traffic_source": (measured_traffic(N, B) or (None, None))[1],
                          "algorithmic_bytes_per_launch": bytes_per_env_step * B * (1 if a.mode == "step" else chunk),
                          "avg_launch_us": round(dev_ms * 1e3 / a.steps * (1 if a.mode == "step" else chunk), 3),
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},

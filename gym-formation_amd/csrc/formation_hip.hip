@@ -844,9 +844,13 @@ static const Variant kVariants[] = {
     FG_VARIANT(0, 512, 512, 1), FG_VARIANT(0, 1024, 1024, 1),
 };
 
-static const Variant* variant_for(int N) {
+static const Variant* variant_for(int N, int B = 0) {
     if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
     int want_t = 0, want_e = 0, want_flat = 0;
+    // Size-aware default (MI355X sweep, profiles/): a batch that fills the chip several times
+    // over streams best with no idle waves and 1 KiB tile stores; a single-generation batch
+    // (27 x 4096 = 4 workgroups per CU) is latency-bound and prefers spare writer waves.
+    if (N == 27 && B >= 12288) { want_t = 128; want_e = 4; want_flat = 10; }
     if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
     if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
@@ -862,8 +866,8 @@ static const Variant* variant_for(int N) {
     return nullptr;
 }
 
-static bool geometry_for(int N, Geometry* g) {
-    const Variant* v = variant_for(N);
+static bool geometry_for(int N, Geometry* g, int B = 0) {
+    const Variant* v = variant_for(N, B);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
     g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
@@ -873,8 +877,8 @@ static bool geometry_for(int N, Geometry* g) {
 
 static int launch_step(Args a, hipStream_t st) {
     Geometry g;
-    const Variant* v = variant_for(a.N);
-    if (!v || !geometry_for(a.N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const Variant* v = variant_for(a.N, a.B);
+    if (!v || !geometry_for(a.N, &g, a.B)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
     const int grid = (a.B + g.E - 1) / g.E;
     if (const char* s = getenv("FG_NT")) a.nt_store = atoi(s);
