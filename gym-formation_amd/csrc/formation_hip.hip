@@ -696,103 +696,192 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
 }
 
 // ---------------------------------------------------------------------------
-// basic_formation_env (BASELINE config 1): one lane per agent, one env per
-// aligned group of G lanes of a wave (N <= 64).  Observation
-// basic_formation_env.py:29-41, reward :43-52.
+// Landmark scenarios with few agents (N + M <= 64): basic_formation_env (BASELINE config 1),
+// formation_hd_partial_env, formation_hd_partial_range_env, formation_hd_obs_env.
+// One lane per movable entity (N agents, then M obstacles), one env per aligned group of G
+// lanes of a wave.  Reference lines under formation_gym/envs/:
+//   basic     observation basic_formation_env.py:29-41, reward :43-52 (self "collision" included)
+//   partial   observation formation_hd_partial_env.py:38-57 (ring neighbours), reward :59-72
+//   range     observation formation_hd_partial_range_env.py:38-52 (clipped), reward as partial
+//   obstacle  observation formation_hd_obs_env.py:44-58, reward :60-99 incl. the obstacle
+//             velocity override (:84-89); obstacles are movable colliders of World.step
 // ---------------------------------------------------------------------------
-struct BasicArgs {
+struct ScnArgs {
     FgParams p;
-    int B, N, L, do_phys;
+    FgScenario sc;
+    int B, N, do_phys;
     float* px; float* py; float* vx; float* vy;
-    const float* act; const float* lm; int32_t* step;
+    const float* act; const float* lm; float* opos; float* ovel; int32_t* step;
     float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
 };
 
 template <int G, int T>
-__global__ __launch_bounds__(T) void basic_kernel(const BasicArgs a) {
+__global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     constexpr int E = T / G;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int N = a.N, L = a.L;
+    const int N = a.N, L = a.sc.num_landmarks, M = a.sc.num_obstacles, NE = N + M;
+    const int kind = a.sc.kind;
     const int tid = threadIdx.x;
     const int e = tid / G, i = tid % G;
     const int b = blockIdx.x * E + e;
-    const bool valid = (b < a.B) && (i < N);
-    float2* const PRE = smem + e * (2 * N + L);
-    float2* const POST = PRE + N;
-    float2* const LM = POST + N;
+    const bool live = b < a.B;
+    const bool is_agent = live && i < N;
+    const bool is_obst = live && i >= N && i < NE;
+    float2* const PRE = smem + e * (2 * NE + L);
+    float2* const POST = PRE + NE;
+    float2* const LM = POST + NE;
     float2 p = make_float2(0.f, 0.f), v = p;
     const size_t sidx = (size_t)b * N + i;
-    if (valid) {
+    const size_t oidx = (size_t)b * M + (i - N);
+    if (is_agent) {
         p = make_float2(a.px[sidx], a.py[sidx]);
         v = make_float2(a.vx[sidx], a.vy[sidx]);
-        PRE[i] = p; POST[i] = p;
+    } else if (is_obst) {
+        p = reinterpret_cast<const float2*>(a.opos)[oidx];
+        v = reinterpret_cast<const float2*>(a.ovel)[oidx];
     }
-    if (b < a.B && i < L) LM[i] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + i];
-    for (int l = G + i; (b < a.B) && l < L; l += G) LM[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + l];
-    int t_step = (b < a.B && a.step) ? a.step[b] : 0;
+    if (is_agent || is_obst) { PRE[i] = p; POST[i] = p; }
+    for (int l = i; live && l < L; l += G) LM[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + l];
+    int t_step = (live && a.step) ? a.step[b] : 0;
     __syncthreads();
+    const float my_size = 0.5f * (i < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
     if (a.do_phys) {
-        if (valid) {
-            const float cutoff = a.p.dist_min + 30.0f * a.p.contact_margin;
-            const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
-            float2 f = contact_force_on(PRE, N, i, p, a.p.contact_force, a.p.contact_margin,
-                                        a.p.dist_min, cutoff * cutoff);
-            f.x += a.p.mass * (a.p.sensitivity * u.x);
-            f.y += a.p.mass * (a.p.sensitivity * u.y);
-            v.x = v.x * (1.0f - a.p.damping) + (f.x / a.p.mass) * a.p.dt;
-            v.y = v.y * (1.0f - a.p.damping) + (f.y / a.p.mass) * a.p.dt;
+        if (is_agent || is_obst) {
+            // World.step: all pairs of movable colliders, contact distance size_i + size_j
+            float fx = 0.f, fy = 0.f;
+            const float k = a.p.contact_margin;
+            for (int j = 0; j < NE; ++j) {
+                const float2 q = PRE[j];
+                const float dmin = my_size + 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+                const float cut = dmin + 18.0f * k;
+                const float dx = p.x - q.x, dy = p.y - q.y;
+                const float d2 = dx * dx + dy * dy;
+                if (j != i && d2 < cut * cut) {
+                    const float d = __builtin_amdgcn_sqrtf(d2);
+                    const float x = (dmin - d) / k;
+                    const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+                    const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                    fx += dx * c; fy += dy * c;
+                }
+            }
+            if (is_agent) {
+                const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
+                fx += a.p.mass * (a.p.sensitivity * u.x);
+                fy += a.p.mass * (a.p.sensitivity * u.y);
+            }
+            v.x = v.x * (1.0f - a.p.damping) + (fx / a.p.mass) * a.p.dt;
+            v.y = v.y * (1.0f - a.p.damping) + (fy / a.p.mass) * a.p.dt;
             p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
             POST[i] = p;
-            a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+            if (is_agent) {
+                a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+            } else {
+                // the reward callback re-arms the obstacle velocity every step (:84-89)
+                const bool falling = p.y > a.sc.obstacle_floor;
+                reinterpret_cast<float2*>(a.opos)[oidx] = p;
+                reinterpret_cast<float2*>(a.ovel)[oidx] =
+                    make_float2(falling ? a.sc.obstacle_vx : 0.f, falling ? a.sc.obstacle_vy : 0.f);
+            }
         }
         t_step += 1;
         __syncthreads();
     }
-    // reward: -sum_l min_a |p_a - l|  - #{a incl. self : |p_a - p_i| < thresh}
-    float cover = 0.f;   // lane l < L holds min_a |p_a - lm_l|
-    int arg = 0;
-    for (int l0 = 0; l0 < L; l0 += G) {
-        const int l = l0 + i;
-        float best = INFINITY; int barg = 0;
-        if (b < a.B && l < L) {
-            const float2 m = LM[l];
-            for (int j = 0; j < N; ++j) {
-                const float2 q = POST[j];
-                const float dx = q.x - m.x, dy = q.y - m.y;
-                const float d2 = dx * dx + dy * dy;
-                if (d2 < best) { best = d2; barg = j; }
-            }
-            cover += sqrtf(best);
-            if (a.near_ag) a.near_ag[(size_t)b * L + l] = barg;
-        }
-    }
-    (void)arg;
-    float red[1] = {cover};
     float scratch_dummy[1];
-    env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch_dummy);
+    // ---- formation term ----
+    float form = 0.f;      // basic: sum_l min_a |p_a - l| ; others: Hausdorff(centred agents, centred landmarks)
+    if (kind == FG_SCN_BASIC) {
+        float cover = 0.f;
+        for (int l0 = 0; l0 < L; l0 += G) {
+            const int l = l0 + i;
+            if (live && l < L) {
+                const float2 m = LM[l];
+                float best = INFINITY; int barg = 0;
+                for (int j = 0; j < N; ++j) {
+                    const float2 q = POST[j];
+                    const float dx = q.x - m.x, dy = q.y - m.y, d2 = dx * dx + dy * dy;
+                    if (d2 < best) { best = d2; barg = j; }
+                }
+                cover += sqrtf(best);
+                if (a.near_ag) a.near_ag[(size_t)b * L + l] = barg;
+            }
+        }
+        float red[1] = {cover};
+        env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch_dummy);
+        form = red[0];
+    } else {
+        float s4[4] = {is_agent ? p.x : 0.f, is_agent ? p.y : 0.f, 0.f, 0.f};
+        for (int l = i; live && l < L; l += G) { s4[2] += LM[l].x; s4[3] += LM[l].y; }
+        env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(s4, scratch_dummy);
+        const float mx = s4[0] / (float)N, my = s4[1] / (float)N;
+        const float lx = s4[2] / (float)L, ly = s4[3] / (float)L;
+        float rowmin = -INFINITY, colmax = -INFINITY;
+        if (is_agent) {                                         // min over landmarks for my agent
+            rowmin = INFINITY;
+            for (int l = 0; l < L; ++l) {
+                const float dx = (p.x - mx) - (LM[l].x - lx), dy = (p.y - my) - (LM[l].y - ly);
+                rowmin = fminf(rowmin, dx * dx + dy * dy);
+            }
+        }
+        for (int l = i; live && l < L; l += G) {                // min over agents for my landmark(s)
+            float cm = INFINITY;
+            for (int j = 0; j < N; ++j) {
+                const float dx = (POST[j].x - mx) - (LM[l].x - lx), dy = (POST[j].y - my) - (LM[l].y - ly);
+                cm = fminf(cm, dx * dx + dy * dy);
+            }
+            colmax = fmaxf(colmax, cm);
+        }
+        float red[2] = {rowmin, colmax};
+        env_reduce<G, G, 2, R_MAX, R_MAX, R_MAX, R_MAX>(red, scratch_dummy);
+        form = sqrtf(fmaxf(red[0], red[1]));
+    }
+    // ---- collision counts ----
     int cnt = 0;
-    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
-    if (valid) for (int j = 0; j < N; ++j) {
-        const float2 q = POST[j];
-        const float dx = q.x - p.x, dy = q.y - p.y;
-        cnt += (dx * dx + dy * dy < thr2) ? 1 : 0;           // self included (:49-51)
+    if (is_agent) {
+        const float thr = a.p.collide_thresh, thr2 = (float)((double)thr * (double)thr);
+        for (int j = 0; j < N; ++j) {
+            const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
+            cnt += ((kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < thr2) ? 1 : 0;
+        }
+        const float ot = 0.5f * a.p.dist_min + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
+        for (int j = N; j < NE; ++j) {
+            const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
+            cnt += (dx * dx + dy * dy < ot2) ? 1 : 0;
+        }
     }
     float cs[1] = {(float)cnt};
     env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch_dummy);
     const bool is_done = t_step >= a.p.world_length;
-    const int D = 4 + 2 * L + 4 * (N - 1);
-    if (valid) {
-        a.rew[sidx] = (float)(-(double)N * (double)red[0] - (double)cs[0]);
-        if (a.indiv) a.indiv[sidx] = -red[0] - (float)cnt;
+    // ---- outputs ----
+    const int nbr = (kind == FG_SCN_PARTIAL) ? a.sc.num_obs : (N - 1);
+    const int D = 2 + (kind == FG_SCN_BASIC ? 2 : 0) + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1);
+    if (is_agent) {
+        a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
+        if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
         if (a.done) a.done[sidx] = is_done ? 1 : 0;
         float2* o = reinterpret_cast<float2*>(a.obs + sidx * D);
-        o[0] = v; o[1] = p;
-        for (int l = 0; l < L; ++l) { const float2 m = LM[l]; o[2 + l] = make_float2(m.x - p.x, m.y - p.y); }
-        int w = 2 + L;
-        for (int j = 0; j < N; ++j) if (j != i) { const float2 q = POST[j]; o[w++] = make_float2(q.x - p.x, q.y - p.y); }
+        int w = 0;
+        o[w++] = v;
+        if (kind == FG_SCN_BASIC) o[w++] = p;
+        for (int l = 0; l < L; ++l) {
+            const float2 m = LM[l];
+            o[w++] = (kind == FG_SCN_BASIC) ? make_float2(m.x - p.x, m.y - p.y) : m;
+        }
+        for (int j = N; j < NE; ++j) { const float2 q = POST[j]; o[w++] = make_float2(q.x - p.x, q.y - p.y); }
+        if (kind == FG_SCN_PARTIAL) {
+            for (int kk = 0; kk < nbr; ++kk) {
+                const float2 q = POST[(i + 1 + kk) % N];
+                o[w++] = make_float2(q.x - p.x, q.y - p.y);
+            }
+        } else {
+            const float r = (kind == FG_SCN_RANGE) ? a.sc.obs_range : INFINITY;
+            for (int j = 0; j < N; ++j) if (j != i) {
+                const float2 q = POST[j];
+                o[w++] = make_float2(fminf(fmaxf(q.x - p.x, -r), r), fminf(fmaxf(q.y - p.y, -r), r));
+            }
+        }
         for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
     }
-    if (a.do_phys && a.step && b < a.B && i == 0) a.step[b] = t_step;
+    if (a.do_phys && a.step && live && i == 0) a.step[b] = t_step;
 }
 
 // ---------------------------------------------------------------------------
@@ -1030,36 +1119,64 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
     return FG_OK;
 }
 
+static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, int N, int do_physics,
+                           float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                           const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                           int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                           int32_t* near_ag, void* stream) {
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!sc) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
+    const int L = sc->num_landmarks, M = sc->num_obstacles;
+    if (sc->kind < FG_SCN_BASIC || sc->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
+    if (B <= 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B and L must be > 0, M >= 0%s");
+    if (N < 2 || N + M > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 64%s");
+    if (sc->kind == FG_SCN_PARTIAL && (sc->num_obs < 0 || sc->num_obs > 1024)) return fail(FG_ERR_BAD_ARG, "bad num_obs%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || !reward || (do_physics && !act) ||
+        (M > 0 && (!obst_pos || !obst_vel)))
+        return fail(FG_ERR_BAD_ARG, "scenario step: a required pointer is NULL%s");
+    if (((uintptr_t)obs & 7u) || ((uintptr_t)landmarks & 7u) || (act && ((uintptr_t)act & 7u)) ||
+        ((uintptr_t)obst_pos & 7u) || ((uintptr_t)obst_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "obs/landmarks/act/obstacle buffers must be 8-byte aligned%s");
+    ScnArgs a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.sc = *sc; a.B = B; a.N = N; a.do_phys = do_physics ? 1 : 0;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act; a.lm = landmarks;
+    a.opos = obst_pos; a.ovel = obst_vel; a.step = step;
+    a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
+    const int G = pow2ceil(N + M) < 4 ? 4 : pow2ceil(N + M);
+    const int E = 64 / G;
+    const int grid = (B + E - 1) / E;
+    const int lds = E * (2 * (N + M) + L) * (int)sizeof(float2);
+    hipStream_t st = (hipStream_t)stream;
+    if (G == 4) hipLaunchKernelGGL((scn_kernel<4, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 32) hipLaunchKernelGGL((scn_kernel<32, 64>), dim3(grid), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((scn_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int do_physics,
+                     float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                     const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                     int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                     void* stream) {
+    return launch_scenario(params, scenario, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
+                           obst_pos, obst_vel, step, obs, reward, indiv_reward, done, nullptr, stream);
+}
+
 int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                   const float* act, const float* landmarks, int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_ag, void* stream) {
-    int rc = check_params(params);
-    if (rc) return rc;
-    if (B <= 0 || L <= 0) return fail(FG_ERR_BAD_ARG, "B and L must be > 0%s");
-    if (N < 2 || N > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "basic_formation_env kernel needs 2 <= N <= 64%s");
-    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || !reward || (do_physics && !act))
-        return fail(FG_ERR_BAD_ARG, "fg_step_basic: a required pointer is NULL%s");
-    if (((uintptr_t)obs & 7u) || ((uintptr_t)landmarks & 7u) || (act && ((uintptr_t)act & 7u)))
-        return fail(FG_ERR_ALIGNMENT, "obs/landmarks/act must be 8-byte aligned%s");
-    BasicArgs a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.B = B; a.N = N; a.L = L; a.do_phys = do_physics ? 1 : 0;
-    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act; a.lm = landmarks; a.step = step;
-    a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
-    const int G = pow2ceil(N) < 4 ? 4 : pow2ceil(N);
-    const int E = 64 / G;
-    const int grid = (B + E - 1) / E;
-    const int lds = E * (2 * N + L) * (int)sizeof(float2);
-    hipStream_t st = (hipStream_t)stream;
-    if (G == 4) hipLaunchKernelGGL((basic_kernel<4, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 8) hipLaunchKernelGGL((basic_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 16) hipLaunchKernelGGL((basic_kernel<16, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 32) hipLaunchKernelGGL((basic_kernel<32, 64>), dim3(grid), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((basic_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
-    hipError_t err = hipGetLastError();
-    if (err != hipSuccess) return fail(FG_ERR_HIP, "basic launch failed: %s", hipGetErrorString(err));
-    return FG_OK;
+    if (N > 64) return fail(FG_ERR_UNSUPPORTED_N, "basic_formation_env kernel needs 2 <= N <= 64%s");
+    FgScenario sc; memset(&sc, 0, sizeof(sc));
+    sc.kind = FG_SCN_BASIC; sc.num_landmarks = L; sc.penalty = 1.0f;
+    return launch_scenario(params, &sc, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
+                           nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
 }
 
 }  // extern "C"

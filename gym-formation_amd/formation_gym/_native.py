@@ -41,6 +41,25 @@ class FgParams(ctypes.Structure):
     ]
 
 
+FG_SCN_BASIC, FG_SCN_PARTIAL, FG_SCN_RANGE, FG_SCN_OBSTACLE = 1, 2, 3, 4
+
+
+class FgScenario(ctypes.Structure):
+    """Mirror of `struct FgScenario` (include/formation_hip.h)."""
+    _fields_ = [
+        ("kind", ctypes.c_int32),
+        ("num_landmarks", ctypes.c_int32),
+        ("num_obstacles", ctypes.c_int32),
+        ("num_obs", ctypes.c_int32),
+        ("obs_range", ctypes.c_float),
+        ("obstacle_size", ctypes.c_float),
+        ("obstacle_vx", ctypes.c_float),
+        ("obstacle_vy", ctypes.c_float),
+        ("obstacle_floor", ctypes.c_float),
+        ("penalty", ctypes.c_float),
+    ]
+
+
 class FormationHipError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libformation_hip: status %d: %s" % (code, msg))
@@ -63,6 +82,7 @@ SIGNATURES = {
     "fg_rollout_hd": (_I, [_PP, _I, _I, _I] + [_P] * 12 + [_I, _P]),
     "fg_reset_hd": (_I, [_PP, _I, _I] + [_P] * 9),
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
+    "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
 }
 
 _lib = None

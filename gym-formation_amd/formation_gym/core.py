@@ -36,6 +36,8 @@ class EntityState(object):
         w, i = self._world, self._index
         if self._kind == "agent":
             return torch.stack((w.pos_x[:, i], w.pos_y[:, i]), dim=-1)
+        if self._kind == "obstacle":
+            return w.obstacle_pos[:, i]
         return w.landmark_pos[:, i]
 
     @p_pos.setter
@@ -45,6 +47,8 @@ class EntityState(object):
         if self._kind == "agent":
             w.pos_x[:, i] = value[..., 0]
             w.pos_y[:, i] = value[..., 1]
+        elif self._kind == "obstacle":
+            w.obstacle_pos[:, i] = value
         else:
             w.landmark_pos[:, i] = value
 
@@ -53,14 +57,19 @@ class EntityState(object):
         w, i = self._world, self._index
         if self._kind == "agent":
             return torch.stack((w.vel_x[:, i], w.vel_y[:, i]), dim=-1)
+        if self._kind == "obstacle":
+            return w.obstacle_vel[:, i]
         return torch.zeros((w.num_envs, 2), dtype=torch.float32, device=w.device)
 
     @p_vel.setter
     def p_vel(self, value):
         w, i = self._world, self._index
+        value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+        if self._kind == "obstacle":
+            w.obstacle_vel[:, i] = value
+            return
         if self._kind != "agent":
             return
-        value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
         w.vel_x[:, i] = value[..., 0]
         w.vel_y[:, i] = value[..., 1]
 
@@ -181,6 +190,8 @@ class World(object):
         self.action_u = None
         self.step_count = None
         self.landmark_pos = None
+        self.obstacle_pos = None          # movable colliding landmarks (formation_hd_obs_env)
+        self.obstacle_vel = None
         self.scenario = None
 
     # ---- reference-compatible views --------------------------------------
@@ -203,7 +214,11 @@ class World(object):
             raise RuntimeError("formation_gym (MI355X-native) needs a CUDA/HIP device; got %s. "
                                "There is no CPU fallback for the hot path." % self.device)
         _native.load()
-        B, N, L = self.num_envs, len(self.agents), len(self.landmarks)
+        movable = [l for l in self.landmarks if l.movable]
+        static = [l for l in self.landmarks if not l.movable]
+        if self.landmarks != static + movable:
+            raise ValueError("movable landmarks (obstacles) must come last in world.landmarks")
+        B, N, L, M = self.num_envs, len(self.agents), len(static), len(movable)
         f = dict(dtype=torch.float32, device=self.device)
         self.pos_x = torch.zeros((B, N), **f)
         self.pos_y = torch.zeros((B, N), **f)
@@ -212,14 +227,16 @@ class World(object):
         self.action_u = torch.zeros((B, N, 2), **f)
         self.step_count = torch.zeros((B,), dtype=torch.int32, device=self.device)
         self.landmark_pos = torch.zeros((B, max(L, 1), 2), **f)
-        self.num_agents, self.num_landmarks = N, L
+        self.obstacle_pos = torch.zeros((B, max(M, 1), 2), **f)
+        self.obstacle_vel = torch.zeros((B, max(M, 1), 2), **f)
+        self.num_agents, self.num_landmarks, self.num_obstacles = N, L, M
         for i, a in enumerate(self.agents):
             a.i = i
             a.state = AgentState(self, "agent", i)
             a.action = Action(self, i)
         for i, l in enumerate(self.landmarks):
             l.i = N + i
-            l.state = EntityState(self, "landmark", i)
+            l.state = EntityState(self, "landmark", i) if i < L else EntityState(self, "obstacle", i - L)
 
     def set_state(self, pos=None, vel=None):
         """Upload [B,N,2] positions / velocities (any array-like) into the SoA tensors."""

@@ -84,6 +84,31 @@ typedef struct FgParams {
     uint64_t rng_offset;
 } FgParams;
 
+/* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:
+ *   kind            which Scenario file under formation_gym/envs/
+ *   num_landmarks   L: make_world default of that file (make_env passes only num_agents)
+ *   num_obstacles   M: formation_hd_obs_env.py:14 (movable colliding landmarks)
+ *   num_obs         formation_hd_partial_env.py:15,44 ring neighbours observed
+ *   obs_range       formation_hd_partial_range_env.py:15,46 clip of relative positions
+ *   obstacle_size   formation_hd_obs_env.py:39;  obstacle_v{x,y}, obstacle_floor  :84-89
+ *   penalty         reward per collision: 1 (basic/partial/range), 2 (obstacle, :92-98)          */
+typedef enum FgScenarioKind {
+    FG_SCN_BASIC = 1, FG_SCN_PARTIAL = 2, FG_SCN_RANGE = 3, FG_SCN_OBSTACLE = 4
+} FgScenarioKind;
+
+typedef struct FgScenario {
+    int32_t kind;
+    int32_t num_landmarks;
+    int32_t num_obstacles;
+    int32_t num_obs;
+    float obs_range;
+    float obstacle_size;
+    float obstacle_vx;
+    float obstacle_vy;
+    float obstacle_floor;
+    float penalty;
+} FgScenario;
+
 /* library / diagnostics --------------------------------------------------- */
 int fg_abi_version(void);
 const char* fg_last_error(void);
@@ -148,6 +173,17 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   const float* act, const float* landmarks, int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_ag, void* stream);
+
+/* MultiAgentEnv.step for formation_hd_partial_env / formation_hd_partial_range_env /
+ * formation_hd_obs_env (and basic_formation_env), N + M <= 64:
+ *   landmarks float [B][L][2]; obst_pos, obst_vel float [B][M][2] (updated in place, NULL if M = 0);
+ *   obs float [B][N][D], D = 2 (+2 basic) + 2L + 2M + 2*nbr + 2(N-1), nbr = num_obs (partial) or N-1.
+ * do_physics = 0 evaluates observation/reward/done on the current state (env.reset()). */
+int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int do_physics,
+                     float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                     const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                     int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -485,3 +485,127 @@ class PortEnv(object):
         total = np.sum(rew_n)
         rew_n = [[total]] * self.N
         return obs_n, rew_n, done_n, info_n
+
+
+# --------------------------------------------------------------------------
+# remaining scenarios ("next" row f3): formation_hd_partial_env,
+# formation_hd_partial_range_env, formation_hd_obs_env
+# --------------------------------------------------------------------------
+
+class ScnParams(HdParams):
+    """Constants of the three landmark-formation scenarios.
+    partial:  envs/formation_hd_partial_env.py:15-36   (agent 0.04, num_obs 3, L 5, length 25)
+    range:    envs/formation_hd_partial_range_env.py:15-36 (agent 0.04, obs_range 0.7, L 4, length 25)
+    obstacle: envs/formation_hd_obs_env.py:14-42       (agent 0.1, L 4, 3 obstacles of 0.15, length 50)"""
+
+    def __init__(self, kind):
+        assert kind in ("partial", "range", "obstacle")
+        self.kind = kind
+        self.agent_size = 0.1 if kind == "obstacle" else 0.04
+        self.world_length = 50 if kind == "obstacle" else 25
+        self.num_landmarks = {"partial": 5, "range": 4, "obstacle": 4}[kind]
+        self.num_obstacles = 3 if kind == "obstacle" else 0
+        self.obstacle_size = 0.15
+        self.num_obs = 3
+        self.obs_range = 0.7
+        self.penalty = 2.0 if kind == "obstacle" else 1.0      # formation_hd_obs_env.py:92-98
+        self.obstacle_vel = (0.0, -1.0)                        # :84-89
+        self.obstacle_floor = -2.2
+
+    @property
+    def collide_thresh(self):          # is_collision: size_a + size_b (no /2 in these files)
+        return self.agent_size + self.agent_size
+
+
+def reset_scn(kind, seed, N):
+    """reset_world draw order: N agent positions, L landmark positions (U(-1,1)^2); the
+    obstacle scenario then draws each obstacle from U([step_k, 2.0], [step_k+1, 2.5])
+    (formation_hd_obs_env.py:101-114)."""
+    P = ScnParams(kind)
+    rs = np.random.RandomState(seed)
+    pos = rs.uniform(-1, +1, (N, 2))
+    L, M = P.num_landmarks, P.num_obstacles
+    lm = np.zeros((L, 2)); ob = np.zeros((M, 2))
+    step = np.linspace(-1.8, 1.8, M + 1) if M else None
+    for i in range(L + M):
+        if i < L:
+            lm[i] = rs.uniform(-1, +1, 2)
+        else:
+            k = i - L
+            ob[k] = rs.uniform([step[k], 2.0], [step[k + 1], 2.5])
+    return dict(pos=pos[None], vel=np.zeros((1, N, 2)), landmarks=lm[None], obst_pos=ob[None],
+                obst_vel=np.tile(np.array(P.obstacle_vel), (1, M, 1)), step=np.zeros(1, dtype=np.int32))
+
+
+def physics_entities(pos, vel, force0, size, P):
+    """World.step over E movable colliding entities with per-entity size and unit mass
+    (core.py:240-277; force ratio m_b/m_a = 1).  force0 = non-contact force per entity."""
+    pos = np.asarray(pos, dtype=np.float64); vel = np.asarray(vel, dtype=np.float64)
+    E = pos.shape[1]
+    delta = pos[:, :, None, :] - pos[:, None, :, :]
+    dist = np.sqrt((delta ** 2).sum(-1))
+    dmin = size[:, None] + size[None, :]
+    pen = softplus_penetration(dist, dmin[None], P.contact_margin)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        f = P.contact_force * delta / dist[..., None] * pen[..., None]
+    f = np.where(np.eye(E, dtype=bool)[None, :, :, None], 0.0, f)
+    F = force0 + f.sum(2)
+    vel = vel * (1 - P.damping) + (F / P.mass) * P.dt
+    return pos + vel * P.dt, vel
+
+
+def _hausdorff_centred(pos, lm):
+    u = pos - pos.mean(1, keepdims=True)
+    v = lm - lm.mean(1, keepdims=True)
+    D = np.sqrt(((u[:, :, None, :] - v[:, None, :, :]) ** 2).sum(-1))
+    return np.maximum(D.min(2).max(1), D.min(1).max(1))
+
+
+def observation_scn(kind, pos, vel, lm, obst_pos, P):
+    B, N, _ = pos.shape
+    rel = pos[:, None, :, :] - pos[:, :, None, :]              # [B,i,j] = p_j - p_i
+    keep = ~np.eye(N, dtype=bool)
+    lm_abs = np.repeat(lm.reshape(B, 1, -1), N, 1)
+    zeros = np.zeros((B, N, 2 * (N - 1)))
+    if kind == "partial":            # formation_hd_partial_env.py:38-57
+        idx = (np.arange(N)[:, None] + 1 + np.arange(P.num_obs)[None, :]) % N
+        nb = rel[:, np.arange(N)[:, None], idx].reshape(B, N, 2 * P.num_obs)
+        return np.concatenate((vel, lm_abs, nb, zeros), 2)
+    if kind == "range":              # formation_hd_partial_range_env.py:38-52
+        oth = np.clip(rel[:, keep].reshape(B, N, 2 * (N - 1)), -P.obs_range, P.obs_range)
+        return np.concatenate((vel, lm_abs, oth, zeros), 2)
+    ob_rel = (obst_pos[:, None, :, :] - pos[:, :, None, :]).reshape(B, N, -1)   # formation_hd_obs_env.py:44-58
+    return np.concatenate((vel, lm_abs, ob_rel, rel[:, keep].reshape(B, N, 2 * (N - 1)), zeros), 2)
+
+
+def step_scn(kind, state, act, P=None):
+    """One env.step of the three scenarios.  state: pos, vel [B,N,2], landmarks [B,L,2],
+    obst_pos, obst_vel [B,M,2], step [B]."""
+    P = P or ScnParams(kind)
+    pos = np.asarray(state["pos"], dtype=np.float64); vel = np.asarray(state["vel"], dtype=np.float64)
+    act = np.asarray(act, dtype=np.float64)
+    B, N, _ = pos.shape
+    M = P.num_obstacles
+    op = np.asarray(state["obst_pos"], dtype=np.float64).reshape(B, M, 2)
+    ov = np.asarray(state["obst_vel"], dtype=np.float64).reshape(B, M, 2)
+    size = np.array([P.agent_size] * N + [P.obstacle_size] * M)
+    F0 = np.concatenate((P.mass * P.sensitivity * act, np.zeros((B, M, 2))), 1)
+    ep, ev = physics_entities(np.concatenate((pos, op), 1), np.concatenate((vel, ov), 1), F0, size, P)
+    pos, vel, op, ov = ep[:, :N], ev[:, :N], ep[:, N:], ev[:, N:]
+    step = np.asarray(state["step"]) + 1
+    lm = np.asarray(state["landmarks"], dtype=np.float64)
+    H = _hausdorff_centred(pos, lm)
+    PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
+    close = PD < P.collide_thresh
+    close[:, np.arange(N), np.arange(N)] = False
+    indiv = -H[:, None] - P.penalty * close.sum(2)
+    if M:
+        # reward side effect: obstacles keep falling until the floor (formation_hd_obs_env.py:84-89)
+        ov = np.where((op[..., 1] > P.obstacle_floor)[..., None], np.array(P.obstacle_vel), 0.0)
+        OD = np.sqrt(((pos[:, :, None, :] - op[:, None, :, :]) ** 2).sum(-1))
+        indiv = indiv - P.penalty * (OD < P.agent_size + P.obstacle_size).sum(2)
+    out = dict(indiv=indiv, shared=indiv.sum(1), obs=observation_scn(kind, pos, vel, lm, op, P))
+    out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]
+    out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)
+    new = dict(state, pos=pos, vel=vel, obst_pos=op, obst_vel=ov, step=step.astype(np.int32))
+    return new, out

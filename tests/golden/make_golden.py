@@ -168,6 +168,54 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None):
     return res
 
 
+def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None):
+    """Seeded rollout of one of the remaining scenarios (formation_hd_partial_env,
+    formation_hd_partial_range_env, formation_hd_obs_env) through the reference API."""
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
+    keys = ("pos", "vel", "lm", "lmvel", "obs", "indiv", "shared", "done")
+    out = {k: [] for k in keys}
+    init = {k: [] for k in ("pos0", "vel0", "lm0", "lmvel0", "obs0")}
+    meta = {}
+    for b in range(B):
+        env = fg.make_env(name, False, N)
+        env.seed(seed + 1000 * b)
+        o0 = env.reset()
+        if crowd is not None:
+            for a in env.world.agents:
+                a.state.p_pos = a.state.p_pos * crowd
+            o0 = [env._get_obs(a) for a in env.agents]
+        sc = _scenario_of(env)
+        lm = lambda: np.array([l.state.p_pos for l in env.world.landmarks], dtype=np.float64)
+        lmv = lambda: np.array([l.state.p_vel for l in env.world.landmarks], dtype=np.float64)
+        p, v = _state(env)
+        init["pos0"].append(p); init["vel0"].append(v); init["lm0"].append(lm()); init["lmvel0"].append(lmv())
+        init["obs0"].append(np.array(o0, dtype=np.float64))
+        rec = {k: [] for k in keys}
+        for t in range(T):
+            act_n = [acts[t, b, i].astype(np.float64).copy() for i in range(N)]
+            obs_n, rew_n, done_n, info_n = env.step(act_n)
+            p, v = _state(env)
+            rec["pos"].append(p); rec["vel"].append(v); rec["lm"].append(lm()); rec["lmvel"].append(lmv())
+            rec["obs"].append(np.array(obs_n, dtype=np.float64))
+            rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
+            rec["shared"].append(np.array([r[0] for r in rew_n]))
+            rec["done"].append(np.array(done_n, dtype=np.bool_))
+        for k in keys:
+            out[k].append(np.array(rec[k]))
+        meta = dict(world_length=np.array(env.world_length), agent_size=np.array(env.world.agents[0].size),
+                    num_landmarks=np.array(getattr(sc, "num_landmarks", len(env.world.landmarks))),
+                    num_entities=np.array(len(env.world.landmarks)),
+                    num_obs=np.array(getattr(sc, "num_obs", -1)), obs_range=np.array(getattr(sc, "obs_range", -1.0)),
+                    lm_sizes=np.array([l.size for l in env.world.landmarks]),
+                    obs_dim=np.array(env.observation_space[0].shape[0]))
+    res = {k: np.stack(v, axis=1) for k, v in out.items()}
+    res.update({k: np.array(v) for k, v in init.items()})
+    res.update(meta)
+    res.update(acts=acts, seed=np.array(seed), act_seed=np.array(act_seed),
+               crowd=np.array(-1.0 if crowd is None else crowd))
+    return res
+
+
 def rollout_basic(fg, N, T, seed, act_seed):
     acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, 1, N, 2)).astype(np.float32)
     env = fg.make_env("basic_formation_env", False, N)
@@ -263,37 +311,48 @@ def hausdorff_kat():
 
 
 def main():
+    only = sys.argv[1:]          # optional: regenerate only the named fixtures
     tmp = tempfile.mkdtemp(prefix="fg_shims_")
     _install_shims(tmp)
     fg = _import_reference()
 
     def save(name, d):
+        if only and name not in only:
+            return
         path = os.path.join(OUT, name + ".npz")
-        np.savez_compressed(path, **d)
+        np.savez_compressed(path, **d())
         print("%-28s %8.1f kB" % (name, os.path.getsize(path) / 1024))
 
     # formation_hd_env rollouts, default spread (few contacts) and crowded (many)
-    save("hd_n3", rollout_hd(fg, 3, 4, 25, seed=1, act_seed=11))
-    save("hd_n9", rollout_hd(fg, 9, 4, 25, seed=2, act_seed=12))
-    save("hd_n27", rollout_hd(fg, 27, 3, 25, seed=3, act_seed=13))
-    save("hd_n81", rollout_hd(fg, 81, 2, 25, seed=4, act_seed=14))
-    save("hd_n9_crowd", rollout_hd(fg, 9, 4, 25, seed=5, act_seed=15, crowd=0.15))
-    save("hd_n27_crowd", rollout_hd(fg, 27, 3, 25, seed=6, act_seed=16, crowd=0.25))
-    save("hd_n81_crowd", rollout_hd(fg, 81, 2, 12, seed=7, act_seed=17, crowd=0.3))
-    save("hd_n243", rollout_hd(fg, 243, 1, 3, seed=8, act_seed=18, obs_at=[3]))
+    save("hd_n3", lambda: rollout_hd(fg, 3, 4, 25, seed=1, act_seed=11))
+    save("hd_n9", lambda: rollout_hd(fg, 9, 4, 25, seed=2, act_seed=12))
+    save("hd_n27", lambda: rollout_hd(fg, 27, 3, 25, seed=3, act_seed=13))
+    save("hd_n81", lambda: rollout_hd(fg, 81, 2, 25, seed=4, act_seed=14))
+    save("hd_n9_crowd", lambda: rollout_hd(fg, 9, 4, 25, seed=5, act_seed=15, crowd=0.15))
+    save("hd_n27_crowd", lambda: rollout_hd(fg, 27, 3, 25, seed=6, act_seed=16, crowd=0.25))
+    save("hd_n81_crowd", lambda: rollout_hd(fg, 81, 2, 12, seed=7, act_seed=17, crowd=0.3))
+    save("hd_n243", lambda: rollout_hd(fg, 243, 1, 3, seed=8, act_seed=18, obs_at=[3]))
     # an even agent count and a non-power-of-3 one (generic-N kernel path)
-    save("hd_n4", rollout_hd(fg, 4, 3, 10, seed=21, act_seed=31))
-    save("hd_n10", rollout_hd(fg, 10, 2, 10, seed=22, act_seed=32, crowd=0.3))
+    save("hd_n4", lambda: rollout_hd(fg, 4, 3, 10, seed=21, act_seed=31))
+    save("hd_n10", lambda: rollout_hd(fg, 10, 2, 10, seed=22, act_seed=32, crowd=0.3))
     # done flip of formation_hd_env at world_length = 100
-    save("hd_n3_done", rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
+    save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
     # config 1: basic_formation_env, N=3, incl. the done flip at step 50
-    save("basic_n3", rollout_basic(fg, 3, 52, seed=1, act_seed=20))
-    save("reset", reset_fixture(fg, [(1, 3), (7, 9), (1001, 9), (3, 27), (4, 81)]))
-    save("shapes", shape_fixture(fg))
-    save("policy_n3", policy_fixture(fg, 3, 30, seed=41))
-    save("policy_n9", policy_fixture(fg, 9, 30, seed=42))
-    save("policy_n27", policy_fixture(fg, 27, 12, seed=43))
-    save("hausdorff_kat", hausdorff_kat())
+    save("basic_n3", lambda: rollout_basic(fg, 3, 52, seed=1, act_seed=20))
+    save("reset", lambda: reset_fixture(fg, [(1, 3), (7, 9), (1001, 9), (3, 27), (4, 81)]))
+    save("shapes", lambda: shape_fixture(fg))
+    save("policy_n3", lambda: policy_fixture(fg, 3, 30, seed=41))
+    save("policy_n9", lambda: policy_fixture(fg, 9, 30, seed=42))
+    save("policy_n27", lambda: policy_fixture(fg, 27, 12, seed=43))
+    save("hausdorff_kat", lambda: hausdorff_kat())
+    # remaining scenarios ("next" row f3)
+    save("partial_n5", lambda: rollout_scn(fg, "formation_hd_partial_env", 5, 3, 27, seed=51, act_seed=61))
+    save("partial_n9_crowd", lambda: rollout_scn(fg, "formation_hd_partial_env", 9, 3, 12, seed=52, act_seed=62, crowd=0.15))
+    save("partial_n3", lambda: rollout_scn(fg, "formation_hd_partial_env", 3, 2, 6, seed=53, act_seed=63))
+    save("range_n4", lambda: rollout_scn(fg, "formation_hd_partial_range_env", 4, 3, 27, seed=54, act_seed=64))
+    save("range_n7_crowd", lambda: rollout_scn(fg, "formation_hd_partial_range_env", 7, 3, 12, seed=55, act_seed=65, crowd=0.2))
+    save("obst_n4", lambda: rollout_scn(fg, "formation_hd_obs_env", 4, 3, 52, seed=56, act_seed=66))
+    save("obst_n8", lambda: rollout_scn(fg, "formation_hd_obs_env", 8, 2, 40, seed=57, act_seed=67))
 
 
 if __name__ == "__main__":

@@ -348,3 +348,77 @@ def test_bfs_policy_closed_loop_on_device():
         if first is None:
             first = rew[:, 0, 0].clone()
     assert (rew[:, 0, 0] > first).float().mean() > 0.9
+
+
+SCN_GPU = [("formation_hd_partial_env", "partial", "partial_n5"), ("formation_hd_partial_env", "partial", "partial_n9_crowd"),
+           ("formation_hd_partial_env", "partial", "partial_n3"),
+           ("formation_hd_partial_range_env", "range", "range_n4"), ("formation_hd_partial_range_env", "range", "range_n7_crowd"),
+           ("formation_hd_obs_env", "obstacle", "obst_n4"), ("formation_hd_obs_env", "obstacle", "obst_n8")]
+
+
+@pytest.mark.parametrize("scenario,kind,name", SCN_GPU)
+def test_remaining_scenarios_teacher_forced(golden, scenario, kind, name):
+    """formation_hd_partial_env / _partial_range_env / _obs_env through fg_step_scenario,
+    re-seeded from the reference every step."""
+    g = golden(name)
+    P = O.ScnParams(kind)
+    T, B, N = g["acts"].shape[:3]
+    L = P.num_landmarks
+    env = _make(N, B, scenario)
+    assert env.world_length == P.world_length and env.observation_space[0].shape == (int(g["obs_dim"]),)
+
+    def load(pos, vel, lm, lmvel, step):
+        env.world.set_state(pos, vel)
+        env.world.landmark_pos.copy_(torch.as_tensor(lm[:, :L], dtype=torch.float32))
+        if P.num_obstacles:
+            env.world.obstacle_pos.copy_(torch.as_tensor(lm[:, L:], dtype=torch.float32))
+            env.world.obstacle_vel.copy_(torch.as_tensor(lmvel[:, L:], dtype=torch.float32))
+        env.world.step_count.fill_(step)
+
+    load(g["pos0"], g["vel0"], g["lm0"], g["lmvel0"], 0)
+    out = {"obs": env._out["obs"], "reward": env._out["reward"]}
+    env.scenario.observe_batch(env.world, out)
+    np.testing.assert_allclose(_np(out["obs"]), g["obs0"], rtol=0, atol=ATOL)
+    for t in range(T):
+        if t:
+            load(g["pos"][t - 1], g["vel"][t - 1], g["lm"][t - 1], g["lmvel"][t - 1], t)
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        if P.num_obstacles:
+            np.testing.assert_allclose(_np(env.world.obstacle_pos), g["lm"][t][:, L:], rtol=0, atol=ATOL)
+            np.testing.assert_allclose(_np(env.world.obstacle_vel), g["lmvel"][t][:, L:], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=2 * ATOL)
+        # collision counts are integers: excuse only pairs sitting on the threshold
+        want = g["indiv"][t]
+        bad = np.abs(_np(info["individual_reward"]) - want) > 2 * ATOL
+        if bad.any():
+            new, _ = O.step_scn(kind, dict(pos=g["pos"][t - 1] if t else g["pos0"], vel=g["vel"][t - 1] if t else g["vel0"],
+                                           landmarks=(g["lm"][t - 1] if t else g["lm0"])[:, :L],
+                                           obst_pos=(g["lm"][t - 1] if t else g["lm0"])[:, L:],
+                                           obst_vel=(g["lmvel"][t - 1] if t else g["lmvel0"])[:, L:],
+                                           step=np.full(B, t)), g["acts"][t].astype(np.float64), P)
+            PD = np.sqrt(((new["pos"][:, :, None] - new["pos"][:, None]) ** 2).sum(-1)) + 10 * np.eye(N)
+            assert (np.abs(PD - P.collide_thresh).min() < 1e-5), "individual reward mismatch away from a threshold"
+        else:
+            np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=1e-5, atol=5 * ATOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+
+
+def test_remaining_scenarios_seeded_reset(golden):
+    import formation_gym
+    for scenario, name in [("formation_hd_partial_env", "partial_n5"), ("formation_hd_partial_range_env", "range_n4"),
+                           ("formation_hd_obs_env", "obst_n4")]:
+        g = golden(name)
+        B, N = g["pos0"].shape[:2]
+        env = formation_gym.make_env(scenario, False, N, num_envs=B, device="cuda:0")
+        env.seed(int(g["seed"]))
+        obs = env.reset()
+        np.testing.assert_allclose(_np(obs), g["obs0"], rtol=0, atol=1e-6)     # same MT19937 streams
+        # reference-style single env
+        env1 = formation_gym.make_env(scenario, False, N)
+        env1.seed(int(g["seed"]))
+        o = env1.reset()
+        assert isinstance(o, list) and len(o) == N
+        np.testing.assert_allclose(np.array(o), g["obs0"][0], rtol=0, atol=1e-6)

@@ -178,3 +178,53 @@ def test_port_env_reset_stream(golden):
     env.seed(7)
     obs = env.reset()
     np.testing.assert_allclose(np.array(obs), g["s7_n9_obs"], rtol=0, atol=1e-15)
+
+
+SCN_CASES = [("partial", "partial_n5"), ("partial", "partial_n9_crowd"), ("partial", "partial_n3"),
+             ("range", "range_n4"), ("range", "range_n7_crowd"), ("obstacle", "obst_n4"), ("obstacle", "obst_n8")]
+
+
+def _scn_state(g, P, t=None):
+    L = P.num_landmarks
+    src = (lambda k: g[k + "0"]) if t is None else (lambda k: g[k][t])
+    B = g["pos0"].shape[0]
+    return dict(pos=src("pos"), vel=src("vel"), landmarks=src("lm")[:, :L], obst_pos=src("lm")[:, L:],
+                obst_vel=src("lmvel")[:, L:], step=np.full(B, 0 if t is None else t + 1, dtype=np.int32))
+
+
+@pytest.mark.parametrize("kind,name", SCN_CASES)
+def test_remaining_scenarios_match_reference(golden, kind, name):
+    g = golden(name)
+    P = O.ScnParams(kind)
+    assert int(g["world_length"]) == P.world_length and int(g["num_landmarks"]) == P.num_landmarks
+    assert float(g["agent_size"]) == P.agent_size
+    assert int(g["num_entities"]) == P.num_landmarks + P.num_obstacles
+    st = _scn_state(g, P)
+    np.testing.assert_allclose(O.observation_scn(kind, st["pos"], st["vel"], st["landmarks"], st["obst_pos"], P),
+                               g["obs0"], rtol=0, atol=1e-12)
+    assert g["obs0"].shape[-1] == int(g["obs_dim"])
+    T = g["acts"].shape[0]
+    for t in range(T):
+        prev = _scn_state(g, P, t - 1) if t else st
+        new, out = O.step_scn(kind, prev, g["acts"][t].astype(np.float64), P)
+        np.testing.assert_allclose(new["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(new["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(new["obst_pos"], g["lm"][t][:, P.num_landmarks:], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(new["obst_vel"], g["lmvel"][t][:, P.num_landmarks:], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["reward"][..., 0], g["shared"][t], rtol=1e-12, atol=1e-10)
+        np.testing.assert_array_equal(out["done"], g["done"][t])
+
+
+@pytest.mark.parametrize("kind,name", [("partial", "partial_n5"), ("range", "range_n4"), ("obstacle", "obst_n4")])
+def test_remaining_scenarios_reset_stream(golden, kind, name):
+    g = golden(name)
+    N = g["pos0"].shape[1]
+    P = O.ScnParams(kind)
+    for b in range(g["pos0"].shape[0]):
+        st = O.reset_scn(kind, int(g["seed"]) + 1000 * b, N)
+        np.testing.assert_array_equal(st["pos"][0], g["pos0"][b])
+        np.testing.assert_array_equal(st["landmarks"][0], g["lm0"][b][:P.num_landmarks])
+        np.testing.assert_array_equal(st["obst_pos"][0], g["lm0"][b][P.num_landmarks:])
+        np.testing.assert_array_equal(st["obst_vel"][0], g["lmvel0"][b][P.num_landmarks:])
