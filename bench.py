@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true", help="tuning aid: episodes never reset")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
 
     import numpy as np
@@ -111,10 +113,15 @@ def main():
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if a.backend == "nccl" else None
 
     import formation_gym
     from formation_gym import _native
@@ -173,10 +180,8 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
-        if world_size > 1:
-            tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            wall, dev_ms = float(tt[0]), float(tt[1])
+        wall = sharding.max_over_ranks(wall, red_dev)          # slowest rank
+        dev_ms = sharding.max_over_ranks(dev_ms, red_dev)
         return wall, dev_ms
 
     seq = None

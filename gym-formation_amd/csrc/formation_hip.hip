@@ -855,7 +855,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     const int nbr = (kind == FG_SCN_PARTIAL) ? a.sc.num_obs : (N - 1);
     const int D = 2 + (kind == FG_SCN_BASIC ? 2 : 0) + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1);
     if (is_agent) {
-        a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
+        if (a.rew) a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
         if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
         if (a.done) a.done[sidx] = is_done ? 1 : 0;
         float2* o = reinterpret_cast<float2*>(a.obs + sidx * D);
@@ -1132,7 +1132,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     if (B <= 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B and L must be > 0, M >= 0%s");
     if (N < 2 || N + M > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 64%s");
     if (sc->kind == FG_SCN_PARTIAL && (sc->num_obs < 0 || sc->num_obs > 1024)) return fail(FG_ERR_BAD_ARG, "bad num_obs%s");
-    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || !reward || (do_physics && !act) ||
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || (do_physics && (!act || !reward)) ||
         (M > 0 && (!obst_pos || !obst_vel)))
         return fail(FG_ERR_BAD_ARG, "scenario step: a required pointer is NULL%s");
     if (((uintptr_t)obs & 7u) || ((uintptr_t)landmarks & 7u) || (act && ((uintptr_t)act & 7u)) ||

@@ -82,7 +82,7 @@ class Scenario(BaseScenario):
             1 if do_physics else 0,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
-            out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+            out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
             _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream()))
         self._cache = out
 

@@ -122,7 +122,7 @@ class LandmarkScenario(BaseScenario):
             _native.ptr(act), world.landmark_pos.data_ptr(),
             world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
             world.step_count.data_ptr(),
-            out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+            out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
             _native.ptr(out.get("done")), _native.current_stream()))
         self._cache = out
 

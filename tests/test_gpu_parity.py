@@ -422,3 +422,43 @@ def test_remaining_scenarios_seeded_reset(golden):
         o = env1.reset()
         assert isinstance(o, list) and len(o) == N
         np.testing.assert_allclose(np.array(o), g["obs0"][0], rtol=0, atol=1e-6)
+
+
+def _run(cmd, env_extra=None, timeout=600):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **(env_extra or {}))
+    out = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    return out.stdout
+
+
+def test_bench_json_contract_single_and_two_ranks():
+    """bench.py prints ONE JSON line with the contract keys; the 2-rank path (barrier, MAX over
+    ranks, sharded seeds) is exercised with two gloo ranks sharing this GPU."""
+    import json
+    line = [l for l in _run(["bench.py", "--steps", "30", "--warmup", "5", "--envs", "512", "--agents", "9",
+                             "--no-cpu-baseline"]).splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
+    assert d["state_finite"] and d["value"] > 0 and "workload" in d["config"]
+    out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29571", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
+                "--agents", "9", "--backend", "gloo", "--no-extra"])
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d2 = json.loads(line[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["global_envs"] == 512 and d2["scaling"] == "weak"
+
+
+def test_demo_driver_runs():
+    out = _run(["gym-formation_amd/demo.py", "-n", "3", "--num-layer", "2", "--num-envs", "64", "--steps", "120"])
+    assert "env-steps/s" in out
+    out = _run(["gym-formation_amd/demo.py", "-s", "formation_hd_obs_env", "-n", "4", "-r", "--num-envs", "32", "--steps", "60"])
+    assert "env-steps/s" in out
