@@ -151,6 +151,56 @@ FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
 }
 
 // ---------------------------------------------------------------------------
+// World options no reference scenario enables: walls, motor noise, speed clamp
+// ---------------------------------------------------------------------------
+// core.py:325-362 get_wall_collision_force, summed over the walls (hard walls, no ghosts)
+FG_DEV void wall_forces(const FgParams& P, float2 p, float size, float& fx, float& fy) {
+    for (int w = 0; w < P.num_walls && w < FG_MAX_WALLS; ++w) {
+        const FgWall wl = P.walls[w];
+        const float prll = wl.vertical ? p.y : p.x;
+        const float perp = wl.vertical ? p.x : p.y;
+        if (prll < wl.end0 - size || prll > wl.end1 + size) continue;      // beyond the endpoints
+        float ct = 1.0f, st = 0.0f;
+        if (prll < wl.end0 || prll > wl.end1) {                            // rounding the corner
+            const float past = (prll < wl.end0) ? prll - wl.end0 : prll - wl.end1;
+            st = past / size;                                              // sin(theta)
+            ct = sqrtf(fmaxf(1.0f - st * st, 0.0f));
+        }
+        const float dmin = ct * size + 0.5f * wl.width;
+        const float delta = perp - wl.axis_pos;
+        const float dist = fabsf(delta);
+        const float x = (dmin - dist) / P.contact_margin;
+        const float pen = P.contact_margin * (fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))));
+        const float mag = P.contact_force * delta / dist * pen;            // dist == 0 -> NaN, as the reference
+        const float f_perp = ct * mag, f_prll = st * fabsf(mag);
+        if (wl.vertical) { fx += f_perp; fy += f_prll; } else { fy += f_perp; fx += f_prll; }
+    }
+}
+
+// action force incl. accel (core.py:236, environment.py:219-220) and motor noise (core.py:232-233)
+FG_DEV float2 action_force(const FgParams& P, float2 u, uint32_t b, uint32_t i, uint64_t offset) {
+    const float gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
+    float2 f = make_float2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
+    if (P.u_noise > 0.0f) {
+        uint32_t c[4] = {b, i ^ 0x80000000u, (uint32_t)offset, (uint32_t)(offset >> 32)};
+        philox4x32(c, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+        const float r = sqrtf(-2.0f * logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));
+        const float a = 6.2831853f * ((float)(c[1] >> 8) * (1.0f / 16777216.0f));
+        f.x += P.u_noise * r * cosf(a);
+        f.y += P.u_noise * r * sinf(a);
+    }
+    return f;
+}
+
+FG_DEV float2 clamp_speed(const FgParams& P, float2 v) {                    // core.py:271-276
+    if (P.max_speed > 0.0f) {
+        const float speed = sqrtf(v.x * v.x + v.y * v.y);
+        if (speed > P.max_speed) { v.x = v.x / speed * P.max_speed; v.y = v.y / speed * P.max_speed; }
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
 // World.step pair force on one agent (core.py:289-322, ratio m_b/m_a = 1)
 // ---------------------------------------------------------------------------
 FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, float2 p,
@@ -499,10 +549,12 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
                 float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
-                f.x += a.p.mass * (a.p.sensitivity * u.x);
-                f.y += a.p.mass * (a.p.sensitivity * u.y);
+                const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
+                f.x += fa.x; f.y += fa.y;
+                if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
                 v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
                 v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
+                v = clamp_speed(a.p, v);
                 p.x += v.x * dt;
                 p.y += v.y * dt;
                 A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
@@ -766,11 +818,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             }
             if (is_agent) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
-                fx += a.p.mass * (a.p.sensitivity * u.x);
-                fy += a.p.mass * (a.p.sensitivity * u.y);
+                const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset);
+                fx += fa.x; fy += fa.y;
             }
+            if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
             v.x = v.x * (1.0f - a.p.damping) + (fx / a.p.mass) * a.p.dt;
             v.y = v.y * (1.0f - a.p.damping) + (fy / a.p.mass) * a.p.dt;
+            if (is_agent) v = clamp_speed(a.p, v);
             p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
             POST[i] = p;
             if (is_agent) {
@@ -980,6 +1034,8 @@ static int check_params(const FgParams* p) {
     if (!p) return fail(FG_ERR_BAD_ARG, "params is NULL%s");
     if (!(p->mass > 0.f) || !(p->contact_margin > 0.f) || !(p->dt > 0.f))
         return fail(FG_ERR_BAD_ARG, "params: mass, contact_margin and dt must be > 0%s");
+    if (p->num_walls < 0 || p->num_walls > FG_MAX_WALLS || p->accel < 0.f || p->max_speed < 0.f || p->u_noise < 0.f)
+        return fail(FG_ERR_BAD_ARG, "params: 0 <= num_walls <= 4, accel/max_speed/u_noise >= 0%s");
     return FG_OK;
 }
 

@@ -14,13 +14,20 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_WALLS = 4
 
 FG_OK = 0
 FG_ERR_BAD_ARG = -1
 FG_ERR_UNSUPPORTED_N = -2
 FG_ERR_ALIGNMENT = -3
 FG_ERR_HIP = -4
+
+
+class FgWall(ctypes.Structure):
+    """Mirror of `struct FgWall`."""
+    _fields_ = [("vertical", ctypes.c_int32), ("axis_pos", ctypes.c_float), ("end0", ctypes.c_float),
+                ("end1", ctypes.c_float), ("width", ctypes.c_float), ("reserved", ctypes.c_int32)]
 
 
 class FgParams(ctypes.Structure):
@@ -38,6 +45,11 @@ class FgParams(ctypes.Structure):
         ("auto_reset", ctypes.c_int32),
         ("seed", ctypes.c_uint64),
         ("rng_offset", ctypes.c_uint64),
+        ("accel", ctypes.c_float),
+        ("max_speed", ctypes.c_float),
+        ("u_noise", ctypes.c_float),
+        ("num_walls", ctypes.c_int32),
+        ("walls", FgWall * 4),
     ]
 
 

@@ -103,8 +103,9 @@ class Action(object):
 
 
 class Wall(object):
-    """Wall description (core.py:27-41).  No BASELINE scenario creates walls
-    (world.walls == []); kept for API completeness, not simulated yet."""
+    """Wall description (core.py:27-41).  No reference scenario creates walls
+    (world.walls == []); when present (at most 4, hard) they are simulated in-kernel
+    (core.py:325-362)."""
 
     def __init__(self, orient="H", axis_pos=0.0, endpoints=(-1, 1), width=0.1, hard=True):
         self.orient = orient
@@ -260,18 +261,30 @@ class World(object):
         if len(sizes) != 1 or len(masses) != 1:
             raise NotImplementedError("kernels assume identical agent size and mass")
         for a in self.agents:
-            if a.max_speed is not None or a.u_noise or not a.movable or not a.collide:
-                raise NotImplementedError("max_speed / u_noise / immovable or ghost agents are not "
-                                          "reachable from the reference's make_env and not built")
-        if self.walls:
-            raise NotImplementedError("walls are inactive in every reference scenario and not built")
+            if not a.movable or not a.collide or a.ghost:
+                raise NotImplementedError("immovable / non-colliding / ghost agents do not occur in the "
+                                          "reference scenarios and are not built")
+        opts = {(a.max_speed, a.accel, a.u_noise) for a in self.agents}
+        if len(opts) != 1:
+            raise NotImplementedError("kernels assume identical max_speed / accel / u_noise for all agents")
+        if len(self.walls) > _native.MAX_WALLS:
+            raise NotImplementedError("at most %d walls" % _native.MAX_WALLS)
+        if any(not w.hard for w in self.walls):
+            raise NotImplementedError("soft walls only matter for ghost entities, which are not built")
         sens = a0.accel if a0.accel is not None else sensitivity     # environment.py:218-220
-        return _native.FgParams(
+        p = _native.FgParams(
             dt=self.dt, damping=self.damping, contact_force=self.contact_force,
             contact_margin=self.contact_margin, sensitivity=sens, mass=a0.mass,
             dist_min=a0.size + a0.size, collide_thresh=collide_thresh,
             world_length=int(self.world_length), auto_reset=1 if auto_reset else 0,
-            seed=int(seed), rng_offset=int(rng_offset))
+            seed=int(seed), rng_offset=int(rng_offset),
+            accel=float(a0.accel or 0.0), max_speed=float(a0.max_speed or 0.0),
+            u_noise=float(a0.u_noise or 0.0), num_walls=len(self.walls))
+        for k, w in enumerate(self.walls):
+            p.walls[k] = _native.FgWall(vertical=0 if w.orient == "H" else 1, axis_pos=float(w.axis_pos),
+                                        end0=float(w.endpoints[0]), end1=float(w.endpoints[1]),
+                                        width=float(w.width), reserved=0)
+        return p
 
     def step(self, sensitivity=5.0):
         """World.step (core.py:206-225) for all envs: action force, all-pairs

@@ -44,8 +44,9 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 1
+#define FG_ABI_VERSION 2
 #define FG_MAX_AGENTS 1024
+#define FG_MAX_WALLS 4
 
 typedef enum FgStatus {
     FG_OK = 0,
@@ -68,7 +69,20 @@ typedef enum FgStatus {
  *                      (when done: re-initialise the env on device and return the RESET
  *                      observation together with the pre-reset reward/done)
  *   seed, rng_offset  counter-RNG key / per-call offset for the device-side reset
- *                   (distributional parity with formation_hd_env.py:77-95 only)          */
+ *                   (distributional parity with formation_hd_env.py:77-95 only)
+ * World options that no reference scenario switches on (0 = None, the reference default):
+ *   accel           core.py:236 + environment.py:219-220: force = mass*accel*(accel*action)
+ *   max_speed       core.py:271-276 speed clamp after the velocity update
+ *   u_noise         core.py:232-233 Gaussian motor noise (device counter RNG, distributional parity)
+ *   walls           core.py:27-41,255-261,325-362 get_wall_collision_force, hard walls            */
+typedef struct FgWall {
+    int32_t vertical;    /* orient: 0 = 'H' (lies on y = axis_pos), 1 = 'V' */
+    float axis_pos;
+    float end0, end1;    /* endpoints along the wall */
+    float width;
+    int32_t reserved;
+} FgWall;
+
 typedef struct FgParams {
     float dt;
     float damping;
@@ -82,6 +96,11 @@ typedef struct FgParams {
     int32_t auto_reset;
     uint64_t seed;
     uint64_t rng_offset;
+    float accel;
+    float max_speed;
+    float u_noise;
+    int32_t num_walls;
+    FgWall walls[FG_MAX_WALLS];
 } FgParams;
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:

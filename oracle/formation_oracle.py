@@ -133,7 +133,33 @@ def reset_basic(seed, N, L=3):
 # batched vectorised oracle
 # --------------------------------------------------------------------------
 
-def physics_step(pos, vel, act, P, dtype=np.float64):
+GOLDEN_WALLS = [("V", -0.9, (-1.0, 1.0), 0.1), ("V", 0.9, (-0.6, 0.6), 0.1), ("H", 0.8, (-0.5, 0.5), 0.2)]
+
+
+def wall_force(pos, size, wall, P, dtype=np.float64):
+    """core.py:325-362 get_wall_collision_force for every entity [B,N,2] against one wall
+    (orient, axis_pos, endpoints, width); hard wall, no ghosts."""
+    orient, axis_pos, ep, width = wall
+    prll, perp = (0, 1) if orient == "H" else (1, 0)
+    x = pos[..., prll]
+    beyond = (x < ep[0] - size) | (x > ep[1] + size)
+    partial = ~beyond & ((x < ep[0]) | (x > ep[1]))
+    past = np.where(x < ep[0], x - ep[0], x - ep[1])
+    with np.errstate(invalid="ignore"):
+        theta = np.where(partial, np.arcsin(np.clip(past / size, -1, 1)), 0.0)
+    dist_min = np.where(partial, np.cos(theta) * size + 0.5 * width, size + 0.5 * width)
+    delta = pos[..., perp] - axis_pos
+    dist = np.abs(delta)
+    pen = softplus_penetration(dist, dist_min, dtype(P.contact_margin))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mag = dtype(P.contact_force) * delta / dist * pen
+    f = np.zeros_like(pos)
+    f[..., perp] = np.cos(theta) * mag
+    f[..., prll] = np.sin(theta) * np.abs(mag)
+    return np.where(beyond[..., None], dtype(0), f)
+
+
+def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None):
     """World.step for agent-only colliders (core.py:206-322 with the early-outs
     of :292-297 applied: landmarks have collide=False, so only agent-agent
     pairs survive).  pos, vel, act: [B,N,2].  Returns new (pos, vel).
@@ -146,7 +172,10 @@ def physics_step(pos, vel, act, P, dtype=np.float64):
     pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
     act = np.asarray(act, dtype=dtype)
     B, N, _ = pos.shape
-    F = dtype(P.mass) * (dtype(P.sensitivity) * act)
+    if accel is None:
+        F = dtype(P.mass) * (dtype(P.sensitivity) * act)
+    else:                                  # environment.py:219-220 and core.py:236 both use accel
+        F = dtype(P.mass * accel) * (dtype(accel) * act)
     delta = pos[:, :, None, :] - pos[:, None, :, :]            # [B,i,j,2] = p_i - p_j
     dist = np.sqrt((delta ** 2).sum(-1))                       # [B,i,j]
     pen = softplus_penetration(dist, dtype(P.dist_min), dtype(P.contact_margin))
@@ -155,7 +184,13 @@ def physics_step(pos, vel, act, P, dtype=np.float64):
     eye = np.eye(N, dtype=bool)[None, :, :, None]
     f = np.where(eye, dtype(0), f)                             # core.py:296 same entity
     F = F + f.sum(2)
+    for w in (walls or []):                                    # core.py:255-261
+        F = F + wall_force(pos, dtype(P.agent_size), w, P, dtype)
     vel = vel * dtype(1 - P.damping) + (F / dtype(P.mass)) * dtype(P.dt)
+    if max_speed is not None:                                  # core.py:271-276
+        speed = np.sqrt((vel ** 2).sum(-1, keepdims=True))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vel = np.where(speed > max_speed, vel / speed * dtype(max_speed), vel)
     pos = pos + vel * dtype(P.dt)
     return pos, vel
 
@@ -213,12 +248,12 @@ def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64):
                 velterm=velterm, H=H)
 
 
-def step_hd(state, act, P=None, dtype=np.float64):
+def step_hd(state, act, P=None, dtype=np.float64, **world_options):
     """One MultiAgentEnv.step of formation_hd_env for B envs (environment.py:
     113-142).  `state` = dict(pos, vel, ideal_shape, ideal_vel, step); returns
     (new_state, out) with out = dict(obs, reward[B,N,1], done[B,N], indiv, ...)."""
     P = P or HdParams()
-    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype)
+    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype, **world_options)
     step = np.asarray(state["step"]) + 1                       # environment.py:114
     out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype)
     out["obs"] = observation_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], dtype)

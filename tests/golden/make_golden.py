@@ -118,8 +118,13 @@ def _hd_extras(pos, shape, thresh):
                 cnt_margin=np.array(off.min()))
 
 
-def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None):
-    """Seeded rollout of formation_hd_env through the reference API."""
+WALLS = [("V", -0.9, (-1.0, 1.0), 0.1), ("V", 0.9, (-0.6, 0.6), 0.1), ("H", 0.8, (-0.5, 0.5), 0.2)]
+
+
+def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=None):
+    """Seeded rollout of formation_hd_env through the reference API.  `options` switches on
+    the World features no reference scenario enables: max_speed (core.py:271-276), accel
+    (core.py:236, environment.py:219-220), walls (core.py:255-261,325-362)."""
     obs_at = set(obs_at or [1, T])
     acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
     out = {k: [] for k in ("pos", "vel", "indiv", "shared", "done", "hd", "hd_idx",
@@ -128,6 +133,13 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None):
     pos0, vel0, shp, ivel, obs0 = [], [], [], [], []
     for b in range(B):
         env = fg.make_env("formation_hd_env", False, N)
+        if options:
+            import formation_gym.core as rcore
+            for a in env.world.agents:
+                a.max_speed = options.get("max_speed")
+                a.accel = options.get("accel")
+            if options.get("walls"):
+                env.world.walls = [rcore.Wall(o, ax, ep, w) for (o, ax, ep, w) in WALLS]
         env.seed(seed + 1000 * b)
         o0 = env.reset()
         sc = _scenario_of(env)
@@ -336,6 +348,8 @@ def main():
     save("hd_n4", lambda: rollout_hd(fg, 4, 3, 10, seed=21, act_seed=31))
     save("hd_n10", lambda: rollout_hd(fg, 10, 2, 10, seed=22, act_seed=32, crowd=0.3))
     # done flip of formation_hd_env at world_length = 100
+    save("hd_n9_options", lambda: rollout_hd(fg, 9, 4, 30, seed=23, act_seed=33, options=dict(max_speed=0.6, accel=3.0, walls=True)))
+    save("hd_n27_walls", lambda: rollout_hd(fg, 27, 2, 20, seed=24, act_seed=34, options=dict(walls=True)))
     save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
     # config 1: basic_formation_env, N=3, incl. the done flip at step 50
     save("basic_n3", lambda: rollout_basic(fg, 3, 52, seed=1, act_seed=20))

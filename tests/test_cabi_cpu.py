@@ -36,16 +36,29 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_native.SIGNATURES) == names
 
 
-def test_abi_version_and_struct_layout(lib):
-    assert lib.fg_abi_version() == _native.ABI_VERSION == 1
-    text = open(HEADER).read()
-    assert "#define FG_ABI_VERSION 1" in text
-    body = re.search(r"typedef struct FgParams \{(.*?)\} FgParams;", text, re.S).group(1)
-    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b(float|int32_t|uint64_t)\s+(\w+);", body)
-    ctype = {"float": ctypes.c_float, "int32_t": ctypes.c_int32, "uint64_t": ctypes.c_uint64}
-    assert [(n, ctype[t]) for t, n in fields] == list(_native.FgParams._fields_)
-    assert ctypes.sizeof(_native.FgParams) == 8 * 4 + 2 * 4 + 2 * 8
+def test_abi_version_and_struct_layout(lib, tmp_path):
+    """The ctypes mirrors must have the C layout: compile the header with gcc and compare
+    sizeof / offsetof of every field."""
+    import subprocess
+    assert lib.fg_abi_version() == _native.ABI_VERSION == 2
+    assert "#define FG_ABI_VERSION 2" in open(HEADER).read()
+    structs = {"FgParams": _native.FgParams, "FgScenario": _native.FgScenario, "FgWall": _native.FgWall}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "formation_hip.h"', 'int main(void){']
+    for name, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (name, name))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (name, fname, name, fname))
+    lines.append('return 0;}')
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (name, fname)]) == getattr(cls, fname).offset, (name, fname)
+    assert _native.MAX_WALLS == 4 and "#define FG_MAX_WALLS 4" in open(HEADER).read()
 
 
 def test_algorithmic_bytes_and_geometry(lib):
@@ -62,7 +75,8 @@ def test_algorithmic_bytes_and_geometry(lib):
 
 def _params(**kw):
     d = dict(dt=0.1, damping=0.25, contact_force=100.0, contact_margin=1e-3, sensitivity=5.0, mass=1.0,
-             dist_min=0.06, collide_thresh=0.03, world_length=100, auto_reset=0, seed=0, rng_offset=0)
+             dist_min=0.06, collide_thresh=0.03, world_length=100, auto_reset=0, seed=0, rng_offset=0,
+             accel=0.0, max_speed=0.0, u_noise=0.0, num_walls=0)
     d.update(kw)
     return _native.FgParams(**d)
 
@@ -83,12 +97,18 @@ def test_argument_validation_before_any_launch(lib):
     assert b"aligned" in lib.fg_last_error()
     assert lib.fg_step_hd(None, 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_hd(_params(mass=0.0), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_hd(_params(num_walls=5), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_hd(_params(max_speed=-1.0), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
     assert lib.fg_physics_step(P, 4, 1, *([p] * 6)) == _native.FG_ERR_UNSUPPORTED_N
     assert lib.fg_observe_hd(P, 4, 9, p, p, p, p, p, p, p, None, None, None, None, None, None, None, None) \
         == _native.FG_ERR_BAD_ARG                                                      # nothing to write
     assert lib.fg_rollout_hd(P, 4, 9, 0, *([p] * 12), 1, None) == _native.FG_ERR_BAD_ARG   # K <= 0
     assert lib.fg_reset_hd(P, 4, 5000, *([p] * 9)) == _native.FG_ERR_UNSUPPORTED_N
     assert lib.fg_step_basic(P, 4, 100, 3, 1, *([p] * 13)) == _native.FG_ERR_UNSUPPORTED_N
+    sc = _native.FgScenario(kind=_native.FG_SCN_OBSTACLE, num_landmarks=4, num_obstacles=3, penalty=2.0)
+    assert lib.fg_step_scenario(P, sc, 4, 62, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 64
+    assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     with pytest.raises(_native.FormationHipError):
         _native.check(lib.fg_step_hd(P, 0, 9, *ok_ptrs))
 

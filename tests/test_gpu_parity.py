@@ -462,3 +462,47 @@ def test_demo_driver_runs():
     assert "env-steps/s" in out
     out = _run(["gym-formation_amd/demo.py", "-s", "formation_hd_obs_env", "-n", "4", "-r", "--num-envs", "32", "--steps", "60"])
     assert "env-steps/s" in out
+
+
+@pytest.mark.parametrize("name,opts", [("hd_n9_options", dict(max_speed=0.6, accel=3.0, walls=True)),
+                                        ("hd_n27_walls", dict(walls=True))])
+def test_world_options_teacher_forced(golden, name, opts):
+    """max_speed, accel and walls (World features the reference scenarios leave off)."""
+    from formation_gym.core import Wall
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    for a in env.world.agents:
+        a.max_speed = opts.get("max_speed")
+        a.accel = opts.get("accel")
+    if opts.get("walls"):
+        env.world.walls = [Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS]
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        _load(env, prev_pos, prev_vel, g["ideal_shape"], g["ideal_vel"], np.full(B, t))
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    if opts.get("max_speed"):
+        assert float(torch.stack(env.world.get_state()[1:]).norm(dim=-1).max()) <= opts["max_speed"] * (1 + 1e-5)
+
+
+def test_motor_noise_is_gaussian_with_the_requested_scale():
+    """u_noise (core.py:232-233): device counter RNG, distributional parity only."""
+    N, B = 9, 2048
+    env = _make(N, B)
+    st = O.reset_hd(1 + 1000 * np.arange(B), N)
+    _load(env, st["pos"] * 3.0, st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])   # spread out: no contacts
+    ref = _make(N, B)
+    _load(ref, st["pos"] * 3.0, st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    for a in env.world.agents:
+        a.u_noise = 0.5
+    act = torch.zeros((B, N, 2), device="cuda")
+    env.step(act); ref.step(act)
+    dv = (env.world.get_state()[1] - ref.world.get_state()[1]) / 0.1          # = noise force (mass 1, dt 0.1)
+    assert abs(float(dv.mean())) < 0.02 and abs(float(dv.std()) - 0.5) < 0.02
+    env.step(act)
+    dv2 = (env.world.get_state()[1] - ref.world.get_state()[1])
+    assert float((dv2 / 0.1 - 0.75 * dv).std()) > 0.3                           # fresh noise every step

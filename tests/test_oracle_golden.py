@@ -228,3 +228,20 @@ def test_remaining_scenarios_reset_stream(golden, kind, name):
         np.testing.assert_array_equal(st["landmarks"][0], g["lm0"][b][:P.num_landmarks])
         np.testing.assert_array_equal(st["obst_pos"][0], g["lm0"][b][P.num_landmarks:])
         np.testing.assert_array_equal(st["obst_vel"][0], g["lmvel0"][b][P.num_landmarks:])
+
+
+@pytest.mark.parametrize("name,opts", [("hd_n9_options", dict(max_speed=0.6, accel=3.0, walls=O.GOLDEN_WALLS)),
+                                        ("hd_n27_walls", dict(walls=O.GOLDEN_WALLS))])
+def test_world_options_match_reference(golden, name, opts):
+    """max_speed / accel / walls: World features no reference scenario switches on (f4)."""
+    g = golden(name)
+    B = g["pos0"].shape[0]
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(g["acts"].shape[0]):
+        st = dict(pos=prev_pos, vel=prev_vel, ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"],
+                  step=np.full(B, t, dtype=np.int32))
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64), **opts)
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
