@@ -155,7 +155,9 @@ FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
 // ---------------------------------------------------------------------------
 // core.py:325-362 get_wall_collision_force, summed over the walls (hard walls, no ghosts)
 FG_DEV void wall_forces(const FgParams& P, float2 p, float size, float& fx, float& fy) {
-    for (int w = 0; w < P.num_walls && w < FG_MAX_WALLS; ++w) {
+#pragma unroll
+    for (int w = 0; w < FG_MAX_WALLS; ++w) {                                   // static indices: no scratch copy
+        if (w >= P.num_walls) break;
         const FgWall wl = P.walls[w];
         const float prll = wl.vertical ? p.y : p.x;
         const float perp = wl.vertical ? p.x : p.y;
@@ -164,17 +166,25 @@ FG_DEV void wall_forces(const FgParams& P, float2 p, float size, float& fx, floa
         if (prll < wl.end0 || prll > wl.end1) {                            // rounding the corner
             const float past = (prll < wl.end0) ? prll - wl.end0 : prll - wl.end1;
             st = past / size;                                              // sin(theta)
-            ct = sqrtf(fmaxf(1.0f - st * st, 0.0f));
+            ct = __builtin_amdgcn_sqrtf(fmaxf(1.0f - st * st, 0.0f));
         }
         const float dmin = ct * size + 0.5f * wl.width;
         const float delta = perp - wl.axis_pos;
         const float dist = fabsf(delta);
         const float x = (dmin - dist) / P.contact_margin;
-        const float pen = P.contact_margin * (fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))));
-        const float mag = P.contact_force * delta / dist * pen;            // dist == 0 -> NaN, as the reference
+        const float pen = P.contact_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+        const float mag = P.contact_force * delta * __builtin_amdgcn_rcpf(dist) * pen;   // dist == 0 -> NaN, as the reference
         const float f_perp = ct * mag, f_prll = st * fabsf(mag);
         if (wl.vertical) { fx += f_perp; fy += f_prll; } else { fy += f_perp; fx += f_prll; }
     }
+}
+
+FG_DEV float2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset) {
+    uint32_t c[4] = {b, i ^ 0x80000000u, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float r = sqrtf(-2.0f * __logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));   // Box-Muller
+    const float a = 6.2831853f * ((float)(c[1] >> 8) * (1.0f / 16777216.0f));
+    return make_float2(r * __cosf(a), r * __sinf(a));
 }
 
 // action force incl. accel (core.py:236, environment.py:219-220) and motor noise (core.py:232-233)
@@ -182,12 +192,9 @@ FG_DEV float2 action_force(const FgParams& P, float2 u, uint32_t b, uint32_t i, 
     const float gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
     float2 f = make_float2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
     if (P.u_noise > 0.0f) {
-        uint32_t c[4] = {b, i ^ 0x80000000u, (uint32_t)offset, (uint32_t)(offset >> 32)};
-        philox4x32(c, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
-        const float r = sqrtf(-2.0f * logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));
-        const float a = 6.2831853f * ((float)(c[1] >> 8) * (1.0f / 16777216.0f));
-        f.x += P.u_noise * r * cosf(a);
-        f.y += P.u_noise * r * sinf(a);
+        const float2 n = motor_noise(P.seed, b, i, offset);
+        f.x += P.u_noise * n.x;
+        f.y += P.u_noise * n.y;
     }
     return f;
 }
@@ -481,8 +488,13 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ smem, float2* __restrict_
 //   IDX also emit the landmark-index assignments
 // LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-template <int NC, int G, int T, int E, bool IDX, int WR>
-__global__ __launch_bounds__(T) void step_kernel(const Args a) {
+#ifndef FG_WPS
+#define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
+#endif
+template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
+__global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) void step_kernel(const Args a) {
+    // OPTS: World options no reference scenario enables (accel, max_speed, u_noise, walls);
+    // compiled into a separate instantiation so that the common path keeps its registers.
     constexpr bool FLAT = (WR == 1);
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -549,12 +561,17 @@ __global__ __launch_bounds__(T) void step_kernel(const Args a) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
                 float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
-                const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
-                f.x += fa.x; f.y += fa.y;
-                if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
+                if constexpr (OPTS) {
+                    const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
+                    f.x += fa.x; f.y += fa.y;
+                    if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
+                } else {
+                    f.x += a.p.mass * (a.p.sensitivity * u.x);
+                    f.y += a.p.mass * (a.p.sensitivity * u.y);
+                }
                 v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
                 v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
-                v = clamp_speed(a.p, v);
+                if constexpr (OPTS) v = clamp_speed(a.p, v);
                 p.x += v.x * dt;
                 p.y += v.y * dt;
                 A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
@@ -952,28 +969,31 @@ struct Geometry { int G, T, E, lds; };
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int NC, int G, int T, int E, bool IDX, int WR>
+template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR>), dim3(grid), dim3(T), lds, st, a);
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR, OPTS>), dim3(grid), dim3(T), lds, st, a);
     return hipGetLastError();
 }
 
 using LaunchFn = hipError_t (*)(const Args&, int, int, hipStream_t);
 // wr: observation writer 0 = register-cached rows, 1 = flat decode (run-time N), 1 + RT = LDS tiles of RT rows
-struct Variant { int NC, G, T, E, wr; LaunchFn plain, idx; };
-#define FG_VARIANT_W(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W>, &launch_v<NC, G, T, E, true, W>}
+struct Variant { int NC, G, T, E, wr; LaunchFn plain, idx, opts; };   // opts: IDX + World options
+#define FG_VARIANT_W(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W, false>, \
+                                      &launch_v<NC, G, T, E, true, W, false>, nullptr}
+#define FG_VARIANT_O(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W, false>, \
+                                      &launch_v<NC, G, T, E, true, W, false>, &launch_v<NC, G, T, E, true, W, true>}
 #define FG_VARIANT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, ((NC) == 0 ? 1 : 0))
 #define FG_VARIANT_FLAT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, 1)
 
 // The first entry of a given NC is the default; the others are selectable with
 // FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
 static const Variant kVariants[] = {
-    FG_VARIANT(3, 4, 128, 16), FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8),
-    FG_VARIANT(9, 16, 128, 4), FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 8),
-    FG_VARIANT(27, 32, 256, 4), FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
+    FG_VARIANT_O(3, 4, 128, 16, 0), FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8),
+    FG_VARIANT_O(9, 16, 128, 4, 0), FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 8),
+    FG_VARIANT_O(27, 32, 256, 4, 0), FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
     FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 512, 4),
-    FG_VARIANT(81, 128, 128, 1), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
-    FG_VARIANT(243, 256, 256, 1), FG_VARIANT(243, 256, 512, 1),
+    FG_VARIANT_O(81, 128, 128, 1, 0), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
+    FG_VARIANT_O(243, 256, 256, 1, 0), FG_VARIANT(243, 256, 512, 1),
     // flat float4 writer kept for A/B runs (FG_FLAT=1)
     FG_VARIANT_FLAT(27, 32, 256, 4), FG_VARIANT_FLAT(27, 32, 128, 4), FG_VARIANT_FLAT(9, 16, 128, 4),
     FG_VARIANT_FLAT(81, 128, 128, 1), FG_VARIANT_FLAT(243, 256, 256, 1),
@@ -982,14 +1002,18 @@ static const Variant kVariants[] = {
     FG_VARIANT_W(27, 32, 256, 4, 10), FG_VARIANT_W(27, 32, 128, 4, 10), FG_VARIANT_W(27, 32, 128, 2, 10), FG_VARIANT_W(27, 32, 64, 2, 10),
     FG_VARIANT_W(27, 32, 256, 2, 10), FG_VARIANT_W(27, 32, 256, 2, 4),
     FG_VARIANT_W(9, 16, 128, 4, 10), FG_VARIANT_W(9, 16, 64, 4, 10),
-    FG_VARIANT(0, 4, 64, 16), FG_VARIANT(0, 8, 64, 8), FG_VARIANT(0, 16, 64, 4), FG_VARIANT(0, 32, 128, 4),
-    FG_VARIANT(0, 64, 128, 2), FG_VARIANT(0, 128, 128, 1), FG_VARIANT(0, 256, 256, 1),
-    FG_VARIANT(0, 512, 512, 1), FG_VARIANT(0, 1024, 1024, 1),
+    FG_VARIANT_O(0, 4, 64, 16, 1), FG_VARIANT_O(0, 8, 64, 8, 1), FG_VARIANT_O(0, 16, 64, 4, 1), FG_VARIANT_O(0, 32, 128, 4, 1),
+    FG_VARIANT_O(0, 64, 128, 2, 1), FG_VARIANT_O(0, 128, 128, 1, 1), FG_VARIANT_O(0, 256, 256, 1, 1),
+    FG_VARIANT_O(0, 512, 512, 1, 1), FG_VARIANT_O(0, 1024, 1024, 1, 1),
 };
 
-static const Variant* variant_for(int N, int B = 0) {
+static const Variant* variant_for(int N, int B = 0, bool need_opts = false) {
     if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
     int want_t = 0, want_e = 0, want_flat = 0;
+    if (need_opts) {                      // the first entry of every NC (and every generic one) carries OPTS
+        for (const Variant& v : kVariants) if (v.NC == N && v.opts) return &v;
+        B = 0;
+    }
     // Size-aware default (MI355X sweep, profiles/): a batch that fills the chip several times
     // over streams best with no idle waves and 1 KiB tile stores; a single-generation batch
     // (27 x 4096 = 4 workgroups per CU) is latency-bound and prefers spare writer waves.
@@ -998,6 +1022,7 @@ static const Variant* variant_for(int N, int B = 0) {
     if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
     for (const Variant& v : kVariants) {
+        if (need_opts) break;
         if (v.NC != N || v.wr != want_flat) continue;
         if (!dflt) dflt = &v;
         if (v.T == want_t && v.E == want_e) return &v;
@@ -1009,8 +1034,8 @@ static const Variant* variant_for(int N, int B = 0) {
     return nullptr;
 }
 
-static bool geometry_for(int N, Geometry* g, int B = 0) {
-    const Variant* v = variant_for(N, B);
+static bool geometry_for(int N, Geometry* g, int B = 0, bool need_opts = false) {
+    const Variant* v = variant_for(N, B, need_opts);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
     g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
@@ -1020,12 +1045,13 @@ static bool geometry_for(int N, Geometry* g, int B = 0) {
 
 static int launch_step(Args a, hipStream_t st) {
     Geometry g;
-    const Variant* v = variant_for(a.N, a.B);
-    if (!v || !geometry_for(a.N, &g, a.B)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
+    const Variant* v = variant_for(a.N, a.B, opts);
+    if (!v || !geometry_for(a.N, &g, a.B, opts)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
     const int grid = (a.B + g.E - 1) / g.E;
     if (const char* s = getenv("FG_NT")) a.nt_store = atoi(s);
-    const hipError_t err = (idx ? v->idx : v->plain)(a, grid, g.lds, st);
+    const hipError_t err = (opts ? v->opts : idx ? v->idx : v->plain)(a, grid, g.lds, st);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
