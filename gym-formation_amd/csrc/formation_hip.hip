@@ -323,19 +323,21 @@ FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
     return make_float2(c ? t.x : 0.0f, c ? t.y : 0.0f);
 }
 
-template <int NC, int T, int E>
-FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__ out_env0, int El, int parts) {
+template <int NC, int NW, int E>
+FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
+                           float2* __restrict__ out_env0, int El, int parts) {
+    // tables0 / env_stride: A-table of env 0 and the distance (float2) to the next env's;
+    // w: index of this wave among the NW waves that share the job
     // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
     constexpr int N = NC;
-    constexpr int NW = T / 64;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;             // waves sharing one env
     constexpr int ESTEP = (E >= NW) ? NW : 1;               // env stride of one wave
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int row0 = (E >= NW) ? 0 : w % WPE;
     constexpr unsigned ROWU = 3u * N;                       // units per row
     for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
-        const float2* __restrict__ AA = env_tables(smem, ee, N);
+        const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
         float2* __restrict__ out = out_env0 + (size_t)ee * (ROWU * N);
         if constexpr (N <= 64) {
             // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
@@ -420,16 +422,15 @@ FG_DEV void write_obs_rows(const float2* __restrict__ smem, float2* __restrict__
 // ---------------------------------------------------------------------------
 template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 + 1) & ~1; }
 
-template <int NC, int T, int E, int RT>
-FG_DEV void write_obs_tiled(const float2* __restrict__ smem, float2* __restrict__ tiles,
+template <int NC, int NW, int E, int RT>
+FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
                             float2* __restrict__ out_env0, size_t unit0, int El) {
     constexpr int N = NC;
-    constexpr int NW = T / 64;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
     static_assert(N <= 32 && N % RT == 0, "tiled writer: N <= 32, RT divides N");
     constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     float2* __restrict__ tile0 = tiles + w * tile_units<NC, RT>();
     constexpr int RW = 64 / N;
     const int rsub = lane / N, u = lane - rsub * N;
@@ -438,7 +439,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ smem, float2* __restrict_
     constexpr int RS = 64 / (2 * N);
     const int ssub = lane / (2 * N), sidx = lane - ssub * 2 * N;
     for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? NW : E)) {
-        const float2* __restrict__ AA = env_tables(smem, ee, N);
+        const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
         const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
         const float2 Pu = lds_if(act && u >= 1, AA, u);
         const float2 sv = lds_if(ssub < RS, AA, N + sidx);
@@ -663,12 +664,14 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
             // ---- phase 5: observations --------------------------------------
             if (want_obs && NC > 0 && !FLAT) {
                 if constexpr (NC > 0 && WR == 0)
-                    write_obs_rows<NC, T, E>(smem, reinterpret_cast<float2*>(a.obs) +
-                                             ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El, 3);
+                    write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
+                                                  reinterpret_cast<float2*>(a.obs) +
+                                                  ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El, 3);
                 if constexpr (NC > 0 && WR >= 2) {
                     const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
                     float2* tiles = env_tables(smem, E, N) + 36;            // after env blocks + 72 floats of scratch
-                    write_obs_tiled<NC, T, E, WR - 2 + 1>(smem, tiles, reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+                    write_obs_tiled<NC, T / 64, E, WR - 2 + 1>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6, tiles,
+                                                               reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
                 }
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
@@ -728,6 +731,164 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
         a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
     }
     if (a.do_phys && a.step && env_ok && i == 0) a.step[b] = t_step;
+}
+
+// ---------------------------------------------------------------------------
+// Pipelined K-step rollout (N <= 32): wave specialisation inside one workgroup.
+//   producer waves (tid < TP): agents on lanes as in step_kernel; they run World.step + reward
+//       of step k+1 while
+//   writer waves   (tid >= TP): stream the observations of step k,
+// handing over through double-buffered LDS tables and ONE workgroup barrier per step.
+// In a single-step launch the pair loops and reductions sit in front of the store stream;
+// here they hide under it, so the rollout runs at the store rate.  Everything a producer
+// needs from other lanes is produced by its own wave (G <= 64): LDS operations of one wave
+// complete in order and the reductions are in-register butterflies, so producers need no
+// barrier among themselves.
+// LDS per env (floats): tables[2][A[3N] | V[N] | NV[N]] (float2), then QX QY PX PY SX SY [NP].
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
+
+template <int NC, int G, int TP, int TW, int E, int WR>
+__global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
+    static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
+    constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float* const smemf = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const bool producer = tid < TP;
+    const int e = producer ? tid / G : 0;
+    const int i = tid % G;
+    const int b0 = blockIdx.x * E;
+    const int b = b0 + e;
+    const bool env_ok = producer && (b < a.B);
+    const bool valid = env_ok && (i < N);
+    const int El = min(E, a.B - b0);
+    float* const blk = smemf + e * roll_block_floats(N);
+    float2* const TB0 = reinterpret_cast<float2*>(blk);                 // tables of buffer 0; buffer 1 at + 5N
+    float* const QX = blk + 20 * N;
+    float* const QY = QX + NP; float* const PX = QY + NP; float* const PY = PX + NP;
+    float* const SX = PY + NP; float* const SY = SX + NP;
+
+    const float one_minus_damp = 1.0f - a.p.damping;
+    const float dt = a.p.dt;
+    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;
+    const float cutoff2 = cutoff * cutoff;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const float invN = 1.0f / (float)N;
+
+    float2 p = make_float2(0.f, 0.f), v = p, s = p, iv = p;
+    int t_step = 0;
+    const size_t sidx = (size_t)b * N + i;
+    if (valid) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        s = reinterpret_cast<const float2*>(a.shape)[sidx];
+        QX[i] = p.x; QY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
+        if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
+    } else if (env_ok && i < NP) {
+        QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+    }
+    if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+
+    // one producer step: World.step + reward of step k into table buffer (k & 1)
+    auto produce = [&](int k) {
+        float2* const A = TB0 + (k & 1) * 5 * N;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid) {
+            const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+            float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                                            a.p.dist_min, cutoff2);
+            f.x += a.p.mass * (a.p.sensitivity * u.x);
+            f.y += a.p.mass * (a.p.sensitivity * u.y);
+            v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
+            v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
+            p.x += v.x * dt;
+            p.y += v.y * dt;
+            PX[i] = p.x; PY[i] = p.y;
+        }
+        t_step += 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+        env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, nullptr);
+        const float mx = sums[0] * invN, my = sums[1] * invN;
+        const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+        float rowmin = INFINITY, colmin = INFINITY;
+        int cnt = 0, arg_lm = 0, arg_ag = 0;
+        if (valid)
+            reward_pass_packed<false>(PX, PY, SX, SY, NP, p, p.x - mx, p.y - my, s.x + mx, s.y + my, thr2,
+                                      rowmin, colmin, cnt, arg_lm, arg_ag);
+        float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+        env_reduce<G, G, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
+        const float H = sqrtf(fmaxf(red[0], red[1]));
+        const float ex = iv.x - mvx, ey = iv.y - mvy;
+        const float velterm = sqrtf(ex * ex + ey * ey);
+        const bool is_done = t_step >= a.p.world_length;
+        if (valid) {
+            const size_t o = ((size_t)k * a.B + b) * N + i;
+            if (a.rew) a.rew[o] = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt;
+            if (a.done) a.done[o] = is_done ? 1 : 0;
+        }
+        if (a.p.auto_reset) {
+            const bool mine = is_done && env_ok;
+            if (__any(mine) != 0) {
+                uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
+                                 (uint32_t)((a.p.rng_offset + k) >> 32)};
+                philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                const float rx = raw[0], ry = raw[1];
+                env_reduce<G, G, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, nullptr);
+                uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
+                                  (uint32_t)((a.p.rng_offset + k) >> 32)};
+                philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                if (mine) {
+                    iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                    t_step = 0;
+                    if (valid) {
+                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_float2(0.f, 0.f);
+                        s = make_float2(rx - raw[0] * invN, ry - raw[1] * invN);
+                        SX[i] = s.x; SY[i] = s.y;
+                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
+                        if (i == 0) reinterpret_cast<float2*>(a.ivel)[b] = iv;
+                    }
+                }
+            }
+        }
+        if (valid) {                                   // publish this step's tables + next step's partners
+            A[i] = p; A[3 * N + i] = v; A[4 * N + i] = make_float2(-v.x, -v.y);
+            A[2 * N - 1 + i] = s;
+            if (i == 0) A[3 * N - 1] = iv;
+            QX[i] = p.x; QY[i] = p.y;
+        }
+    };
+
+    if (producer) produce(0);
+    __syncthreads();
+    for (int k = 0; k < a.K; ++k) {
+        if (producer) {
+            if (k + 1 < a.K) produce(k + 1);
+        } else {
+            int slot = k;
+            bool want_obs = a.obs != nullptr;
+            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+            if (want_obs) {
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
+                if constexpr (WR == 0)
+                    write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                               reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
+                else
+                    write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                                        reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
+                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
+    if (a.step && env_ok && i == 0) a.step[b] = t_step;
 }
 
 // ---------------------------------------------------------------------------
@@ -1168,6 +1329,38 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
+    // K >= 2 at the specialised small N: producer / writer pipelined kernel
+    const char* nopipe = getenv("FG_NOPIPE");
+    if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
+        int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
+        if (const char* e = getenv("FG_TW")) tw = atoi(e);
+        hipStream_t st = (hipStream_t)stream;
+        hipError_t err = hipSuccess;
+        int wr = 10;
+        if (const char* e = getenv("FG_ROLLWR")) wr = atoi(e);
+#define FG_ROLL(NCV, GV, TPV, TWV, EV, WRV)                                                              \
+        {   const int grid = (B + (EV) - 1) / (EV);                                                      \
+            int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                                \
+            if ((WRV) > 0) lds += ((TWV) / 64) * ((3 * (NCV) * ((WRV) - 1) + 3) & ~1) * (int)sizeof(float2); \
+            hipLaunchKernelGGL((rollout_kernel<NCV, GV, TPV, TWV, EV, WRV>), dim3(grid), dim3((TPV) + (TWV)), lds, st, a); \
+            err = hipGetLastError(); }
+        if (N == 27) {
+            int re = 8;
+            if (const char* e = getenv("FG_ROLLE")) re = atoi(e);
+            if (re == 2) { if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 10) else FG_ROLL(27, 32, 64, 128, 2, 10) }
+                           else { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 0) else FG_ROLL(27, 32, 64, 128, 2, 0) } }
+            else if (re == 8) { if (wr == 10) { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 10) else FG_ROLL(27, 32, 256, 256, 8, 10) }
+                                else { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 0) else FG_ROLL(27, 32, 256, 256, 8, 0) } }
+            else
+            if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 10) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 10) else FG_ROLL(27, 32, 128, 128, 4, 10) }
+            else { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 0) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 0) else FG_ROLL(27, 32, 128, 128, 4, 0) }
+        }
+        else if (N == 9) FG_ROLL(9, 16, 64, 64, 4, 0)
+        else FG_ROLL(3, 4, 64, 64, 16, 0)
+#undef FG_ROLL
+        if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
+        return FG_OK;
+    }
     return launch_step(a, (hipStream_t)stream);
 }
 
