@@ -6,7 +6,13 @@
 
 A "step" is one pass of the hot path (MultiAgentEnv.step: _set_action ->
 World.step -> observation/reward/done for every agent) over one batch of B
-environments per GPU = one launch of the fused HIP kernel `fg_step_hd`.
+environments per GPU.  Two launch modes, both doing and writing exactly the
+same per-step work (every observation of every step lands in HBM):
+  rollout (default)  `fg_rollout_hd`: --chunk consecutive steps per launch with
+                     pre-staged actions, outputs to [K,B,N,...] rollout buffers
+                     (SURVEY.md 7.4 K4 / 8(d) "pre-staged [K,B,N,2]");
+  step               `fg_step_hd`: one launch per env.step (what a policy in
+                     the loop uses); reported beside it as `other_mode`.
 Workload (BASELINE.json configs[2], the shape the north-star target is quoted
 on): formation_hd_env, 27 agents x 4096 envs per GPU, fp32, synthetic
 random-policy rollout: env b starts from np.random.RandomState(1 + 1000 b) in
@@ -32,17 +38,19 @@ for _p in (ROOT, PKG):
 HBM_PEAK_GBPS = 8000.0          # MI355X spec peak (MI355X_MICROARCH.md); 6290 measured copy
 
 
-def measured_traffic(n_agents, envs):
-    """HBM bytes per launch from the newest committed rocprofv3 PMC summary for this workload
-    (profiles/*_<N>x<B>.json, made by profiles/run_profile.sh + summarize.py), else None."""
+def measured_traffic(n_agents, envs, mode, steps_per_launch):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary of this workload AND
+    launch mode (profiles/*_<N>x<B>*.json, made by profiles/run_profile.sh + summarize.py)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%dx%d.json" % (n_agents, envs)))):
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%dx%d*.json" % (n_agents, envs)))):
         try:
             d = json.load(open(f))
+            cfg = d["bench"]["config"]
         except Exception:
             continue
-        if "hbm_traffic_bytes_per_launch" in d:
+        if "hbm_traffic_bytes_per_launch" in d and cfg.get("mode") == mode and \
+                cfg.get("steps_per_launch", 1) == steps_per_launch:
             best = (d["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     return best
 
@@ -93,7 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--agents", type=int, default=27)
     ap.add_argument("--envs", type=int, default=4096, help="environments PER GPU")
-    ap.add_argument("--mode", choices=["step", "rollout"], default="step",
+    ap.add_argument("--mode", choices=["step", "rollout"], default="rollout",
                     help="step: one fg_step_hd launch per step; rollout: fg_rollout_hd, --chunk steps per launch")
     ap.add_argument("--chunk", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,7 +147,10 @@ def main():
     env.scenario._seed = 1 + rank
     env.world.step_count.zero_()
 
-    P = 64                                             # pre-staged action pool, cycled
+    N, B = a.agents, a.envs
+    # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
+    chunk = max(1, min(a.chunk, int(48e9 // (B * N * 6 * N * 4)) or 1))
+    P = 3 * chunk if chunk >= 8 else 64                # pre-staged action pool (whole launches), cycled
     gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
     act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
     out = env._out
@@ -186,7 +197,6 @@ def main():
 
     seq = None
     if a.mode == "rollout" or not a.no_extra:
-        chunk = max(1, min(a.chunk, P))
         f = dict(dtype=torch.float32, device=dev)
         seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
                    indiv=torch.empty((chunk, B, N), **f),
@@ -228,11 +238,13 @@ def main():
                                    "episode 100 with device auto-reset" % (N, B),
                        "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
-                       "kernel": "fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"])},
+                       "steps_per_launch": 1 if a.mode == "step" else chunk,
+                       "kernel": ("fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"]))
+                       if a.mode == "step" else "fg::rollout_kernel<%d> (producer/writer pipelined)" % N},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": (measured_traffic(N, B) or (None, None))[0] if a.mode == "step" else None,
-                         "traffic_source": (measured_traffic(N, B) or (None, None))[1],
+                         "traffic": measured_traffic(N, B, a.mode, 1 if a.mode == "step" else chunk)[0],
+                         "traffic_source": measured_traffic(N, B, a.mode, 1 if a.mode == "step" else chunk)[1],
                          "algorithmic_bytes_per_launch": bytes_per_env_step * B * (1 if a.mode == "step" else chunk),
                          "avg_launch_us": round(dev_ms * 1e3 / a.steps * (1 if a.mode == "step" else chunk), 3),
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},

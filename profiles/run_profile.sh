@@ -6,7 +6,7 @@ TAG="${1:-r01}"
 OUT="$PWD/gpurun_out/prof_$TAG"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $PWD/bench.py --steps 300 --warmup 50 --no-cpu-baseline --no-extra"
+BENCH="python3 $PWD/bench.py --steps 300 --warmup 60 --no-cpu-baseline --no-extra"
 cd /tmp
 # 1. per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1

@@ -29,7 +29,7 @@ def main(src, dst):
     out["kernel_stats"] = kernels
     trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
     if trace:
-        rows = [r for r in csv.DictReader(open(trace[0])) if "fg::step_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(trace[0])) if "fg::" in r["Kernel_Name"]]
         if rows:
             r = rows[-1]
             out["dispatch"] = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count",
@@ -43,7 +43,7 @@ def main(src, dst):
         if not f:
             continue
         vals = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
-                      if "fg::step_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name)
+                      if "fg::" in r["Kernel_Name"] and r["Counter_Name"] == name)
         if vals:
             out[name + "_KiB_per_launch_median"] = vals[len(vals) // 2]
     if "FETCH_SIZE_KiB_per_launch_median" in out and "WRITE_SIZE_KiB_per_launch_median" in out:
