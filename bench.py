@@ -106,6 +106,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true", help="tuning aid: episodes never reset")
+    ap.add_argument("--obs-every", type=int, default=1,
+                    help="tuning aid (rollout mode): write an observation only every n-th step; the JSON line is "
+                         "then NOT a valid benchmark result")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
@@ -177,7 +180,7 @@ def main():
             if lo + k > P:
                 k = P - lo
             env.scenario.rollout_batch(env.world, act_pool[lo:lo + k], {k2: v[:k] for k2, v in seq.items()},
-                                       auto_reset=not a.no_auto_reset, rng_offset=t)
+                                       obs_every=a.obs_every, auto_reset=not a.no_auto_reset, rng_offset=t)
             t += k
 
     def timed(fn, steps, warmup):
@@ -250,6 +253,8 @@ def main():
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
             "state_finite": finite,
         }
+        if a.obs_every != 1:
+            res["INVALID"] = "observations written only every %d-th step (tuning run)" % a.obs_every
         if extra:
             res["other_mode"] = extra
         if world_size == 1 and not a.no_cpu_baseline:

@@ -473,7 +473,10 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
 #pragma unroll
             for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
                 const unsigned q = q0 + lane;
-                if (q < npair) dst4[q] = src4[q];
+                if (q < npair) {
+                    if (FG_TILE_NT) __builtin_nontemporal_store(src4[q], &dst4[q]);
+                    else dst4[q] = src4[q];
+                }
             }
             if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
         }
@@ -489,6 +492,9 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
 //   IDX also emit the landmark-index assignments
 // LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
+#ifndef FG_TILE_NT
+#define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer
+#endif
 #ifndef FG_WPS
 #define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
 #endif
@@ -868,7 +874,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     __syncthreads();
     for (int k = 0; k < a.K; ++k) {
         if (producer) {
-            if (k + 1 < a.K) produce(k + 1);
+            if (k + 1 < a.K && !a.nt_store) produce(k + 1);      // nt_store doubles as a tuning switch: writers only
         } else {
             int slot = k;
             bool want_obs = a.obs != nullptr;
@@ -1330,6 +1336,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised small N: producer / writer pipelined kernel
+    if (const char* e = getenv("FG_NT")) a.nt_store = atoi(e);
     const char* nopipe = getenv("FG_NOPIPE");
     if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
@@ -1345,10 +1352,13 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
             hipLaunchKernelGGL((rollout_kernel<NCV, GV, TPV, TWV, EV, WRV>), dim3(grid), dim3((TPV) + (TWV)), lds, st, a); \
             err = hipGetLastError(); }
         if (N == 27) {
-            int re = 8;
+            int re = 16;                   // 16 envs per workgroup: 8 producer + 4 writer waves, one workgroup per CU
             if (const char* e = getenv("FG_ROLLE")) re = atoi(e);
             if (re == 2) { if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 10) else FG_ROLL(27, 32, 64, 128, 2, 10) }
                            else { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 0) else FG_ROLL(27, 32, 64, 128, 2, 0) } }
+            else if (re == 16) { if (wr == 10) { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 10) else FG_ROLL(27, 32, 512, 512, 16, 10) }
+                                 else { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 0) else FG_ROLL(27, 32, 512, 512, 16, 0) } }
+            else if (re == 8 && tw == 512) { if (wr == 10) FG_ROLL(27, 32, 256, 512, 8, 10) else FG_ROLL(27, 32, 256, 512, 8, 0) }
             else if (re == 8) { if (wr == 10) { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 10) else FG_ROLL(27, 32, 256, 256, 8, 10) }
                                 else { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 0) else FG_ROLL(27, 32, 256, 256, 8, 0) } }
             else
