@@ -26,6 +26,10 @@
 
 #include "formation_hip.h"
 
+#ifndef FG_TILE_NT
+#define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer (measured: -6 %, profiles/README.md)
+#endif
+
 namespace fg {
 
 #define FG_DEV __device__ __forceinline__
@@ -492,9 +496,6 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
 //   IDX also emit the landmark-index assignments
 // LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-#ifndef FG_TILE_NT
-#define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer
-#endif
 #ifndef FG_WPS
 #define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
 #endif
