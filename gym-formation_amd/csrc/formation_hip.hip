@@ -453,7 +453,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             float2* __restrict__ img = tile0 + par;
             // ---- compose RT rows ----
 #pragma unroll
-            for (int rb = 0; rb < RT; rb += RW) {
+            for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
                 const int rl = rb + rsub;
                 if (act && rl < RT) {
                     const int r = r0 + rl;
@@ -463,7 +463,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
                 }
             }
 #pragma unroll
-            for (int rb = 0; rb < RT; rb += RS) {
+            for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RS) {
                 const int rl = rb + ssub;
                 if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
             }
@@ -478,7 +478,8 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
                 const unsigned q = q0 + lane;
                 if (q < npair) {
-                    if (FG_TILE_NT) __builtin_nontemporal_store(src4[q], &dst4[q]);
+                    if (FG_TILE_NT == 1) __builtin_nontemporal_store(src4[q], &dst4[q]);
+                    else if (FG_TILE_NT == 2) { const f32x4 cst = {1.f, 2.f, 3.f, 4.f}; dst4[q] = cst; }   // timing probe
                     else dst4[q] = src4[q];
                 }
             }
@@ -892,7 +893,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                                                         reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
             }
         }
-        __syncthreads();
+        if (a.nt_store != 2) __syncthreads();          // nt_store == 2: timing experiment only (no hand-over sync)
     }
     if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
     if (a.step && env_ok && i == 0) a.step[b] = t_step;
