@@ -426,6 +426,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
 // ---------------------------------------------------------------------------
 template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 + 1) & ~1; }
 
+// `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
 template <int NC, int NW, int E, int RT>
 FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
                             float2* __restrict__ out_env0, size_t unit0, int El) {
@@ -434,57 +435,83 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
     static_assert(N <= 32 && N % RT == 0, "tiled writer: N <= 32, RT divides N");
     constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
+    constexpr int TILES_ENV = N / RT;                                  // tiles per env
+    constexpr int MY_TILES = (TILES_ENV + WPE - 1) / WPE;              // of which this wave takes every WPE-th
     const int lane = threadIdx.x & 63;
-    float2* __restrict__ tile0 = tiles + w * tile_units<NC, RT>();
+    float2* tile0 = tiles + w * 2 * tile_units<NC, RT>();
     constexpr int RW = 64 / N;
     const int rsub = lane / N, u = lane - rsub * N;
     const bool act = rsub < RW;
     const int xoff = (u == 0) ? 4 * N : 0;
     constexpr int RS = 64 / (2 * N);
     const int ssub = lane / (2 * N), sidx = lane - ssub * 2 * N;
-    for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? NW : E)) {
-        const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
-        const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
-        const float2 Pu = lds_if(act && u >= 1, AA, u);
-        const float2 sv = lds_if(ssub < RS, AA, N + sidx);
-        for (int r0 = ((E >= NW) ? 0 : w % WPE) * RT; r0 < N; r0 += RT * WPE) {
-            const size_t U = unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
-            const unsigned par = (unsigned)(U & 1);
-            float2* __restrict__ img = tile0 + par;
-            // ---- compose RT rows ----
-#pragma unroll
-            for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
-                const int rl = rb + rsub;
-                if (act && rl < RT) {
-                    const int r = r0 + rl;
-                    const float2 x = AA[xoff + r];
-                    const float2 c = (u - 1 >= r) ? Pu : Pm;
-                    img[(unsigned)rl * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
-                }
-            }
-#pragma unroll
-            for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RS) {
-                const int rl = rb + ssub;
-                if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
-            }
-            // ---- stream the tile ----
-            float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
-            if (par && lane == 0) out[0] = img[0];
-            constexpr unsigned NPMAX = TU >> 1;
-            const unsigned npair = (TU - par) >> 1;
-            const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(img + par);
-            f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
-#pragma unroll
-            for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
-                const unsigned q = q0 + lane;
-                if (q < npair) {
-                    if (FG_TILE_NT == 1) __builtin_nontemporal_store(src4[q], &dst4[q]);
-                    else if (FG_TILE_NT == 2) { const f32x4 cst = {1.f, 2.f, 3.f, 4.f}; dst4[q] = cst; }   // timing probe
-                    else dst4[q] = src4[q];
-                }
-            }
-            if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
+    const int e_first = (E >= NW) ? w : w / WPE, e_step = (E >= NW) ? NW : E;
+    const int t_first = (E >= NW) ? 0 : w % WPE;
+    const int n_env = (El > e_first) ? (El - e_first + e_step - 1) / e_step : 0;
+    const int total = n_env * MY_TILES;
+
+    int cur_env = -1;
+    const float2* __restrict__ AA = tables0;
+    float2 Pm = make_float2(0.f, 0.f), Pu = Pm, sv = Pm;
+    auto locate = [&](int t, int& ee, int& r0) {                       // t-th tile of this wave
+        const int ie = t / MY_TILES, it = t - ie * MY_TILES;
+        ee = e_first + ie * e_step;
+        r0 = (t_first + it * WPE) * RT;
+    };
+    auto compose = [&](int t) {
+        int ee, r0; locate(t, ee, r0);
+        if (r0 >= N) return;
+        if (ee != cur_env) {                                           // per-env register cache
+            cur_env = ee;
+            AA = tables0 + (size_t)ee * env_stride;
+            Pm = lds_if(act && u >= 1, AA, u - 1);
+            Pu = lds_if(act && u >= 1, AA, u);
+            sv = lds_if(ssub < RS, AA, N + sidx);
         }
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;     // no restrict: the two tiles alternate
+#pragma unroll
+        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
+            const int rl = rb + rsub;
+            if (act && rl < RT) {
+                const int r = r0 + rl;
+                const float2 x = AA[xoff + r];
+                const float2 c = (u - 1 >= r) ? Pu : Pm;
+                img[(unsigned)rl * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RS) {
+            const int rl = rb + ssub;
+            if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
+        }
+    };
+    auto stream = [&](int t) {
+        int ee, r0; locate(t, ee, r0);
+        if (r0 >= N) return;
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
+        float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
+        if (par && lane == 0) out[0] = img[0];
+        constexpr unsigned NPMAX = TU >> 1;
+        const unsigned npair = (TU - par) >> 1;
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + par);
+        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
+#pragma unroll
+        for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
+            const unsigned q = q0 + lane;
+            if (q < npair) {
+                if (FG_TILE_NT == 1) __builtin_nontemporal_store(src4[q], &dst4[q]);
+                else if (FG_TILE_NT == 2) { const f32x4 cst = {1.f, 2.f, 3.f, 4.f}; dst4[q] = cst; }   // timing probe
+                else dst4[q] = src4[q];
+            }
+        }
+        if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
+    };
+    if (total > 0) compose(0);
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) compose(t + 1);
+        stream(t);
     }
 }
 
@@ -1183,10 +1210,10 @@ static const Variant* variant_for(int N, int B = 0, bool need_opts = false) {
         for (const Variant& v : kVariants) if (v.NC == N && v.opts) return &v;
         B = 0;
     }
-    // Size-aware default (MI355X sweep, profiles/): a batch that fills the chip several times
-    // over streams best with no idle waves and 1 KiB tile stores; a single-generation batch
-    // (27 x 4096 = 4 workgroups per CU) is latency-bound and prefers spare writer waves.
-    if (N == 27 && B >= 12288) { want_t = 128; want_e = 4; want_flat = 10; }
+    // Size-aware default (MI355X sweep, profiles/): a batch that fills the chip many times over
+    // streams best with 8 envs per workgroup; a single-generation batch (27 x 4096 = 4 workgroups
+    // per CU) is latency-bound and prefers one env per wave with spare writer waves.
+    if (N == 27 && B >= 32768) { want_t = 256; want_e = 8; }
     if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
     if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
@@ -1208,7 +1235,7 @@ static bool geometry_for(int N, Geometry* g, int B = 0, bool need_opts = false) 
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
     g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
-    if (v->wr >= 2) g->lds += (v->T / 64) * ((3 * N * (v->wr - 1) + 3) & ~1) * (int)sizeof(float2);
+    if (v->wr >= 2) g->lds += 2 * (v->T / 64) * ((3 * N * (v->wr - 1) + 3) & ~1) * (int)sizeof(float2);
     return true;
 }
 
@@ -1350,7 +1377,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
 #define FG_ROLL(NCV, GV, TPV, TWV, EV, WRV)                                                              \
         {   const int grid = (B + (EV) - 1) / (EV);                                                      \
             int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                                \
-            if ((WRV) > 0) lds += ((TWV) / 64) * ((3 * (NCV) * ((WRV) - 1) + 3) & ~1) * (int)sizeof(float2); \
+            if ((WRV) > 0) lds += 2 * ((TWV) / 64) * ((3 * (NCV) * ((WRV) - 1) + 3) & ~1) * (int)sizeof(float2); \
             hipLaunchKernelGGL((rollout_kernel<NCV, GV, TPV, TWV, EV, WRV>), dim3(grid), dim3((TPV) + (TWV)), lds, st, a); \
             err = hipGetLastError(); }
         if (N == 27) {
