@@ -26,6 +26,9 @@
 
 #include "formation_hip.h"
 
+#ifndef FG_WRITER_PRIO
+#define FG_WRITER_PRIO 0   // tuning: s_setprio level of the rollout writer waves
+#endif
 #ifndef FG_TILE_NT
 #define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer (measured: -6 %, profiles/README.md)
 #endif
@@ -900,6 +903,9 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     };
 
     if (producer) produce(0);
+#if FG_WRITER_PRIO
+    else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
+#endif
     __syncthreads();
     for (int k = 0; k < a.K; ++k) {
         if (producer) {

@@ -506,3 +506,33 @@ def test_motor_noise_is_gaussian_with_the_requested_scale():
     env.step(act)
     dv2 = (env.world.get_state()[1] - ref.world.get_state()[1])
     assert float((dv2 / 0.1 - 0.75 * dv).std()) > 0.3                           # fresh noise every step
+
+
+@pytest.mark.parametrize("N,B,K", [(27, 40, 6), (9, 70, 5), (3, 33, 4), (81, 3, 4)])
+def test_rollout_with_auto_reset_equals_single_steps(N, B, K):
+    """Episode ends inside a K-step launch: the pipelined rollout kernel must reset on device
+    exactly like K single-step launches with the same RNG offsets (bit for bit)."""
+    rs = np.random.RandomState(7 + N)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (K, B, N, 2)).astype(np.float32)).cuda()
+    step0 = np.where(np.arange(B) % 3 == 0, 98, np.where(np.arange(B) % 3 == 1, 99, 5))   # mixed phases
+    a = _make(N, B); _load(a, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], step0)
+    b = _make(N, B); _load(b, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], step0)
+    a.scenario.seed(11); b.scenario.seed(11)
+    out = dict(obs=torch.empty((K, B, N, 6 * N), device="cuda"), reward=torch.empty((K, B, N), device="cuda"),
+               indiv=torch.empty((K, B, N), device="cuda"),
+               done=torch.zeros((K, B, N), dtype=torch.uint8, device="cuda"))
+    b.scenario.rollout_batch(b.world, acts, out, auto_reset=True, rng_offset=1000)
+    n_done = 0
+    for k in range(K):
+        a.scenario.step_batch(a.world, acts[k], a._out, auto_reset=True, rng_offset=1000 + k)
+        assert torch.equal(a._out["obs"], out["obs"][k])
+        assert torch.equal(a._out["reward"], out["reward"][k])
+        assert torch.equal(a._out["done"], out["done"][k])
+        n_done += int(a._out["done"][:, 0].sum())
+    assert n_done >= B // 2                                   # episodes really ended inside the launch
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    assert torch.equal(a.world.step_count, b.world.step_count)
+    assert torch.equal(a.scenario.ideal_shape, b.scenario.ideal_shape)
+    assert torch.equal(a.scenario.ideal_vel, b.scenario.ideal_vel)
