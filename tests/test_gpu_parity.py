@@ -536,3 +536,65 @@ def test_rollout_with_auto_reset_equals_single_steps(N, B, K):
     assert torch.equal(a.world.step_count, b.world.step_count)
     assert torch.equal(a.scenario.ideal_shape, b.scenario.ideal_shape)
     assert torch.equal(a.scenario.ideal_vel, b.scenario.ideal_vel)
+
+
+@pytest.mark.parametrize("N,B", [(5, 33), (8, 17), (17, 9), (32, 5), (33, 6), (64, 3), (65, 4), (128, 2), (200, 2), (300, 1)])
+def test_generic_agent_counts_against_oracle(N, B):
+    """Run-time-N kernels (every lane-group width and workgroup size), crowded so that contacts
+    and collision counts occur, with the landmark-index outputs switched on."""
+    rs = np.random.RandomState(1000 + N)
+    st = O.reset_hd(rs.randint(0, 100000, B), N)
+    st["pos"] *= 0.35
+    st["vel"] = rs.uniform(-0.3, 0.3, (B, N, 2))
+    act = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    st = {k: (f32(v) if v.dtype != np.int32 else v) for k, v in st.items()}
+    env = _make(N, B)
+    env.enable_assignments(True)
+    _load(env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    obs, rew, done, info = env.step(torch.as_tensor(act).cuda())
+    new, out = O.step_hd(st, act.astype(np.float64))
+    pos, vel = (_np(x) for x in env.world.get_state())
+    np.testing.assert_allclose(pos, new["pos"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(vel, new["vel"], rtol=0, atol=10 * ATOL)
+    r = O.reward_hd(pos, vel, st["ideal_shape"], st["ideal_vel"], O.HdParams())       # on the GPU's own state
+    ok = r["cnt_margin"] > 1e-6
+    np.testing.assert_allclose(_np(info["individual_reward"])[ok], r["indiv"][ok], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(_np(obs), O.observation_hd(pos, vel, st["ideal_shape"], st["ideal_vel"]), rtol=0, atol=2e-7)
+    _check_indices(env._out["near_lm"].cpu().numpy(), r["near_lm"], r["gap_lm"], "near_lm")
+    _check_indices(env._out["near_ag"].cpu().numpy(), r["near_ag"], r["gap_ag"], "near_ag")
+    tie = r["hd_gap"].min(1) < 1e-6
+    np.testing.assert_array_equal(env._out["hd_idx"].cpu().numpy()[~tie], r["hd_idx"][~tie])
+    assert not done.any() and (env.world.step_count == 1).all()
+
+
+def test_entry_points_are_graph_capturable():
+    """The C ABI enqueues on the caller's stream and never synchronises or allocates, so a
+    sequence of env steps can be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
+    N, B, K = 9, 128, 4
+    rs = np.random.RandomState(3)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (K, B, N, 2)).astype(np.float32)).cuda()
+    eager = _make(N, B); _load(eager, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    graph_env = _make(N, B); _load(graph_env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    for k in range(K):
+        eager.step(acts[k])
+    want_obs = eager._out["obs"].clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for k in range(K):
+                graph_env.scenario.step_batch(graph_env.world, acts[k], graph_env._out)
+    torch.cuda.current_stream().wait_stream(side)
+    # capture does not execute: state is still the initial one
+    assert torch.equal(graph_env.world.step_count, torch.zeros_like(graph_env.world.step_count))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(graph_env._out["obs"], want_obs)
+    for x, y in zip(eager.world.get_state(), graph_env.world.get_state()):
+        assert torch.equal(x, y)
+    assert (graph_env.world.step_count == K).all()
