@@ -967,6 +967,93 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
 }
 
 // ---------------------------------------------------------------------------
+// Bit-exact reset on device: Scenario.reset_world (formation_hd_env.py:77-95) drawing from the
+// env's own legacy NumPy MT19937 stream (environment.py:106-110 seeds it), so that multi-episode
+// rollouts keep matching the reference without a host round trip.  One workgroup per env; the
+// 624-word state lives in LDS, is tempered / twisted in parallel and written back.
+//   draw order: N agent positions, N landmark positions, ideal velocity, two doubles each;
+//   double = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two 32-bit outputs; U(-1,1) = -1 + 2 d.
+// mt_state: uint32 [B][626] = key[624], pos, unused.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8_t* __restrict__ mask,
+                                                       uint32_t* __restrict__ mt_state,
+                                                       float* px, float* py, float* vx, float* vy,
+                                                       float* shape, float* ivel, float* lm_pos, int32_t* step) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B || (mask && !mask[b])) return;
+    uint32_t* const mt = lds_u32;                      // [624]
+    uint32_t* const outs = lds_u32 + 624;              // [8N + 4] tempered outputs
+    double* const dsum = reinterpret_cast<double*>(lds_u32 + 624 + ((8 * N + 4 + 1) & ~1));   // [2] mean of raw
+    uint32_t* const gstate = mt_state + (size_t)b * 626;
+    for (int q = tid; q < 624; q += 256) mt[q] = gstate[q];
+    int pos = (int)gstate[624];
+    __syncthreads();
+    const int M = 8 * N + 4;
+    int produced = 0;
+    auto mix = [](uint32_t a, uint32_t b2) -> uint32_t {
+        const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    while (produced < M) {
+        if (pos >= 624) {                              // regenerate the 624 words (three dependent thirds)
+            uint32_t nv = 0;
+            if (tid < 227) nv = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < 227) mt[tid] = nv;
+            __syncthreads();
+            if (tid < 227) nv = mt[tid] ^ mix(mt[tid + 227], mt[tid + 228]);            // kk = tid + 227
+            __syncthreads();
+            if (tid < 227) mt[tid + 227] = nv;
+            __syncthreads();
+            if (tid < 169) nv = mt[tid + 227] ^ mix(mt[tid + 454], mt[tid + 455]);      // kk = tid + 454 .. 622
+            const uint32_t old623 = mt[623];
+            __syncthreads();
+            if (tid < 169) mt[tid + 454] = nv;
+            __syncthreads();
+            if (tid == 0) mt[623] = mt[396] ^ mix(old623, mt[0]);
+            __syncthreads();
+            pos = 0;
+        }
+        const int take = min(624 - pos, M - produced);
+        for (int q = tid; q < take; q += 256) {
+            uint32_t y = mt[pos + q];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            outs[produced + q] = y;
+        }
+        produced += take; pos += take;
+        __syncthreads();
+    }
+    auto draw = [&](int m) -> double {                 // m-th double of this reset
+        const double a = (double)(outs[2 * m] >> 5), c = (double)(outs[2 * m + 1] >> 6);
+        return -1.0 + 2.0 * ((a * 67108864.0 + c) / 9007199254740992.0);
+    };
+    if (tid == 0) {                                    // np.mean over axis 0: rows added in order
+        double sx = 0.0, sy = 0.0;
+        for (int i = 0; i < N; ++i) { sx += draw(2 * N + 2 * i); sy += draw(2 * N + 2 * i + 1); }
+        dsum[0] = sx / (double)N; dsum[1] = sy / (double)N;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const size_t o = (size_t)b * N + i;
+        px[o] = (float)draw(2 * i); py[o] = (float)draw(2 * i + 1);
+        vx[o] = 0.f; vy[o] = 0.f;
+        const double rx = draw(2 * N + 2 * i), ry = draw(2 * N + 2 * i + 1);
+        shape[2 * o] = (float)(rx - dsum[0]); shape[2 * o + 1] = (float)(ry - dsum[1]);
+        if (lm_pos) { lm_pos[2 * o] = (float)rx; lm_pos[2 * o + 1] = (float)ry; }
+    }
+    if (tid == 0) {
+        ivel[2 * b] = (float)draw(4 * N); ivel[2 * b + 1] = (float)draw(4 * N + 1);
+        if (step) step[b] = 0;
+        gstate[624] = (uint32_t)pos;
+    }
+    for (int q = tid; q < 624; q += 256) gstate[q] = mt[q];
+}
+
+// ---------------------------------------------------------------------------
 // Landmark scenarios with few agents (N + M <= 64): basic_formation_env (BASELINE config 1),
 // formation_hd_partial_env, formation_hd_partial_range_env, formation_hd_obs_env.
 // One lane per movable entity (N agents, then M obstacles), one env per aligned group of G
@@ -1475,6 +1562,21 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     else hipLaunchKernelGGL((scn_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
+                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                   float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
+    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    if (!mt_state || !pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
+        return fail(FG_ERR_BAD_ARG, "fg_reset_hd_mt: a required pointer is NULL%s");
+    const int lds = (624 + ((8 * N + 4 + 1) & ~1)) * (int)sizeof(uint32_t) + 2 * (int)sizeof(double);
+    hipLaunchKernelGGL(mt_reset_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, B, N, mask, mt_state,
+                       pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "mt reset launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
 

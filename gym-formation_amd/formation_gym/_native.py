@@ -93,6 +93,7 @@ SIGNATURES = {
     "fg_observe_hd": (_I, [_PP, _I, _I] + [_P] * 15),
     "fg_rollout_hd": (_I, [_PP, _I, _I, _I] + [_P] * 12 + [_I, _P]),
     "fg_reset_hd": (_I, [_PP, _I, _I] + [_P] * 9),
+    "fg_reset_hd_mt": (_I, [_I, _I] + [_P] * 11),
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
 }

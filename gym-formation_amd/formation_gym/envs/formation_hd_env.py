@@ -53,6 +53,7 @@ class Scenario(BaseScenario):
         reference's single env."""
         self._seed = 1 if seed is None else int(seed)
         self._rngs = None
+        self._mt_state = None
 
     def _streams(self, B):
         if self._rngs is None or len(self._rngs) != B:
@@ -165,6 +166,32 @@ class Scenario(BaseScenario):
             world.step_count.data_ptr(),
             _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
             _native.ptr(out.get("done")), int(obs_every), _native.current_stream()))
+        self._cache = None
+
+    def upload_mt_streams(self, world):
+        """Copy every env's legacy MT19937 state (RandomState(seed + 1000 b), at its CURRENT
+        position) to the device; from here on `reset_mt` continues those streams on the GPU."""
+        B = world.num_envs
+        st = np.zeros((B, 626), dtype=np.uint32)
+        for b, rs in enumerate(self._streams(B)):
+            _, key, pos = rs.get_state()[:3]
+            st[b, :624] = key
+            st[b, 624] = pos
+        self._mt_state = torch.as_tensor(st.view(np.int32)).to(world.device)
+        return self._mt_state
+
+    def reset_mt(self, world, mask=None):
+        """Scenario.reset_world on the GPU from the reference's own RNG streams (bit-exact with
+        the host path `reset_world`): masked envs draw N agent positions, N landmark positions
+        and the ideal velocity from their MT19937 state, which advances in place."""
+        if getattr(self, "_mt_state", None) is None or self._mt_state.shape[0] != world.num_envs:
+            self.upload_mt_streams(world)
+        lib = _native.load()
+        _native.check(lib.fg_reset_hd_mt(
+            world.num_envs, len(world.agents), _native.ptr(mask), self._mt_state.data_ptr(),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.landmark_pos.data_ptr(),
+            world.step_count.data_ptr(), _native.current_stream()))
         self._cache = None
 
     def reset_device(self, world, mask=None, rng_offset=0):

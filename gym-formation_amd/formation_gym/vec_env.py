@@ -12,8 +12,13 @@ import torch
 
 class FormationVecEnv(object):
     def __init__(self, env, reset_mode="device"):
-        if reset_mode not in ("device", "host"):
-            raise ValueError("reset_mode must be 'device' or 'host'")
+        """reset_mode:
+          'device'    counter RNG inside the fused step launch (fastest; distributional parity)
+          'device_mt' the reference's own MT19937 streams continued on the GPU (bit-exact resets,
+                      no host round trip: the host mirrors the step counters, which are deterministic)
+          'host'      the reference's streams on the host (bit-exact; needs a device->host sync)"""
+        if reset_mode not in ("device", "device_mt", "host"):
+            raise ValueError("reset_mode must be 'device', 'device_mt' or 'host'")
         self.env = env
         self.reset_mode = reset_mode
         self.num_envs = env.num_envs
@@ -23,16 +28,41 @@ class FormationVecEnv(object):
         self.agent_types = ['agent' for _ in env.agents]        # env_wrappers.py:33-34
         env.auto_reset = reset_mode == "device"
         self.ts = torch.zeros(self.num_envs, dtype=torch.int64)
+        self._host_steps = None
 
     def get_spaces(self):
         return self.observation_space, self.action_space
 
     def reset(self):
+        if self.reset_mode == "device_mt":
+            import numpy as np
+            sc, world = self.env.scenario, self.env.world
+            sc.upload_mt_streams(world)
+            sc.reset_mt(world)                                    # all envs, on device
+            self.env.current_step = 0
+            sc.observe_batch(world, {"obs": self.env._out["obs"]})
+            self._host_steps = np.zeros(self.num_envs, dtype=np.int64)
+            return self.env._out["obs"]
         return self.env.reset(batched=True)
 
     def step(self, actions):
         """actions [B, N, 2] -> obs [B,N,D], rews [B,N,1], dones [B,N] (bool), infos dict."""
         obs, rew, done, info = self.env.step(actions)
+        if self.reset_mode == "device_mt":
+            if self._host_steps is None:
+                self._host_steps = self.env.world.step_count.cpu().numpy().astype("int64") - 1
+            self._host_steps += 1
+            finished = self._host_steps >= self.env.world_length
+            if finished.any():
+                sc, world = self.env.scenario, self.env.world
+                mask = torch.as_tensor(finished.astype("uint8")).to(world.device, non_blocking=True)
+                rew, done = rew.clone(), done.clone()
+                info = {k: v.clone() for k, v in info.items()}
+                sc.reset_mt(world, mask)
+                sc.observe_batch(world, {"obs": self.env._out["obs"]})
+                self._host_steps[finished] = 0
+                self._keep = mask
+            return self.env._out["obs"], rew, done, info
         if self.reset_mode == "host":
             mask = done.all(dim=1)
             if bool(mask.any()):

@@ -184,6 +184,14 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
                 float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                 float* ideal_shape, float* ideal_vel, int32_t* step, void* stream);
 
+/* The same reset drawn from each env's own legacy NumPy MT19937 stream (environment.py:106-110
+ * np.random.seed; formation_hd_env.py:77-95 draw order), bit-exact with the reference's host RNG:
+ *   mt_state uint32 [B][626] = RandomState.get_state() key[624], pos, pad; advanced in place.
+ *   landmark_pos float [B][N][2] (may be NULL) receives the un-centred landmark positions. */
+int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
+                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                   float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream);
+
 /* MultiAgentEnv.step for basic_formation_env (BASELINE config 1):
  * same physics; observation basic_formation_env.py:29-41, reward :43-52.
  *   landmarks float [B][L][2]; obs float [B][N][4 + 2L + 4(N-1)]. */

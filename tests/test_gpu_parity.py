@@ -598,3 +598,66 @@ def test_entry_points_are_graph_capturable():
     for x, y in zip(eager.world.get_state(), graph_env.world.get_state()):
         assert torch.equal(x, y)
     assert (graph_env.world.step_count == K).all()
+
+
+@pytest.mark.parametrize("N,B", [(3, 5), (9, 4), (27, 6), (81, 3), (243, 2), (100, 3)])
+def test_device_mt19937_reset_is_bit_exact(N, B):
+    """fg_reset_hd_mt continues each env's legacy NumPy stream on the GPU: three consecutive
+    resets (N=243 needs several state regenerations per reset) equal the host path exactly."""
+    import formation_gym
+    dev_env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    host_env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    dev_env.seed(77); host_env.seed(77)
+    dev_env.scenario.upload_mt_streams(dev_env.world)
+    for rep in range(3):
+        mask = None
+        if rep == 1:                                   # masked reset: only some envs draw
+            m = np.zeros(B, dtype=bool); m[::2] = True
+            mask = torch.as_tensor(m.astype(np.uint8)).cuda()
+            host_env.scenario.reset_world(host_env.world, env_mask=m)
+        else:
+            host_env.scenario.reset_world(host_env.world)
+        dev_env.scenario.reset_mt(dev_env.world, mask)
+        for x, y in zip(dev_env.world.get_state(), host_env.world.get_state()):
+            assert torch.equal(x, y)
+        assert torch.equal(dev_env.scenario.ideal_shape, host_env.scenario.ideal_shape)
+        assert torch.equal(dev_env.scenario.ideal_vel, host_env.scenario.ideal_vel)
+        assert torch.equal(dev_env.world.landmark_pos, host_env.world.landmark_pos)
+    # and the very first reset reproduces the reference fixture stream
+    g = load_golden_reset()
+    if N in (9,):
+        e = formation_gym.make_env("formation_hd_env", False, 9, num_envs=2, device="cuda:0")
+        e.seed(7)
+        from formation_gym.vec_env import FormationVecEnv
+        obs = FormationVecEnv(e, reset_mode="device_mt").reset()
+        np.testing.assert_allclose(_np(obs[0]), g["s7_n9_obs"], rtol=0, atol=1e-6)
+
+
+def load_golden_reset():
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reset.npz")) as d:
+        return {k: d[k] for k in d.files}
+
+
+def test_vec_env_device_mt_matches_host_reset_mode():
+    """Multi-episode rollout: 'device_mt' (no host round trip) == 'host' reset mode, bit for bit."""
+    from formation_gym.vec_env import FormationVecEnv
+    N, B, T = 9, 6, 7
+    envs = []
+    for mode in ("device_mt", "host"):
+        e = _make(N, B)
+        e.seed(21)
+        v = FormationVecEnv(e, reset_mode=mode)
+        v.reset()
+        e.world.step_count.copy_(torch.tensor([97, 98, 99, 3, 98, 97], dtype=torch.int32))
+        if mode == "device_mt":
+            v._host_steps = np.array([97, 98, 99, 3, 98, 97], dtype=np.int64)
+        envs.append((e, v))
+    rs = np.random.RandomState(5)
+    for t in range(T):
+        act = torch.as_tensor(rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)).cuda()
+        outs = [v.step(act) for (_, v) in envs]
+        assert torch.equal(outs[0][0], outs[1][0])            # obs (reset obs where done)
+        assert torch.equal(outs[0][1], outs[1][1])            # pre-reset reward
+        assert torch.equal(outs[0][2], outs[1][2])            # pre-reset done
+        assert torch.equal(envs[0][0].world.step_count, envs[1][0].world.step_count)
