@@ -26,6 +26,9 @@
 
 #include "formation_hip.h"
 
+#ifndef FG_PROBES
+#define FG_PROBES 0        // 1: honour the FG_PROBE timing experiments (results are then NOT valid)
+#endif
 #ifndef FG_WRITER_PRIO
 #define FG_WRITER_PRIO 0   // tuning: s_setprio level of the rollout writer waves
 #endif
@@ -58,7 +61,8 @@ constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances 
 struct Args {
     FgParams p;
     int B, N, K, obs_every;
-    int do_phys, do_post, nt_store;
+    int do_phys, do_post;
+    int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)
     float* px; float* py; float* vx; float* vy;
     const float* act;          // [K][B][N][2]
     float* shape;              // [B][N][2]
@@ -212,31 +216,6 @@ FG_DEV float2 clamp_speed(const FgParams& P, float2 v) {                    // c
         if (speed > P.max_speed) { v.x = v.x / speed * P.max_speed; v.y = v.y / speed * P.max_speed; }
     }
     return v;
-}
-
-// ---------------------------------------------------------------------------
-// World.step pair force on one agent (core.py:289-322, ratio m_b/m_a = 1)
-// ---------------------------------------------------------------------------
-FG_DEV float2 contact_force_on(const float2* __restrict__ pre, int N, int i, float2 p,
-                               float cf, float kmargin, float dmin, float cutoff2) {
-    float fx = 0.0f, fy = 0.0f;
-#pragma unroll 3
-    for (int j = 0; j < N; ++j) {
-        const float2 q = pre[j];
-        const float dx = p.x - q.x, dy = p.y - q.y;
-        const float d2 = dx * dx + dy * dy;
-        // beyond dmin + 30 k the softplus penetration is < k e^-30 ~ 1e-16: skipped.
-        // d2 == 0 for two distinct agents is kept: 0/0 -> NaN as in core.py:312.
-        if (j != i && d2 < cutoff2) {
-            const float d = sqrtf(d2);
-            const float x = (dmin - d) / kmargin;
-            const float pen = kmargin * (fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))));
-            const float c = cf * pen / d;
-            fx += dx * c;
-            fy += dy * c;
-        }
-    }
-    return make_float2(fx, fy);
 }
 
 // ---------------------------------------------------------------------------
@@ -747,8 +726,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
                     if (u1 == n3) { u1 = 0u; rp1 += 1u; }
                     const float2 x0 = unit(rp, u), x1 = unit(rp1, u1);
                     const f32x4 w = {x0.x, x0.y, x1.x, x1.y};
-                    if (a.nt_store) __builtin_nontemporal_store(w, &out4[q2]);
-                    else out4[q2] = w;
+                    out4[q2] = w;
                     u += du; rp += drow;
                     if (u >= n3) { u -= n3; rp += 1u; }
                 }
@@ -909,7 +887,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     __syncthreads();
     for (int k = 0; k < a.K; ++k) {
         if (producer) {
-            if (k + 1 < a.K && !a.nt_store) produce(k + 1);      // nt_store doubles as a tuning switch: writers only
+            if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1);      // probe 1/2: writers only
         } else {
             int slot = k;
             bool want_obs = a.obs != nullptr;
@@ -926,7 +904,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                                                         reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
             }
         }
-        if (a.nt_store != 2) __syncthreads();          // nt_store == 2: timing experiment only (no hand-over sync)
+        if (!(FG_PROBES && a.probe == 2)) __syncthreads();                    // probe 2: no hand-over sync
     }
     if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
     if (a.step && env_ok && i == 0) a.step[b] = t_step;
@@ -1339,7 +1317,6 @@ static int launch_step(Args a, hipStream_t st) {
     if (!v || !geometry_for(a.N, &g, a.B, opts)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
     const int grid = (a.B + g.E - 1) / g.E;
-    if (const char* s = getenv("FG_NT")) a.nt_store = atoi(s);
     const hipError_t err = (opts ? v->opts : idx ? v->idx : v->plain)(a, grid, g.lds, st);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
     return FG_OK;
@@ -1458,7 +1435,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised small N: producer / writer pipelined kernel
-    if (const char* e = getenv("FG_NT")) a.nt_store = atoi(e);
+    if (FG_PROBES) { if (const char* e = getenv("FG_PROBE")) a.probe = atoi(e); }
     const char* nopipe = getenv("FG_NOPIPE");
     if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
