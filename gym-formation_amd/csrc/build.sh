@@ -6,7 +6,7 @@ ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -fPIC -shared \
     -I"$ROOT/include" ${FG_EXTRA_FLAGS:-} \
     -o "$OUT/libformation_hip.so" "$HERE/formation_hip.hip"
 echo "built $OUT/libformation_hip.so"
