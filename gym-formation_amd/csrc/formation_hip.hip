@@ -62,6 +62,7 @@ struct Args {
     FgParams p;
     int B, N, K, obs_every;
     int do_phys, do_post;
+    int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
     int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)
     float* px; float* py; float* vx; float* vy;
     const float* act;          // [K][B][N][2]
@@ -925,10 +926,12 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
     const int tid = threadIdx.x, lane = tid & 63;
     const bool producer = tid < TP;
     const int e = producer ? tid >> 6 : 0;
-    const int b0 = blockIdx.x * E;
-    const int b = b0 + e;
-    const bool env_ok = producer && (b < a.B);
-    const int El = min(E, a.B - b0);
+    // K > 1: the workgroup owns E envs for K steps.  K == 1 (`groups` > 1): it owns `groups`
+    // consecutive batches of E envs and pipelines over the batches instead of over the steps.
+    const int NG = (a.K > 1) ? 1 : max(1, a.groups);
+    const int wg0 = blockIdx.x * E * NG;
+    int b = wg0 + e;
+    bool env_ok = producer && (b < a.B);
     float* const blk = smemf + e * roll_block_floats(N);
     float2* const TB0 = reinterpret_cast<float2*>(blk);
     float* const QX = blk + 20 * N;
@@ -947,26 +950,48 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
     bool valid[A];
     float2 iv = make_float2(0.f, 0.f);
     int t_step = 0;
+    if (producer) {                                     // row-independent table entries and loop sentinels: once
 #pragma unroll
-    for (int q = 0; q < A; ++q) {
-        const int i = lane + 64 * q;
-        valid[q] = env_ok && i < N;
-        p[q] = v[q] = s[q] = make_float2(0.f, 0.f);
-        if (valid[q]) {
-            const size_t o = (size_t)b * N + i;
-            p[q] = make_float2(a.px[o], a.py[o]);
-            v[q] = make_float2(a.vx[o], a.vy[o]);
-            s[q] = reinterpret_cast<const float2*>(a.shape)[o];
-            QX[i] = p[q].x; QY[i] = p[q].y; SX[i] = s[q].x; SY[i] = s[q].y;
+        for (int q = 0; q < A; ++q) {
+            const int i = lane + 64 * q;
             if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
-        } else if (env_ok && i < NP) {
-            QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+            if (i >= N && i < NP) {
+                QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+            }
         }
     }
-    if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+    auto load_group = [&](int g) {                      // state of env batch g -> registers + partner arrays
+        b = wg0 + g * E + e;
+        env_ok = producer && (b < a.B);
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            const int i = lane + 64 * q;
+            valid[q] = env_ok && i < N;
+            p[q] = v[q] = s[q] = make_float2(0.f, 0.f);
+            if (valid[q]) {
+                const size_t o = (size_t)b * N + i;
+                p[q] = make_float2(a.px[o], a.py[o]);
+                v[q] = make_float2(a.vx[o], a.vy[o]);
+                s[q] = reinterpret_cast<const float2*>(a.shape)[o];
+                QX[i] = p[q].x; QY[i] = p[q].y; SX[i] = s[q].x; SY[i] = s[q].y;
+            }
+        }
+        iv = make_float2(0.f, 0.f); t_step = 0;
+        if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            if (valid[q]) {
+                const size_t o = (size_t)b * N + lane + 64 * q;
+                a.px[o] = p[q].x; a.py[o] = p[q].y; a.vx[o] = v[q].x; a.vy[o] = v[q].y;
+            }
+        }
+        if (a.step && env_ok && lane == 0) a.step[b] = t_step;
+    };
 
-    auto produce = [&](int k) {
-        float2* const T = TB0 + (k & 1) * 5 * N;
+    auto produce = [&](int k, int buf) {
+        float2* const T = TB0 + buf * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // ---- World.step: all A agents of the lane against each partner pair ----
         float fx[A], fy[A];
@@ -1128,32 +1153,33 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         if (env_ok && lane == 0) T[3 * N - 1] = iv;
     };
 
-    if (producer) produce(0);
+    const bool per_step = a.K == 1;
+    const int total = per_step ? NG : a.K;
+    if (producer) { load_group(0); produce(0, 0); if (per_step) store_group(); }
     __syncthreads();
-    for (int k = 0; k < a.K; ++k) {
+    for (int it = 0; it < total; ++it) {
         if (producer) {
-            if (k + 1 < a.K) produce(k + 1);
+            if (it + 1 < total) {
+                if (per_step) { load_group(it + 1); produce(0, (it + 1) & 1); store_group(); }
+                else produce(it + 1, (it + 1) & 1);
+            }
         } else {
+            const int k = per_step ? 0 : it;
+            const int b0 = wg0 + (per_step ? it * E : 0);
+            const int El = min(E, a.B - b0);
             int slot = k;
-            bool want_obs = a.obs != nullptr;
+            bool want_obs = a.obs != nullptr && El > 0;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
-                write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N,
+                write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, (tid - TP) >> 6,
                                            reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
             }
         }
         __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < A; ++q) {
-        if (valid[q]) {
-            const size_t o = (size_t)b * N + lane + 64 * q;
-            a.px[o] = p[q].x; a.py[o] = p[q].y; a.vx[o] = v[q].x; a.vy[o] = v[q].y;
-        }
-    }
-    if (a.step && env_ok && lane == 0) a.step[b] = t_step;
+    if (!per_step && producer) store_group();
 }
 
 // ---------------------------------------------------------------------------
@@ -1568,6 +1594,41 @@ static int launch_step(Args a, hipStream_t st) {
     return FG_OK;
 }
 
+// 64 < N <= 256: producer / writer pipelined kernel (rollout: over steps; single step: over env batches)
+static int launch_wide(Args a, hipStream_t st) {
+    const int N = a.N, B = a.B;
+    hipError_t err = hipSuccess;
+    int tw = 256;
+    if (const char* e = getenv("FG_TW")) tw = atoi(e);
+    if (a.K == 1) {
+        // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
+        // stream, few enough to keep every CU busy (MI355X sweep, profiles/README.md)
+        const int E = (N == 243 && tw == 128) ? 2 : ((N == 81 && tw == 512) ? 8 : 4);
+        const int batches = (B + E - 1) / E;
+        int target = 256;                                  // workgroups in the grid: one per CU
+        if (const char* e = getenv("FG_STEPWG")) target = atoi(e);
+        a.groups = batches / (target > 0 ? target : 1);
+        if (a.groups < 1) a.groups = 1;
+        if (a.groups > 64) a.groups = 64;
+    } else {
+        a.groups = 1;
+    }
+#define FG_ROLLW(NCV, AV, EV, TWV)                                                                        \
+    {   const int grid = (B + (EV) * a.groups - 1) / ((EV) * a.groups);                                  \
+        const int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                              \
+        if (lds > 64 * 1024) {   /* more than the default dynamic-LDS limit: opt in (once per kernel) */  \
+            static bool raised = false;                                                                  \
+            if (!raised) { (void)hipFuncSetAttribute((const void*)&rollout_kernel_wide<NCV, AV, EV, TWV>,          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = true; } }      \
+        hipLaunchKernelGGL((rollout_kernel_wide<NCV, AV, EV, TWV>), dim3(grid), dim3((EV) * 64 + (TWV)), lds, st, a); \
+        err = hipGetLastError(); }
+    if (N == 81) { if (tw == 128) FG_ROLLW(81, 2, 4, 128) else if (tw == 512) FG_ROLLW(81, 2, 8, 512) else FG_ROLLW(81, 2, 4, 256) }
+    else { if (tw == 128) FG_ROLLW(243, 4, 2, 128) else if (tw == 512) FG_ROLLW(243, 4, 4, 512) else FG_ROLLW(243, 4, 4, 256) }
+#undef FG_ROLLW
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
 static int check_params(const FgParams* p) {
     if (!p) return fail(FG_ERR_BAD_ARG, "params is NULL%s");
     if (!(p->mass > 0.f) || !(p->contact_margin > 0.f) || !(p->dt > 0.f))
@@ -1617,6 +1678,12 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
+    {   // 81 / 243 agents: pipeline over env batches inside the launch (no index outputs, no World options)
+        const char* nopipe = getenv("FG_NOPIPE");
+        const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
+        if ((N == 81 || N == 243) && !(nopipe && atoi(nopipe)) && !opts && !near_lm && !near_ag && !hd_idx)
+            return launch_wide(a, (hipStream_t)stream);
+    }
     return launch_step(a, (hipStream_t)stream);
 }
 
@@ -1683,26 +1750,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     // K >= 2 at the specialised small N: producer / writer pipelined kernel
     if (FG_PROBES) { if (const char* e = getenv("FG_PROBE")) a.probe = atoi(e); }
     const char* nopipe = getenv("FG_NOPIPE");
-    if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 81 || N == 243)) {
-        hipStream_t st = (hipStream_t)stream;
-        hipError_t err = hipSuccess;
-        int tw = (N == 81) ? 256 : 256;
-        if (const char* e = getenv("FG_TW")) tw = atoi(e);
-#define FG_ROLLW(NCV, AV, EV, TWV)                                                                        \
-        {   const int grid = (B + (EV) - 1) / (EV);                                                      \
-            const int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                          \
-            if (lds > 64 * 1024) {   /* more than the default dynamic-LDS limit: opt in (once per kernel) */  \
-                static bool raised = false;                                                              \
-                if (!raised) { (void)hipFuncSetAttribute((const void*)&rollout_kernel_wide<NCV, AV, EV, TWV>,      \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = true; } }  \
-            hipLaunchKernelGGL((rollout_kernel_wide<NCV, AV, EV, TWV>), dim3(grid), dim3((EV) * 64 + (TWV)), lds, st, a); \
-            err = hipGetLastError(); }
-        if (N == 81) { if (tw == 128) FG_ROLLW(81, 2, 4, 128) else if (tw == 512) FG_ROLLW(81, 2, 8, 512) else FG_ROLLW(81, 2, 4, 256) }
-        else { if (tw == 128) FG_ROLLW(243, 4, 2, 128) else if (tw == 512) FG_ROLLW(243, 4, 4, 512) else FG_ROLLW(243, 4, 4, 256) }
-#undef FG_ROLLW
-        if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
-        return FG_OK;
-    }
+    if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
     if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
         if (const char* e = getenv("FG_TW")) tw = atoi(e);
