@@ -1,0 +1,325 @@
+// fg_aux_kernels.hpp - Reset kernels (counter RNG, bit-exact MT19937) and the small landmark-scenario kernel.
+// Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+#ifndef FG_AUX_KERNELS_HPP_
+#define FG_AUX_KERNELS_HPP_
+
+#include "fg_common.hpp"
+#include "fg_pair_loops.hpp"
+
+namespace fg {
+
+// ---------------------------------------------------------------------------
+// standalone masked reset (Scenario.reset_world, formation_hd_env.py:77-95)
+// ---------------------------------------------------------------------------
+template <int G, int T>
+__global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* mask) {
+    constexpr int E = T / G;
+    __shared__ float scratch[64];
+    const int N = a.N;
+    const int tid = threadIdx.x;
+    const int e = (G >= T) ? 0 : tid / G;
+    const int i = (G >= T) ? tid : tid % G;
+    const int b = blockIdx.x * E + e;
+    const bool valid = (b < a.B) && (i < N);
+    const bool mine = valid && (mask == nullptr || mask[b] != 0);
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+    philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+    float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+    const float rx = raw[0], ry = raw[1];
+    env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
+    if (mine) {
+        const size_t sidx = (size_t)b * N + i;
+        const float invN = 1.0f / (float)N;
+        a.px[sidx] = u_pm1(c[0]); a.py[sidx] = u_pm1(c[1]);
+        a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
+        reinterpret_cast<float2*>(a.shape)[sidx] = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));
+        if (i == 0) {
+            uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+            philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+            reinterpret_cast<float2*>(a.ivel)[b] = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+            if (a.step) a.step[b] = 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Bit-exact reset on device: Scenario.reset_world (formation_hd_env.py:77-95) drawing from the
+// env's own legacy NumPy MT19937 stream (environment.py:106-110 seeds it), so that multi-episode
+// rollouts keep matching the reference without a host round trip.  One workgroup per env; the
+// 624-word state lives in LDS, is tempered / twisted in parallel and written back.
+//   draw order: N agent positions, N landmark positions, ideal velocity, two doubles each;
+//   double = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two 32-bit outputs; U(-1,1) = -1 + 2 d.
+// mt_state: uint32 [B][626] = key[624], pos, unused.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8_t* __restrict__ mask,
+                                                       uint32_t* __restrict__ mt_state,
+                                                       float* px, float* py, float* vx, float* vy,
+                                                       float* shape, float* ivel, float* lm_pos, int32_t* step) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B || (mask && !mask[b])) return;
+    uint32_t* const mt = lds_u32;                      // [624]
+    uint32_t* const outs = lds_u32 + 624;              // [8N + 4] tempered outputs
+    double* const dsum = reinterpret_cast<double*>(lds_u32 + 624 + ((8 * N + 4 + 1) & ~1));   // [2] mean of raw
+    uint32_t* const gstate = mt_state + (size_t)b * 626;
+    for (int q = tid; q < 624; q += 256) mt[q] = gstate[q];
+    int pos = (int)gstate[624];
+    __syncthreads();
+    const int M = 8 * N + 4;
+    int produced = 0;
+    auto mix = [](uint32_t a, uint32_t b2) -> uint32_t {
+        const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    while (produced < M) {
+        if (pos >= 624) {                              // regenerate the 624 words (three dependent thirds)
+            uint32_t nv = 0;
+            if (tid < 227) nv = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < 227) mt[tid] = nv;
+            __syncthreads();
+            if (tid < 227) nv = mt[tid] ^ mix(mt[tid + 227], mt[tid + 228]);            // kk = tid + 227
+            __syncthreads();
+            if (tid < 227) mt[tid + 227] = nv;
+            __syncthreads();
+            if (tid < 169) nv = mt[tid + 227] ^ mix(mt[tid + 454], mt[tid + 455]);      // kk = tid + 454 .. 622
+            const uint32_t old623 = mt[623];
+            __syncthreads();
+            if (tid < 169) mt[tid + 454] = nv;
+            __syncthreads();
+            if (tid == 0) mt[623] = mt[396] ^ mix(old623, mt[0]);
+            __syncthreads();
+            pos = 0;
+        }
+        const int take = min(624 - pos, M - produced);
+        for (int q = tid; q < take; q += 256) {
+            uint32_t y = mt[pos + q];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            outs[produced + q] = y;
+        }
+        produced += take; pos += take;
+        __syncthreads();
+    }
+    auto draw = [&](int m) -> double {                 // m-th double of this reset
+        const double a = (double)(outs[2 * m] >> 5), c = (double)(outs[2 * m + 1] >> 6);
+        return -1.0 + 2.0 * ((a * 67108864.0 + c) / 9007199254740992.0);
+    };
+    if (tid == 0) {                                    // np.mean over axis 0: rows added in order
+        double sx = 0.0, sy = 0.0;
+        for (int i = 0; i < N; ++i) { sx += draw(2 * N + 2 * i); sy += draw(2 * N + 2 * i + 1); }
+        dsum[0] = sx / (double)N; dsum[1] = sy / (double)N;
+    }
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const size_t o = (size_t)b * N + i;
+        px[o] = (float)draw(2 * i); py[o] = (float)draw(2 * i + 1);
+        vx[o] = 0.f; vy[o] = 0.f;
+        const double rx = draw(2 * N + 2 * i), ry = draw(2 * N + 2 * i + 1);
+        shape[2 * o] = (float)(rx - dsum[0]); shape[2 * o + 1] = (float)(ry - dsum[1]);
+        if (lm_pos) { lm_pos[2 * o] = (float)rx; lm_pos[2 * o + 1] = (float)ry; }
+    }
+    if (tid == 0) {
+        ivel[2 * b] = (float)draw(4 * N); ivel[2 * b + 1] = (float)draw(4 * N + 1);
+        if (step) step[b] = 0;
+        gstate[624] = (uint32_t)pos;
+    }
+    for (int q = tid; q < 624; q += 256) gstate[q] = mt[q];
+}
+
+// ---------------------------------------------------------------------------
+// Landmark scenarios with few agents (N + M <= 64): basic_formation_env (BASELINE config 1),
+// formation_hd_partial_env, formation_hd_partial_range_env, formation_hd_obs_env.
+// One lane per movable entity (N agents, then M obstacles), one env per aligned group of G
+// lanes of a wave.  Reference lines under formation_gym/envs/:
+//   basic     observation basic_formation_env.py:29-41, reward :43-52 (self "collision" included)
+//   partial   observation formation_hd_partial_env.py:38-57 (ring neighbours), reward :59-72
+//   range     observation formation_hd_partial_range_env.py:38-52 (clipped), reward as partial
+//   obstacle  observation formation_hd_obs_env.py:44-58, reward :60-99 incl. the obstacle
+//             velocity override (:84-89); obstacles are movable colliders of World.step
+// ---------------------------------------------------------------------------
+struct ScnArgs {
+    FgParams p;
+    FgScenario sc;
+    int B, N, do_phys;
+    float* px; float* py; float* vx; float* vy;
+    const float* act; const float* lm; float* opos; float* ovel; int32_t* step;
+    float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
+};
+
+template <int G, int T>
+__global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
+    constexpr int E = T / G;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int N = a.N, L = a.sc.num_landmarks, M = a.sc.num_obstacles, NE = N + M;
+    const int kind = a.sc.kind;
+    const int tid = threadIdx.x;
+    const int e = tid / G, i = tid % G;
+    const int b = blockIdx.x * E + e;
+    const bool live = b < a.B;
+    const bool is_agent = live && i < N;
+    const bool is_obst = live && i >= N && i < NE;
+    float2* const PRE = smem + e * (2 * NE + L);
+    float2* const POST = PRE + NE;
+    float2* const LM = POST + NE;
+    float2 p = make_float2(0.f, 0.f), v = p;
+    const size_t sidx = (size_t)b * N + i;
+    const size_t oidx = (size_t)b * M + (i - N);
+    if (is_agent) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+    } else if (is_obst) {
+        p = reinterpret_cast<const float2*>(a.opos)[oidx];
+        v = reinterpret_cast<const float2*>(a.ovel)[oidx];
+    }
+    if (is_agent || is_obst) { PRE[i] = p; POST[i] = p; }
+    for (int l = i; live && l < L; l += G) LM[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + l];
+    int t_step = (live && a.step) ? a.step[b] : 0;
+    __syncthreads();
+    const float my_size = 0.5f * (i < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+    if (a.do_phys) {
+        if (is_agent || is_obst) {
+            // World.step: all pairs of movable colliders, contact distance size_i + size_j
+            float fx = 0.f, fy = 0.f;
+            const float k = a.p.contact_margin;
+            for (int j = 0; j < NE; ++j) {
+                const float2 q = PRE[j];
+                const float dmin = my_size + 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+                const float cut = dmin + 18.0f * k;
+                const float dx = p.x - q.x, dy = p.y - q.y;
+                const float d2 = dx * dx + dy * dy;
+                if (j != i && d2 < cut * cut) {
+                    const float d = __builtin_amdgcn_sqrtf(d2);
+                    const float x = (dmin - d) / k;
+                    const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+                    const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                    fx += dx * c; fy += dy * c;
+                }
+            }
+            if (is_agent) {
+                const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
+                const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset);
+                fx += fa.x; fy += fa.y;
+            }
+            if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
+            v.x = v.x * (1.0f - a.p.damping) + (fx / a.p.mass) * a.p.dt;
+            v.y = v.y * (1.0f - a.p.damping) + (fy / a.p.mass) * a.p.dt;
+            if (is_agent) v = clamp_speed(a.p, v);
+            p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
+            POST[i] = p;
+            if (is_agent) {
+                a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+            } else {
+                // the reward callback re-arms the obstacle velocity every step (:84-89)
+                const bool falling = p.y > a.sc.obstacle_floor;
+                reinterpret_cast<float2*>(a.opos)[oidx] = p;
+                reinterpret_cast<float2*>(a.ovel)[oidx] =
+                    make_float2(falling ? a.sc.obstacle_vx : 0.f, falling ? a.sc.obstacle_vy : 0.f);
+            }
+        }
+        t_step += 1;
+        __syncthreads();
+    }
+    float scratch_dummy[1];
+    // ---- formation term ----
+    float form = 0.f;      // basic: sum_l min_a |p_a - l| ; others: Hausdorff(centred agents, centred landmarks)
+    if (kind == FG_SCN_BASIC) {
+        float cover = 0.f;
+        for (int l0 = 0; l0 < L; l0 += G) {
+            const int l = l0 + i;
+            if (live && l < L) {
+                const float2 m = LM[l];
+                float best = INFINITY; int barg = 0;
+                for (int j = 0; j < N; ++j) {
+                    const float2 q = POST[j];
+                    const float dx = q.x - m.x, dy = q.y - m.y, d2 = dx * dx + dy * dy;
+                    if (d2 < best) { best = d2; barg = j; }
+                }
+                cover += sqrtf(best);
+                if (a.near_ag) a.near_ag[(size_t)b * L + l] = barg;
+            }
+        }
+        float red[1] = {cover};
+        env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch_dummy);
+        form = red[0];
+    } else {
+        float s4[4] = {is_agent ? p.x : 0.f, is_agent ? p.y : 0.f, 0.f, 0.f};
+        for (int l = i; live && l < L; l += G) { s4[2] += LM[l].x; s4[3] += LM[l].y; }
+        env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(s4, scratch_dummy);
+        const float mx = s4[0] / (float)N, my = s4[1] / (float)N;
+        const float lx = s4[2] / (float)L, ly = s4[3] / (float)L;
+        float rowmin = -INFINITY, colmax = -INFINITY;
+        if (is_agent) {                                         // min over landmarks for my agent
+            rowmin = INFINITY;
+            for (int l = 0; l < L; ++l) {
+                const float dx = (p.x - mx) - (LM[l].x - lx), dy = (p.y - my) - (LM[l].y - ly);
+                rowmin = fminf(rowmin, dx * dx + dy * dy);
+            }
+        }
+        for (int l = i; live && l < L; l += G) {                // min over agents for my landmark(s)
+            float cm = INFINITY;
+            for (int j = 0; j < N; ++j) {
+                const float dx = (POST[j].x - mx) - (LM[l].x - lx), dy = (POST[j].y - my) - (LM[l].y - ly);
+                cm = fminf(cm, dx * dx + dy * dy);
+            }
+            colmax = fmaxf(colmax, cm);
+        }
+        float red[2] = {rowmin, colmax};
+        env_reduce<G, G, 2, R_MAX, R_MAX, R_MAX, R_MAX>(red, scratch_dummy);
+        form = sqrtf(fmaxf(red[0], red[1]));
+    }
+    // ---- collision counts ----
+    int cnt = 0;
+    if (is_agent) {
+        const float thr = a.p.collide_thresh, thr2 = (float)((double)thr * (double)thr);
+        for (int j = 0; j < N; ++j) {
+            const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
+            cnt += ((kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < thr2) ? 1 : 0;
+        }
+        const float ot = 0.5f * a.p.dist_min + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
+        for (int j = N; j < NE; ++j) {
+            const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
+            cnt += (dx * dx + dy * dy < ot2) ? 1 : 0;
+        }
+    }
+    float cs[1] = {(float)cnt};
+    env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch_dummy);
+    const bool is_done = t_step >= a.p.world_length;
+    // ---- outputs ----
+    const int nbr = (kind == FG_SCN_PARTIAL) ? a.sc.num_obs : (N - 1);
+    const int D = 2 + (kind == FG_SCN_BASIC ? 2 : 0) + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1);
+    if (is_agent) {
+        if (a.rew) a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
+        if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
+        if (a.done) a.done[sidx] = is_done ? 1 : 0;
+        float2* o = reinterpret_cast<float2*>(a.obs + sidx * D);
+        int w = 0;
+        o[w++] = v;
+        if (kind == FG_SCN_BASIC) o[w++] = p;
+        for (int l = 0; l < L; ++l) {
+            const float2 m = LM[l];
+            o[w++] = (kind == FG_SCN_BASIC) ? make_float2(m.x - p.x, m.y - p.y) : m;
+        }
+        for (int j = N; j < NE; ++j) { const float2 q = POST[j]; o[w++] = make_float2(q.x - p.x, q.y - p.y); }
+        if (kind == FG_SCN_PARTIAL) {
+            for (int kk = 0; kk < nbr; ++kk) {
+                const float2 q = POST[(i + 1 + kk) % N];
+                o[w++] = make_float2(q.x - p.x, q.y - p.y);
+            }
+        } else {
+            const float r = (kind == FG_SCN_RANGE) ? a.sc.obs_range : INFINITY;
+            for (int j = 0; j < N; ++j) if (j != i) {
+                const float2 q = POST[j];
+                o[w++] = make_float2(fminf(fmaxf(q.x - p.x, -r), r), fminf(fmaxf(q.y - p.y, -r), r));
+            }
+        }
+        for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
+    }
+    if (a.do_phys && a.step && live && i == 0) a.step[b] = t_step;
+}
+
+}  // namespace fg
+
+#endif  // FG_AUX_KERNELS_HPP_

@@ -1,0 +1,210 @@
+// fg_common.hpp - Shared device-side definitions: kernel argument block, LDS layout of one environment,
+// in-register butterfly reductions, counter RNG, World options.
+// Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+#ifndef FG_COMMON_HPP_
+#define FG_COMMON_HPP_
+
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "formation_hip.h"
+
+#ifndef FG_PROBES
+#define FG_PROBES 0        // 1: honour the FG_PROBE timing experiments (results are then NOT valid)
+#endif
+#ifndef FG_WRITER_PRIO
+#define FG_WRITER_PRIO 0   // tuning: s_setprio level of the rollout writer waves
+#endif
+#ifndef FG_TILE_NT
+#define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer (measured: -6 %, profiles/README.md)
+#endif
+
+namespace fg {
+
+#define FG_DEV __device__ __forceinline__
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS block of one environment, in floats:
+//   float2 tables  A[3N] = post pos[N] | zeros[N-1] | ideal_shape[N] | ideal_vel[1],  V[N],  NV[N] = -V
+//                  (what the observation writers read: unit u >= N of any row is A[u])
+//   float arrays   QX QY (pre-step pos)  PX PY (post-step pos)  SX SY (ideal shape), each padded
+//                  to NP = N rounded up to 4 with a far-away sentinel, read two agents at a time
+//                  (ds_read_b64) by the packed-math pair loops
+__host__ __device__ constexpr int npad(int n) { return (n + 3) & ~3; }
+__host__ __device__ constexpr int env_block_floats(int n) { return 10 * n + 6 * npad(n); }
+FG_DEV float2* env_tables(float2* smem, int ee, int n) {
+    return reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + ee * env_block_floats(n));
+}
+FG_DEV const float2* env_tables(const float2* smem, int ee, int n) {
+    return reinterpret_cast<const float2*>(reinterpret_cast<const float*>(smem) + ee * env_block_floats(n));
+}
+constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances stay finite (2e36)
+
+struct Args {
+    FgParams p;
+    int B, N, K, obs_every;
+    int do_phys, do_post;
+    int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
+    int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)
+    float* px; float* py; float* vx; float* vy;
+    const float* act;          // [K][B][N][2]
+    float* shape;              // [B][N][2]
+    float* ivel;               // [B][2]
+    int32_t* step;             // [B]
+    float* obs;                // [slots][B][N][6N]
+    float* rew;                // [K][B][N]
+    float* indiv;              // [K][B][N] or NULL
+    uint8_t* done;             // [K][B][N] or NULL
+    int32_t* near_lm; int32_t* near_ag; int32_t* hd_idx;
+};
+
+// ---------------------------------------------------------------------------
+// reductions over the lanes of one environment
+// ---------------------------------------------------------------------------
+enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
+
+template <int OP> FG_DEV float combine(float a, float b) {
+    if (OP == R_SUM) return a + b;
+    if (OP == R_MAX) return fmaxf(a, b);
+    return fminf(a, b);
+}
+
+// Cross-lane partner fetch for a butterfly reduction step, without going through the LDS
+// crossbar (ds_bpermute costs ~100 cycles of latency per step): DPP quad permutes and row
+// mirrors inside a 16-lane row, v_permlane16/32_swap across rows (gfx950).  STEP 4 and 8 use
+// mirrors instead of xor: any pairing of disjoint halves that already hold their own totals
+// gives the same reduction.
+template <int STEP, int OP> FG_DEV float bfly(float v) {
+    const int iv = __builtin_bit_cast(int, v);
+    if constexpr (STEP >= 16) {
+        // v_permlane{16,32}_swap(v, v) returns the two row / half sets side by side:
+        // {rows 0,0,2,2 | rows 1,1,3,3} resp. {low,low | high,high}; combining them IS the step
+        const auto sw = (STEP == 16) ? __builtin_amdgcn_permlane16_swap(iv, iv, false, false)
+                                     : __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+        return combine<OP>(__builtin_bit_cast(float, (int)sw[0]), __builtin_bit_cast(float, (int)sw[1]));
+    } else {
+        constexpr int CTRL = (STEP == 1) ? 0xB1      // quad_perm [1,0,3,2]
+                           : (STEP == 2) ? 0x4E      // quad_perm [2,3,0,1]
+                           : (STEP == 4) ? 0x141     // row_half_mirror
+                                         : 0x140;    // row_mirror
+        const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
+        return combine<OP>(v, __builtin_bit_cast(float, r));
+    }
+}
+
+// G <= 64: the env occupies an aligned group of G lanes of one wave -> in-register butterfly.
+// G  > 64: the env is the whole workgroup (E == 1) -> wave butterfly + LDS partials.
+template <int G, int T, int NV, int OP0, int OP1, int OP2, int OP3>
+FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
+    constexpr int W = (G <= 64) ? G : 64;
+#define FG_STEP(S)                                                                   \
+    if constexpr (W > S) {                                                           \
+        if constexpr (NV > 0) v[0] = bfly<S, OP0>(v[0]);           \
+        if constexpr (NV > 1) v[1] = bfly<S, OP1>(v[1]);           \
+        if constexpr (NV > 2) v[2] = bfly<S, OP2>(v[2]);           \
+        if constexpr (NV > 3) v[3] = bfly<S, OP3>(v[3]);           \
+    }
+    FG_STEP(1) FG_STEP(2) FG_STEP(4) FG_STEP(8) FG_STEP(16) FG_STEP(32)
+#undef FG_STEP
+    if (G > 64) {
+        constexpr int NW = T / 64;
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) scratch[wave * 4 + q] = v[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = scratch[q];
+        for (int w = 1; w < NW; ++w) {
+            if constexpr (NV > 0) v[0] = combine<OP0>(v[0], scratch[w * 4 + 0]);
+            if constexpr (NV > 1) v[1] = combine<OP1>(v[1], scratch[w * 4 + 1]);
+            if constexpr (NV > 2) v[2] = combine<OP2>(v[2], scratch[w * 4 + 2]);
+            if constexpr (NV > 3) v[3] = combine<OP3>(v[3], scratch[w * 4 + 3]);
+        }
+        __syncthreads();   // scratch is reused by the next reduction
+    }
+}
+
+// ---------------------------------------------------------------------------
+// counter-based RNG for the device-side reset (Philox4x32-10, Salmon et al. 2011)
+// ---------------------------------------------------------------------------
+FG_DEV void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t m0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t m1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(m1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(m0 >> 32) ^ c[3] ^ k1;
+        c[1] = (uint32_t)m1; c[3] = (uint32_t)m0; c[0] = n0; c[2] = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
+    return (float)(x >> 8) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// World options no reference scenario enables: walls, motor noise, speed clamp
+// ---------------------------------------------------------------------------
+// core.py:325-362 get_wall_collision_force, summed over the walls (hard walls, no ghosts)
+FG_DEV void wall_forces(const FgParams& P, float2 p, float size, float& fx, float& fy) {
+#pragma unroll
+    for (int w = 0; w < FG_MAX_WALLS; ++w) {                                   // static indices: no scratch copy
+        if (w >= P.num_walls) break;
+        const FgWall wl = P.walls[w];
+        const float prll = wl.vertical ? p.y : p.x;
+        const float perp = wl.vertical ? p.x : p.y;
+        if (prll < wl.end0 - size || prll > wl.end1 + size) continue;      // beyond the endpoints
+        float ct = 1.0f, st = 0.0f;
+        if (prll < wl.end0 || prll > wl.end1) {                            // rounding the corner
+            const float past = (prll < wl.end0) ? prll - wl.end0 : prll - wl.end1;
+            st = past / size;                                              // sin(theta)
+            ct = __builtin_amdgcn_sqrtf(fmaxf(1.0f - st * st, 0.0f));
+        }
+        const float dmin = ct * size + 0.5f * wl.width;
+        const float delta = perp - wl.axis_pos;
+        const float dist = fabsf(delta);
+        const float x = (dmin - dist) / P.contact_margin;
+        const float pen = P.contact_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+        const float mag = P.contact_force * delta * __builtin_amdgcn_rcpf(dist) * pen;   // dist == 0 -> NaN, as the reference
+        const float f_perp = ct * mag, f_prll = st * fabsf(mag);
+        if (wl.vertical) { fx += f_perp; fy += f_prll; } else { fy += f_perp; fx += f_prll; }
+    }
+}
+
+FG_DEV float2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset) {
+    uint32_t c[4] = {b, i ^ 0x80000000u, (uint32_t)offset, (uint32_t)(offset >> 32)};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float r = sqrtf(-2.0f * __logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));   // Box-Muller
+    const float a = 6.2831853f * ((float)(c[1] >> 8) * (1.0f / 16777216.0f));
+    return make_float2(r * __cosf(a), r * __sinf(a));
+}
+
+// action force incl. accel (core.py:236, environment.py:219-220) and motor noise (core.py:232-233)
+FG_DEV float2 action_force(const FgParams& P, float2 u, uint32_t b, uint32_t i, uint64_t offset) {
+    const float gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
+    float2 f = make_float2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
+    if (P.u_noise > 0.0f) {
+        const float2 n = motor_noise(P.seed, b, i, offset);
+        f.x += P.u_noise * n.x;
+        f.y += P.u_noise * n.y;
+    }
+    return f;
+}
+
+FG_DEV float2 clamp_speed(const FgParams& P, float2 v) {                    // core.py:271-276
+    if (P.max_speed > 0.0f) {
+        const float speed = sqrtf(v.x * v.x + v.y * v.y);
+        if (speed > P.max_speed) { v.x = v.x / speed * P.max_speed; v.y = v.y / speed * P.max_speed; }
+    }
+    return v;
+}
+
+}  // namespace fg
+
+#endif  // FG_COMMON_HPP_

@@ -1,0 +1,217 @@
+// fg_obs_writers.hpp - Observation writers: register-cached rows and LDS tiles.
+// Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+#ifndef FG_OBS_WRITERS_HPP_
+#define FG_OBS_WRITERS_HPP_
+
+#include "fg_common.hpp"
+
+namespace fg {
+
+// ---------------------------------------------------------------------------
+// observation row writer (specialised N): every wave streams whole rows.
+// A row is [v_i | p_j - p_i (j != i) | zeros | ideal_shape | ideal_vel] = 3N (x,y) units.
+//  * units N..3N-1 are identical for every row of an env: each lane loads its share ONCE
+//    into registers and then only stores (one 8-byte store per 64 units per row);
+//  * units 0..N-1: lane u keeps p_{u-1} and p_u in registers; per row it reads p_row (or
+//    -v_row on lane u = 0) from LDS, selects by (u-1 >= row), subtracts, stores.
+// ~3 vector instructions per 512-byte wave store instead of ~25 for a flat decode.
+// Waves of the workgroup split the E*N rows: whole envs per wave when E >= #waves, else
+// rows of one env round-robin over the waves that share it.
+// ---------------------------------------------------------------------------
+// value select (never a pointer select: that would go through scratch + flat loads)
+FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
+    const float2 t = p[c ? idx_if_true : 0];
+    return make_float2(c ? t.x : 0.0f, c ? t.y : 0.0f);
+}
+
+template <int NC, int NW, int E>
+FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
+                           float2* __restrict__ out_env0, int El, int parts) {
+    // tables0 / env_stride: A-table of env 0 and the distance (float2) to the next env's;
+    // w: index of this wave among the NW waves that share the job
+    // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
+    constexpr int N = NC;
+    constexpr int WPE = (E >= NW) ? 1 : NW / E;             // waves sharing one env
+    constexpr int ESTEP = (E >= NW) ? NW : 1;               // env stride of one wave
+    static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
+    const int lane = threadIdx.x & 63;
+    const int row0 = (E >= NW) ? 0 : w % WPE;
+    constexpr unsigned ROWU = 3u * N;                       // units per row
+    for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
+        const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
+        float2* __restrict__ out = out_env0 + (size_t)ee * (ROWU * N);
+        if constexpr (N <= 64) {
+            // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
+            // whole block, then the static part (zeros | ideal_shape | ideal_vel, the same for every
+            // row: register-resident) of the same rows follows at once, so that the cache lines a
+            // row shares with its neighbours are completed back to back.
+            constexpr int RW = 64 / N;
+            const int rsub = lane / N, u = lane - rsub * N;
+            const bool act = rsub < RW;
+            const float2 zero = make_float2(0.f, 0.f);
+            const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
+            const float2 Pu = lds_if(act && u >= 1, AA, u);
+            const int xoff = (u == 0) ? 4 * N : 0;          // lane u = 0 reads -v_row (NV = A + 4N)
+            constexpr int CS = (2 * N + 63) / 64;           // 64-unit chunks of the static part
+            constexpr int RS = (2 * N <= 64) ? 64 / (2 * N) : 1;   // rows per static store
+            const int ssub = (2 * N <= 64) ? lane / (2 * N) : 0;
+            const int sidx = (2 * N <= 64) ? lane - ssub * 2 * N : lane;
+            float2 sv[CS];
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+                sv[c] = lds_if(ssub < RS && sidx + 64 * c < 2 * N, AA, N + sidx + 64 * c);
+#pragma unroll 2
+            for (int rb = row0; rb < N; rb += RW * WPE) {
+                const int r = rb + rsub * WPE;
+                if ((parts & 1) && act && r < N) {
+                    const float2 x = AA[xoff + r];
+                    const float2 c = (u - 1 >= r) ? Pu : Pm;
+                    out[(unsigned)r * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+                }
+#pragma unroll
+                for (int k0 = 0; k0 < RW; k0 += RS) {
+                    const int rs = rb + (k0 + ssub) * WPE;
+                    if ((parts & 2) && ssub < RS && k0 + ssub < RW && rs < N) {
+#pragma unroll
+                        for (int c = 0; c < CS; ++c)
+                            if (sidx + 64 * c < 2 * N) out[(unsigned)rs * ROWU + (unsigned)(N + sidx + 64 * c)] = sv[c];
+                    }
+                }
+            }
+        } else {
+            // ---- N > 64: one row per iteration, register-cached chunks of 64 units ----
+            constexpr int CD = (N + 63) / 64, CS = (2 * N + 63) / 64;
+            const float2 zero = make_float2(0.f, 0.f);
+            float2 Pm[CD], Pu[CD], sv[CS];
+#pragma unroll
+            for (int c = 0; c < CD; ++c) {
+                const int u = lane + 64 * c;
+                Pm[c] = lds_if(u >= 1 && u < N, AA, u - 1);
+                Pu[c] = lds_if(u >= 1 && u < N, AA, u);
+            }
+#pragma unroll
+            for (int c = 0; c < CS; ++c) sv[c] = lds_if(lane + 64 * c < 2 * N, AA, N + lane + 64 * c);
+#pragma unroll 2
+            for (int r = row0; r < N; r += WPE) {
+                const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
+                const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
+                float2* __restrict__ orow = out + (unsigned)r * ROWU;
+#pragma unroll
+                for (int c = 0; c < CD; ++c) {
+                    const int u = lane + 64 * c;
+                    const float2 x = (c == 0) ? x0 : xp;
+                    const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
+                    if ((parts & 1) && u < N) orow[u] = make_float2(cc.x - x.x, cc.y - x.y);
+                }
+#pragma unroll
+                for (int c = 0; c < CS; ++c)
+                    if ((parts & 2) && lane + 64 * c < 2 * N) orow[N + lane + 64 * c] = sv[c];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LDS-tiled observation writer (N <= 32): a wave composes RT consecutive rows of one env in
+// its own LDS tile with the register-cached scheme of write_obs_rows (ds_write_b64), then
+// streams the tile out as ONE contiguous span: ds_read_b128 + global_store_dwordx4, lanes
+// consecutive, 1 KiB per wave instruction, so almost every 128-byte line is written by a
+// single store request.  The tile sits in LDS at the same 16-byte phase as its destination
+// (tiles of an odd N start 8 bytes off every other time), so both sides of the copy are
+// naturally aligned.  Only the issuing wave touches its tile: LDS operations of one wave
+// complete in order, no barrier is needed.
+// ---------------------------------------------------------------------------
+template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 + 1) & ~1; }
+
+// `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
+template <int NC, int NW, int E, int RT>
+FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
+                            float2* __restrict__ out_env0, size_t unit0, int El) {
+    constexpr int N = NC;
+    constexpr int WPE = (E >= NW) ? 1 : NW / E;
+    static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
+    static_assert(N <= 32 && N % RT == 0, "tiled writer: N <= 32, RT divides N");
+    constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
+    constexpr int TILES_ENV = N / RT;                                  // tiles per env
+    constexpr int MY_TILES = (TILES_ENV + WPE - 1) / WPE;              // of which this wave takes every WPE-th
+    const int lane = threadIdx.x & 63;
+    float2* tile0 = tiles + w * 2 * tile_units<NC, RT>();
+    constexpr int RW = 64 / N;
+    const int rsub = lane / N, u = lane - rsub * N;
+    const bool act = rsub < RW;
+    const int xoff = (u == 0) ? 4 * N : 0;
+    constexpr int RS = 64 / (2 * N);
+    const int ssub = lane / (2 * N), sidx = lane - ssub * 2 * N;
+    const int e_first = (E >= NW) ? w : w / WPE, e_step = (E >= NW) ? NW : E;
+    const int t_first = (E >= NW) ? 0 : w % WPE;
+    const int n_env = (El > e_first) ? (El - e_first + e_step - 1) / e_step : 0;
+    const int total = n_env * MY_TILES;
+
+    int cur_env = -1;
+    const float2* __restrict__ AA = tables0;
+    float2 Pm = make_float2(0.f, 0.f), Pu = Pm, sv = Pm;
+    auto locate = [&](int t, int& ee, int& r0) {                       // t-th tile of this wave
+        const int ie = t / MY_TILES, it = t - ie * MY_TILES;
+        ee = e_first + ie * e_step;
+        r0 = (t_first + it * WPE) * RT;
+    };
+    auto compose = [&](int t) {
+        int ee, r0; locate(t, ee, r0);
+        if (r0 >= N) return;
+        if (ee != cur_env) {                                           // per-env register cache
+            cur_env = ee;
+            AA = tables0 + (size_t)ee * env_stride;
+            Pm = lds_if(act && u >= 1, AA, u - 1);
+            Pu = lds_if(act && u >= 1, AA, u);
+            sv = lds_if(ssub < RS, AA, N + sidx);
+        }
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;     // no restrict: the two tiles alternate
+#pragma unroll
+        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
+            const int rl = rb + rsub;
+            if (act && rl < RT) {
+                const int r = r0 + rl;
+                const float2 x = AA[xoff + r];
+                const float2 c = (u - 1 >= r) ? Pu : Pm;
+                img[(unsigned)rl * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RS) {
+            const int rl = rb + ssub;
+            if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
+        }
+    };
+    auto stream = [&](int t) {
+        int ee, r0; locate(t, ee, r0);
+        if (r0 >= N) return;
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
+        float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
+        if (par && lane == 0) out[0] = img[0];
+        constexpr unsigned NPMAX = TU >> 1;
+        const unsigned npair = (TU - par) >> 1;
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + par);
+        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
+#pragma unroll
+        for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
+            const unsigned q = q0 + lane;
+            if (q < npair) {
+                if (FG_TILE_NT == 1) __builtin_nontemporal_store(src4[q], &dst4[q]);
+                else if (FG_TILE_NT == 2) { const f32x4 cst = {1.f, 2.f, 3.f, 4.f}; dst4[q] = cst; }   // timing probe
+                else dst4[q] = src4[q];
+            }
+        }
+        if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
+    };
+    if (total > 0) compose(0);
+    for (int t = 0; t < total; ++t) {
+        if (t + 1 < total) compose(t + 1);
+        stream(t);
+    }
+}
+
+}  // namespace fg
+
+#endif  // FG_OBS_WRITERS_HPP_

@@ -1,0 +1,446 @@
+// fg_rollout_kernels.hpp - Producer / writer pipelined kernels (rollout over steps, single step over env batches).
+// Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+#ifndef FG_ROLLOUT_KERNELS_HPP_
+#define FG_ROLLOUT_KERNELS_HPP_
+
+#include "fg_common.hpp"
+#include "fg_pair_loops.hpp"
+#include "fg_obs_writers.hpp"
+
+namespace fg {
+
+// ---------------------------------------------------------------------------
+// Pipelined K-step rollout (N <= 32): wave specialisation inside one workgroup.
+//   producer waves (tid < TP): agents on lanes as in step_kernel; they run World.step + reward
+//       of step k+1 while
+//   writer waves   (tid >= TP): stream the observations of step k,
+// handing over through double-buffered LDS tables and ONE workgroup barrier per step.
+// In a single-step launch the pair loops and reductions sit in front of the store stream;
+// here they hide under it, so the rollout runs at the store rate.  Everything a producer
+// needs from other lanes is produced by its own wave (G <= 64): LDS operations of one wave
+// complete in order and the reductions are in-register butterflies, so producers need no
+// barrier among themselves.
+// LDS per env (floats): tables[2][A[3N] | V[N] | NV[N]] (float2), then QX QY PX PY SX SY [NP].
+// ---------------------------------------------------------------------------
+__host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
+
+template <int NC, int G, int TP, int TW, int E, int WR>
+__global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
+    static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
+    constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float* const smemf = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x;
+    const bool producer = tid < TP;
+    const int e = producer ? tid / G : 0;
+    const int i = tid % G;
+    const int b0 = blockIdx.x * E;
+    const int b = b0 + e;
+    const bool env_ok = producer && (b < a.B);
+    const bool valid = env_ok && (i < N);
+    const int El = min(E, a.B - b0);
+    float* const blk = smemf + e * roll_block_floats(N);
+    float2* const TB0 = reinterpret_cast<float2*>(blk);                 // tables of buffer 0; buffer 1 at + 5N
+    float* const QX = blk + 20 * N;
+    float* const QY = QX + NP; float* const PX = QY + NP; float* const PY = PX + NP;
+    float* const SX = PY + NP; float* const SY = SX + NP;
+
+    const float one_minus_damp = 1.0f - a.p.damping;
+    const float dt = a.p.dt;
+    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;
+    const float cutoff2 = cutoff * cutoff;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const float invN = 1.0f / (float)N;
+
+    float2 p = make_float2(0.f, 0.f), v = p, s = p, iv = p;
+    int t_step = 0;
+    const size_t sidx = (size_t)b * N + i;
+    if (valid) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        s = reinterpret_cast<const float2*>(a.shape)[sidx];
+        QX[i] = p.x; QY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
+        if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
+    } else if (env_ok && i < NP) {
+        QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+    }
+    if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+
+    // one producer step: World.step + reward of step k into table buffer (k & 1)
+    auto produce = [&](int k) {
+        float2* const A = TB0 + (k & 1) * 5 * N;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid) {
+            const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+            float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                                            a.p.dist_min, cutoff2);
+            f.x += a.p.mass * (a.p.sensitivity * u.x);
+            f.y += a.p.mass * (a.p.sensitivity * u.y);
+            v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
+            v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
+            p.x += v.x * dt;
+            p.y += v.y * dt;
+            PX[i] = p.x; PY[i] = p.y;
+        }
+        t_step += 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+        env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, nullptr);
+        const float mx = sums[0] * invN, my = sums[1] * invN;
+        const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+        float rowmin = INFINITY, colmin = INFINITY;
+        int cnt = 0, arg_lm = 0, arg_ag = 0;
+        if (valid)
+            reward_pass_packed<false>(PX, PY, SX, SY, NP, p, p.x - mx, p.y - my, s.x + mx, s.y + my, thr2,
+                                      rowmin, colmin, cnt, arg_lm, arg_ag);
+        float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+        env_reduce<G, G, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
+        const float H = sqrtf(fmaxf(red[0], red[1]));
+        const float ex = iv.x - mvx, ey = iv.y - mvy;
+        const float velterm = sqrtf(ex * ex + ey * ey);
+        const bool is_done = t_step >= a.p.world_length;
+        if (valid) {
+            const size_t o = ((size_t)k * a.B + b) * N + i;
+            if (a.rew) a.rew[o] = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt;
+            if (a.done) a.done[o] = is_done ? 1 : 0;
+        }
+        if (a.p.auto_reset) {
+            const bool mine = is_done && env_ok;
+            if (__any(mine) != 0) {
+                uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
+                                 (uint32_t)((a.p.rng_offset + k) >> 32)};
+                philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                const float rx = raw[0], ry = raw[1];
+                env_reduce<G, G, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, nullptr);
+                uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
+                                  (uint32_t)((a.p.rng_offset + k) >> 32)};
+                philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                if (mine) {
+                    iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                    t_step = 0;
+                    if (valid) {
+                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_float2(0.f, 0.f);
+                        s = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
+                        SX[i] = s.x; SY[i] = s.y;
+                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
+                        if (i == 0) reinterpret_cast<float2*>(a.ivel)[b] = iv;
+                    }
+                }
+            }
+        }
+        if (valid) {                                   // publish this step's tables + next step's partners
+            A[i] = p; A[3 * N + i] = v; A[4 * N + i] = make_float2(-v.x, -v.y);
+            A[2 * N - 1 + i] = s;
+            if (i == 0) A[3 * N - 1] = iv;
+            QX[i] = p.x; QY[i] = p.y;
+        }
+    };
+
+    if (producer) produce(0);
+#if FG_WRITER_PRIO
+    else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
+#endif
+    __syncthreads();
+    for (int k = 0; k < a.K; ++k) {
+        if (producer) {
+            if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1);      // probe 1/2: writers only
+        } else {
+            int slot = k;
+            bool want_obs = a.obs != nullptr;
+            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+            if (want_obs) {
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
+                if constexpr (WR == 0)
+                    write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                               reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
+                else
+                    write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                                        reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
+                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+            }
+        }
+        if (!(FG_PROBES && a.probe == 2)) __syncthreads();                    // probe 2: no hand-over sync
+    }
+    if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
+    if (a.step && env_ok && i == 0) a.step[b] = t_step;
+}
+
+// ---------------------------------------------------------------------------
+// Pipelined K-step rollout for 64 < N <= 256: the same producer / writer split, with ONE
+// producer wave per environment holding A = ceil(N/64) agents per lane (agent lane + 64 a), so
+// that every reduction stays inside the wave and producers still need no barrier of their own.
+// The partner loops load each partner pair once and update all A agents of the lane.
+// ---------------------------------------------------------------------------
+template <int NC, int A, int E, int TW>
+__global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a) {
+    static_assert(A * 64 >= NC && (A - 1) * 64 < NC && TW % 64 == 0, "bad wide rollout geometry");
+    constexpr int N = NC, NP = npad(NC), NWW = TW / 64, TP = E * 64;
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float* const smemf = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool producer = tid < TP;
+    const int e = producer ? tid >> 6 : 0;
+    // K > 1: the workgroup owns E envs for K steps.  K == 1 (`groups` > 1): it owns `groups`
+    // consecutive batches of E envs and pipelines over the batches instead of over the steps.
+    const int NG = (a.K > 1) ? 1 : max(1, a.groups);
+    const int wg0 = blockIdx.x * E * NG;
+    int b = wg0 + e;
+    bool env_ok = producer && (b < a.B);
+    float* const blk = smemf + e * roll_block_floats(N);
+    float2* const TB0 = reinterpret_cast<float2*>(blk);
+    float* const QX = blk + 20 * N;
+    float* const QY = QX + NP; float* const PX = QY + NP; float* const PY = PX + NP;
+    float* const SX = PY + NP; float* const SY = SX + NP;
+
+    const float one_minus_damp = 1.0f - a.p.damping;
+    const float dt = a.p.dt;
+    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;
+    const float cutoff2 = cutoff * cutoff;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const float invN = 1.0f / (float)N;
+    const float inv_k = 1.0f / a.p.contact_margin;
+
+    float2 p[A], v[A], s[A];
+    bool valid[A];
+    float2 iv = make_float2(0.f, 0.f);
+    int t_step = 0;
+    if (producer) {                                     // row-independent table entries and loop sentinels: once
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            const int i = lane + 64 * q;
+            if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
+            if (i >= N && i < NP) {
+                QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+            }
+        }
+    }
+    auto load_group = [&](int g) {                      // state of env batch g -> registers + partner arrays
+        b = wg0 + g * E + e;
+        env_ok = producer && (b < a.B);
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            const int i = lane + 64 * q;
+            valid[q] = env_ok && i < N;
+            p[q] = v[q] = s[q] = make_float2(0.f, 0.f);
+            if (valid[q]) {
+                const size_t o = (size_t)b * N + i;
+                p[q] = make_float2(a.px[o], a.py[o]);
+                v[q] = make_float2(a.vx[o], a.vy[o]);
+                s[q] = reinterpret_cast<const float2*>(a.shape)[o];
+                QX[i] = p[q].x; QY[i] = p[q].y; SX[i] = s[q].x; SY[i] = s[q].y;
+            }
+        }
+        iv = make_float2(0.f, 0.f); t_step = 0;
+        if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+    };
+    auto store_group = [&]() {
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            if (valid[q]) {
+                const size_t o = (size_t)b * N + lane + 64 * q;
+                a.px[o] = p[q].x; a.py[o] = p[q].y; a.vx[o] = v[q].x; a.vy[o] = v[q].y;
+            }
+        }
+        if (a.step && env_ok && lane == 0) a.step[b] = t_step;
+    };
+
+    auto produce = [&](int k, int buf) {
+        float2* const T = TB0 + buf * 5 * N;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- World.step: all A agents of the lane against each partner pair ----
+        float fx[A], fy[A];
+#pragma unroll
+        for (int q = 0; q < A; ++q) { fx[q] = 0.f; fy[q] = 0.f; }
+        if (env_ok) {
+            for (int j = 0; j < NP; j += 2) {
+                const f32x2 qx = *reinterpret_cast<const f32x2*>(QX + j);
+                const f32x2 qy = *reinterpret_cast<const f32x2*>(QY + j);
+#pragma unroll
+                for (int q = 0; q < A; ++q) {
+                    const int i = lane + 64 * q;
+                    const f32x2 dx = (f32x2){p[q].x, p[q].x} - qx, dy = (f32x2){p[q].y, p[q].y} - qy;
+                    const f32x2 d2 = dx * dx + dy * dy;
+                    const bool n0 = (d2.x < cutoff2) && (j != i) && valid[q];
+                    const bool n1 = (d2.y < cutoff2) && (j + 1 != i) && valid[q];
+                    if (n0 || n1) {
+                        auto add = [&](float ddx, float ddy, float dd2) {
+                            const float d = __builtin_amdgcn_sqrtf(dd2);
+                            const float x = (a.p.dist_min - d) * inv_k;
+                            const float pen = a.p.contact_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+                            const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                            fx[q] += ddx * c; fy[q] += ddy * c;
+                        };
+                        if (n0) add(dx.x, dy.x, d2.x);
+                        if (n1) add(dx.y, dy.y, d2.y);
+                    }
+                }
+            }
+        }
+        // float sums are reduced per 64-agent slice and then combined slice by slice: the exact
+        // association order of step_kernel (wave butterfly, then waves in order) -> bit-identical
+        float sums[4] = {0.f, 0.f, 0.f, 0.f};
+        float part[A][4];
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            part[q][0] = part[q][1] = part[q][2] = part[q][3] = 0.f;
+            if (valid[q]) {
+                const int i = lane + 64 * q;
+                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                const float ffx = fx[q] + a.p.mass * (a.p.sensitivity * u.x);
+                const float ffy = fy[q] + a.p.mass * (a.p.sensitivity * u.y);
+                v[q].x = v[q].x * one_minus_damp + (ffx / a.p.mass) * dt;
+                v[q].y = v[q].y * one_minus_damp + (ffy / a.p.mass) * dt;
+                p[q].x += v[q].x * dt;
+                p[q].y += v[q].y * dt;
+                PX[i] = p[q].x; PY[i] = p[q].y;
+                part[q][0] = p[q].x; part[q][1] = p[q].y; part[q][2] = v[q].x; part[q][3] = v[q].y;
+            }
+        }
+        t_step += 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            env_reduce<64, 64, 4, R_SUM, R_SUM, R_SUM, R_SUM>(part[q], nullptr);
+            if (q == 0) { sums[0] = part[0][0]; sums[1] = part[0][1]; sums[2] = part[0][2]; sums[3] = part[0][3]; }
+            else { sums[0] += part[q][0]; sums[1] += part[q][1]; sums[2] += part[q][2]; sums[3] += part[q][3]; }
+        }
+        const float mx = sums[0] * invN, my = sums[1] * invN;
+        const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+        // ---- reward pass ----
+        float rowmin[A], colmin[A];
+        int cnt[A];
+#pragma unroll
+        for (int q = 0; q < A; ++q) { rowmin[q] = INFINITY; colmin[q] = INFINITY; cnt[q] = -1; }
+        if (env_ok) {
+            for (int j = 0; j < NP; j += 2) {
+                const f32x2 qx = *reinterpret_cast<const f32x2*>(PX + j);
+                const f32x2 qy = *reinterpret_cast<const f32x2*>(PY + j);
+                const f32x2 sx = *reinterpret_cast<const f32x2*>(SX + j);
+                const f32x2 sy = *reinterpret_cast<const f32x2*>(SY + j);
+#pragma unroll
+                for (int q = 0; q < A; ++q) {
+                    const f32x2 cx = qx - (f32x2){p[q].x, p[q].x}, cy = qy - (f32x2){p[q].y, p[q].y};
+                    const f32x2 dc = cx * cx + cy * cy;
+                    cnt[q] += (dc.x < thr2 ? 1 : 0) + (dc.y < thr2 ? 1 : 0);
+                    const float ptx = p[q].x - mx, pty = p[q].y - my;
+                    const f32x2 rx = (f32x2){ptx, ptx} - sx, ry = (f32x2){pty, pty} - sy;
+                    const f32x2 dr = rx * rx + ry * ry;
+                    const float tx = s[q].x + mx, ty = s[q].y + my;
+                    const f32x2 ux = qx - (f32x2){tx, tx}, uy = qy - (f32x2){ty, ty};
+                    const f32x2 dq = ux * ux + uy * uy;
+                    rowmin[q] = fminf(fminf(rowmin[q], dr.x), dr.y);
+                    colmin[q] = fminf(fminf(colmin[q], dq.x), dq.y);
+                }
+            }
+        }
+        float red[3] = {-INFINITY, -INFINITY, 0.f};
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            if (valid[q]) {
+                cnt[q] += (thr2 > 0.0f ? 0 : 1);
+                red[0] = fmaxf(red[0], rowmin[q]); red[1] = fmaxf(red[1], colmin[q]); red[2] += (float)cnt[q];
+            }
+        }
+        env_reduce<64, 64, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
+        const float H = sqrtf(fmaxf(red[0], red[1]));
+        const float ex = iv.x - mvx, ey = iv.y - mvy;
+        const float velterm = sqrtf(ex * ex + ey * ey);
+        const bool is_done = t_step >= a.p.world_length;
+        const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            if (valid[q]) {
+                const size_t o = ((size_t)k * a.B + b) * N + lane + 64 * q;
+                if (a.rew) a.rew[o] = shared;
+                if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt[q];
+                if (a.done) a.done[o] = is_done ? 1 : 0;
+            }
+        }
+        if (a.p.auto_reset && is_done && env_ok) {            // wave-uniform: the wave owns one env
+            float raw[2] = {0.f, 0.f};
+            float rawp[A][2];
+            float rx[A], ry[A];
+            uint32_t c0[A], c1[A];
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                uint32_t c[4] = {(uint32_t)b, (uint32_t)(lane + 64 * q), (uint32_t)(a.p.rng_offset + k),
+                                 (uint32_t)((a.p.rng_offset + k) >> 32)};
+                philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                c0[q] = c[0]; c1[q] = c[1];
+                rx[q] = valid[q] ? u_pm1(c[2]) : 0.f; ry[q] = valid[q] ? u_pm1(c[3]) : 0.f;
+                rawp[q][0] = rx[q]; rawp[q][1] = ry[q];
+            }
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                env_reduce<64, 64, 2, R_SUM, R_SUM, R_SUM, R_SUM>(rawp[q], nullptr);
+                if (q == 0) { raw[0] = rawp[0][0]; raw[1] = rawp[0][1]; } else { raw[0] += rawp[q][0]; raw[1] += rawp[q][1]; }
+            }
+            uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
+                              (uint32_t)((a.p.rng_offset + k) >> 32)};
+            philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+            iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+            t_step = 0;
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                if (valid[q]) {
+                    const int i = lane + 64 * q;
+                    const size_t o = (size_t)b * N + i;
+                    p[q] = make_float2(u_pm1(c0[q]), u_pm1(c1[q]));
+                    v[q] = make_float2(0.f, 0.f);
+                    s[q] = make_float2(__builtin_fmaf(-raw[0], invN, rx[q]), __builtin_fmaf(-raw[1], invN, ry[q]));
+                    SX[i] = s[q].x; SY[i] = s[q].y;
+                    reinterpret_cast<float2*>(a.shape)[o] = s[q];
+                }
+            }
+            if (lane == 0) reinterpret_cast<float2*>(a.ivel)[b] = iv;
+        }
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            if (valid[q]) {
+                const int i = lane + 64 * q;
+                T[i] = p[q]; T[3 * N + i] = v[q]; T[4 * N + i] = make_float2(-v[q].x, -v[q].y);
+                T[2 * N - 1 + i] = s[q];
+                QX[i] = p[q].x; QY[i] = p[q].y;
+            }
+        }
+        if (env_ok && lane == 0) T[3 * N - 1] = iv;
+    };
+
+    const bool per_step = a.K == 1;
+    const int total = per_step ? NG : a.K;
+    if (producer) { load_group(0); produce(0, 0); if (per_step) store_group(); }
+    __syncthreads();
+    for (int it = 0; it < total; ++it) {
+        if (producer) {
+            if (it + 1 < total) {
+                if (per_step) { load_group(it + 1); produce(0, (it + 1) & 1); store_group(); }
+                else produce(it + 1, (it + 1) & 1);
+            }
+        } else {
+            const int k = per_step ? 0 : it;
+            const int b0 = wg0 + (per_step ? it * E : 0);
+            const int El = min(E, a.B - b0);
+            int slot = k;
+            bool want_obs = a.obs != nullptr && El > 0;
+            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+            if (want_obs) {
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
+                                           roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                           reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
+            }
+        }
+        __syncthreads();
+    }
+    if (!per_step && producer) store_group();
+}
+
+}  // namespace fg
+
+#endif  // FG_ROLLOUT_KERNELS_HPP_

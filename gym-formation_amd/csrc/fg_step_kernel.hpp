@@ -1,0 +1,266 @@
+// fg_step_kernel.hpp - The fused single-launch step kernel (also the K-loop fallback and run-time N).
+// Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+#ifndef FG_STEP_KERNEL_HPP_
+#define FG_STEP_KERNEL_HPP_
+
+#include "fg_common.hpp"
+#include "fg_pair_loops.hpp"
+#include "fg_obs_writers.hpp"
+
+namespace fg {
+
+// ---------------------------------------------------------------------------
+// the fused step / rollout kernel
+//   NC  compile-time agent count (0 = run-time a.N)
+//   G   lanes reserved per environment for the per-agent phases (power of two >= N)
+//   T   threads per workgroup (>= E * G); ALL T threads stream observations
+//   E   environments per workgroup
+//   IDX also emit the landmark-index assignments
+// LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
+// ---------------------------------------------------------------------------
+#ifndef FG_WPS
+#define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
+#endif
+template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
+__global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) void step_kernel(const Args a) {
+    // OPTS: World options no reference scenario enables (accel, max_speed, u_noise, walls);
+    // compiled into a separate instantiation so that the common path keeps its registers.
+    constexpr bool FLAT = (WR == 1);
+    static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int N = NC ? NC : a.N;
+    const int tid = threadIdx.x;
+    const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
+    const int i = (E == 1) ? tid : tid % G;
+    const int b0 = blockIdx.x * E;
+    const int b = b0 + e;
+    const bool env_ok = (e < E) && (b < a.B);     // this thread's lane group owns a live env
+    const bool valid = env_ok && (i < N);
+    const int El = min(E, a.B - b0);
+
+    const int NP = npad(N);
+    float2* const A = env_tables(smem, e < E ? e : 0, N);
+    float2* const V = A + 3 * N;
+    float2* const NV = A + 4 * N;             // -velocity, read by the row writer
+    float* const QX = reinterpret_cast<float*>(A + 5 * N);
+    float* const QY = QX + NP;
+    float* const PX = QY + NP;
+    float* const PY = PX + NP;
+    float* const SX = PY + NP;
+    float* const SY = SX + NP;
+    float* const scratch = reinterpret_cast<float*>(env_tables(smem, E, N));
+    volatile int* const reset_flag = reinterpret_cast<volatile int*>(scratch) + 64;   // 2 ints after the 16x4 reduction partials
+
+    const float one_minus_damp = 1.0f - a.p.damping;
+    const float dt = a.p.dt;
+    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;   // force beyond: < 1e2 k e^-18 ~ 1.5e-9
+    const float cutoff2 = cutoff * cutoff;
+    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const float invN = 1.0f / (float)N;
+
+    // ---- phase 1: state -> registers + LDS --------------------------------
+    float2 p = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f), s = make_float2(0.f, 0.f);
+    int t_step = 0;
+    const size_t sidx = (size_t)b * N + i;
+    if (valid) {
+        p = make_float2(a.px[sidx], a.py[sidx]);
+        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+        QX[i] = p.x; QY[i] = p.y; PX[i] = p.x; PY[i] = p.y;
+        if (a.do_post) {
+            s = reinterpret_cast<const float2*>(a.shape)[sidx];
+            A[2 * N - 1 + i] = s;
+            SX[i] = s.x; SY[i] = s.y;
+            if (i < N - 1) A[N + i] = make_float2(0.f, 0.f);
+            if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
+        }
+    } else if (env_ok && i < NP) {              // sentinel partners of the packed pair loops
+        QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
+    }
+    if (env_ok && a.step) t_step = a.step[b];
+    if (tid < 2) reset_flag[tid] = 0;
+    __syncthreads();
+
+    for (int k = 0; k < a.K; ++k) {
+        int slot = k;
+        bool want_obs = a.do_post && a.obs != nullptr;
+        if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+        // ---- phase 2: World.step ------------------------------------------
+        if (a.do_phys) {
+            if (valid) {
+                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                                                a.p.dist_min, cutoff2);
+                if constexpr (OPTS) {
+                    const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
+                    f.x += fa.x; f.y += fa.y;
+                    if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
+                } else {
+                    f.x += a.p.mass * (a.p.sensitivity * u.x);
+                    f.y += a.p.mass * (a.p.sensitivity * u.y);
+                }
+                v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
+                v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
+                if constexpr (OPTS) v = clamp_speed(a.p, v);
+                p.x += v.x * dt;
+                p.y += v.y * dt;
+                A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+                PX[i] = p.x; PY[i] = p.y;
+            }
+            t_step += 1;
+            // The barrier that publishes the post-step tables also carries one bit per group:
+            // "some env of this workgroup finishes its episode in this step" (auto-reset only),
+            // so the common no-reset step pays no extra barrier later.
+            if (a.p.auto_reset && env_ok && i == 0 && t_step >= a.p.world_length) reset_flag[k & 1] = 1;
+            __syncthreads();
+        }
+
+        if (a.do_post) {
+            // ---- phase 3: reward -------------------------------------------
+            float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+            env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, scratch);
+            const float mx = sums[0] * invN, my = sums[1] * invN;
+            const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+            const float ptx = p.x - mx, pty = p.y - my;        // centred own position
+            const float tx = s.x + mx, ty = s.y + my;          // own ideal point, un-centred
+            float rowmin = INFINITY, colmin = INFINITY;
+            int cnt = 0, arg_lm = 0, arg_ag = 0;
+            if (valid)
+                reward_pass_packed<IDX>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
+                                        rowmin, colmin, cnt, arg_lm, arg_ag);
+            float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+            env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
+            const float H = sqrtf(fmaxf(red[0], red[1]));
+            const float2 iv = A[3 * N - 1];
+            const float ex = iv.x - mvx, ey = iv.y - mvy;
+            const float velterm = sqrtf(ex * ex + ey * ey);
+            const float indiv = (-H - velterm) - (float)cnt;
+            const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            const bool is_done = t_step >= a.p.world_length;
+            if (valid) {
+                const size_t o = ((size_t)k * a.B + b) * N + i;
+                if (a.rew) a.rew[o] = shared;
+                if (a.indiv) a.indiv[o] = indiv;
+                if (a.done) a.done[o] = is_done ? 1 : 0;
+            }
+            if (IDX) {
+                // scipy's witnesses: first maximiser of the row/col minima
+                float w[2] = {(valid && rowmin == red[0]) ? (float)i : 1e9f,
+                              (valid && colmin == red[1]) ? (float)i : 1e9f};
+                env_reduce<G, T, 2, R_MIN, R_MIN, R_MIN, R_MIN>(w, scratch);
+                if (valid) {
+                    if (a.near_lm) a.near_lm[sidx] = arg_lm;
+                    if (a.near_ag) a.near_ag[sidx] = arg_ag;
+                    if (a.hd_idx) {
+                        if (i == (int)w[0]) { a.hd_idx[b * 4 + 0] = i; a.hd_idx[b * 4 + 1] = arg_lm; }
+                        if (i == (int)w[1]) { a.hd_idx[b * 4 + 2] = i; a.hd_idx[b * 4 + 3] = arg_ag; }
+                    }
+                }
+            }
+
+            // ---- phase 4: vec-env auto reset --------------------------------
+            if (a.p.auto_reset && reset_flag[k & 1] != 0) {          // workgroup-uniform
+                if (tid == 0) reset_flag[(k + 1) & 1] = 0;
+                const bool mine = is_done && env_ok;
+                if (G > 64 ? mine : (__any(mine) != 0)) {
+                    uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
+                                     (uint32_t)((a.p.rng_offset + k) >> 32)};
+                    philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                    float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                    const float rx = raw[0], ry = raw[1];
+                    env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
+                    if (mine && valid) {
+                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_float2(0.f, 0.f);
+                        s = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
+                        A[i] = p; V[i] = v; NV[i] = v; A[2 * N - 1 + i] = s;
+                        PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
+                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
+                        if (i == 0) {
+                            uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
+                                              (uint32_t)((a.p.rng_offset + k) >> 32)};
+                            philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
+                            const float2 niv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                            A[3 * N - 1] = niv;
+                            reinterpret_cast<float2*>(a.ivel)[b] = niv;
+                        }
+                    }
+                    if (mine) t_step = 0;
+                }
+                __syncthreads();
+            }
+
+            // ---- phase 5: observations --------------------------------------
+            if (want_obs && NC > 0 && !FLAT) {
+                if constexpr (NC > 0 && WR == 0)
+                    write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
+                                                  reinterpret_cast<float2*>(a.obs) +
+                                                  ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El, 3);
+                if constexpr (NC > 0 && WR >= 2) {
+                    const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                    float2* tiles = env_tables(smem, E, N) + 36;            // after env blocks + 72 floats of scratch
+                    write_obs_tiled<NC, T / 64, E, WR - 2 + 1>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6, tiles,
+                                                               reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+                }
+            } else if (want_obs) {
+                const unsigned n3 = 3u * N;                // (x,y) units per row
+                const unsigned nenv = n3 * N;              // units per env = N rows
+                const size_t U0 = ((size_t)slot * a.B + b0) * nenv;
+                const unsigned total = (unsigned)El * nenv;
+                const unsigned head = (unsigned)(U0 & 1);  // region start not 16-byte aligned
+                float2* const out2 = reinterpret_cast<float2*>(a.obs) + U0;
+                // unit (rp, u): rp = e*N + row is the row index inside the group, u the unit in
+                // the row.  Branch-free so that the LDS reads of several units overlap.
+                auto unit = [&](unsigned rp, unsigned u) -> float2 {
+                    const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
+                    const unsigned row = rp - ee * N;
+                    const float2* AA = env_tables(smem, (int)ee, N);
+                    const unsigned j = u - 1u;
+                    const bool is_delta = j < (unsigned)(N - 1);
+                    unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
+                    idx = (u == 0u) ? n3 + row : idx;
+                    float2 val = AA[idx];
+                    const float2 pi = AA[row];
+                    val.x -= is_delta ? pi.x : 0.0f;
+                    val.y -= is_delta ? pi.y : 0.0f;
+                    return val;
+                };
+                if (head && tid == 0) out2[0] = unit(0u, 0u);
+                const unsigned npair = (total - head) >> 1;
+                f32x4* const out4 = reinterpret_cast<f32x4*>(out2 + head);
+                const unsigned du = (2u * T) % n3, drow = (2u * T) / n3;
+                unsigned q = head + 2u * tid;
+                unsigned rp = q / n3;
+                unsigned u = q - rp * n3;
+#pragma unroll 2
+                for (unsigned q2 = tid; q2 < npair; q2 += T) {
+                    unsigned u1 = u + 1u, rp1 = rp;
+                    if (u1 == n3) { u1 = 0u; rp1 += 1u; }
+                    const float2 x0 = unit(rp, u), x1 = unit(rp1, u1);
+                    const f32x4 w = {x0.x, x0.y, x1.x, x1.y};
+                    out4[q2] = w;
+                    u += du; rp += drow;
+                    if (u >= n3) { u -= n3; rp += 1u; }
+                }
+                if (((total - head) & 1u) && tid == T - 1)
+                    out2[total - 1] = unit((total - 1) / n3, (total - 1) % n3);
+            }
+        }
+
+        if (k + 1 < a.K) {
+            __syncthreads();            // obs phase done reading A/V before the next step writes them
+            if (valid) { QX[i] = p.x; QY[i] = p.y; }
+            __syncthreads();
+        }
+    }
+
+    // ---- state write-back ---------------------------------------------------
+    if (valid && (a.do_phys || a.p.auto_reset)) {
+        a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
+    }
+    if (a.do_phys && a.step && env_ok && i == 0) a.step[b] = t_step;
+}
+
+}  // namespace fg
+
+#endif  // FG_STEP_KERNEL_HPP_

@@ -131,6 +131,6 @@ def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "gym-formation_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".sh")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".sh")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, "%s mentions the oracle" % f
