@@ -538,7 +538,8 @@ def test_rollout_with_auto_reset_equals_single_steps(N, B, K):
     assert torch.equal(a.scenario.ideal_vel, b.scenario.ideal_vel)
 
 
-@pytest.mark.parametrize("N,B", [(5, 33), (8, 17), (17, 9), (32, 5), (33, 6), (64, 3), (65, 4), (128, 2), (200, 2), (300, 1)])
+@pytest.mark.parametrize("N,B", [(5, 33), (8, 17), (17, 9), (32, 5), (33, 6), (64, 3), (65, 4), (128, 2), (200, 2), (300, 1),
+                                 (513, 1), (1024, 1)])
 def test_generic_agent_counts_against_oracle(N, B):
     """Run-time-N kernels (every lane-group width and workgroup size), crowded so that contacts
     and collision counts occur, with the landmark-index outputs switched on."""
