@@ -85,12 +85,22 @@ def cpu_baseline(n_agents, budget_s=12.0):
     with ctx.Pool(cores) as pool:
         elapsed = pool.map(_cpu_port_worker, [(n_agents, steps, 1 + 1000 * r) for r in range(cores)])
     wall = max(elapsed)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
         "value": round(cores * steps / wall, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": "%d envs x %d steps of formation_hd_env N=%d, one env per process "
                   "(oracle.PortEnv, numpy/scipy, fp64), wall = slowest worker %.1fs; "
                   "pool start-up excluded (%.1fs total)" % (cores, steps, n_agents, wall, time.perf_counter() - t0),
         "agent_steps_per_s": round(cores * steps * n_agents / wall, 1),
+        "cpu_model": model,
+        # the reference's files never travel to the GPU box; this port was timed against the REAL
+        # reference in the build container (8 vCPU Xeon 2.1 GHz, one env per process):
+        "calibration": "port / reference env-steps/s on the same 8 cores: 325 / 321 at N=27, 1130 / 1298 at N=9",
     }
 
 
