@@ -24,8 +24,10 @@ namespace fg {
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
 
-template <int NC, int G, int TP, int TW, int E, int WR>
+template <int NC, int G, int TP, int TW, int E, int WR, bool SHARE = false>
 __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
+    // SHARE: all waves pull observation tiles from an LDS counter (producers join once their
+    // step is produced); needs WR >= 2 (LDS tiles).
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -140,13 +142,36 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
         }
     };
 
+    // SHARE layout after the env blocks: int ctr[2] (16 bytes), then tiles: 2 per writer wave, 1 per producer wave
+    int* const tile_ctr = reinterpret_cast<int*>(smemf + E * roll_block_floats(N));
+    float2* const tile_base = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N) + 4);
+    if (SHARE && tid == 0) { tile_ctr[0] = 0; tile_ctr[1] = 0; }
     if (producer) produce(0);
 #if FG_WRITER_PRIO
     else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
 #endif
     __syncthreads();
     for (int k = 0; k < a.K; ++k) {
-        if (producer) {
+        if constexpr (SHARE) {
+            if (tid == 0) tile_ctr[(k + 1) & 1] = 0;          // last used in step k-1, which the barrier closed
+            int slot = k;
+            bool want_obs = a.obs != nullptr;
+            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+            if (producer && k + 1 < a.K) produce(k + 1);
+            if (want_obs) {
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
+                constexpr int TUNITS = tile_units<NC, WR - 1>();
+                if (producer)
+                    write_obs_tiled_shared<NC, E, WR - 1, 1>(tables0, roll_block_floats(N) / 2,
+                        tile_base + (NWW * 2 + (tid >> 6)) * TUNITS, &tile_ctr[k & 1],
+                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+                else
+                    write_obs_tiled_shared<NC, E, WR - 1, 2>(tables0, roll_block_floats(N) / 2,
+                        tile_base + ((tid - TP) >> 6) * 2 * TUNITS, &tile_ctr[k & 1],
+                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+            }
+        } else if (producer) {
             if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1);      // probe 1/2: writers only
         } else {
             int slot = k;

@@ -308,8 +308,28 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
         if (N == 27) {
             int re = 16;                   // 16 envs per workgroup: 8 producer + 4 writer waves, one workgroup per CU
             if (const char* e = getenv("FG_ROLLE")) re = atoi(e);
+            int share = 0;                 // tuning: producers join the observation stream through an LDS tile counter
+            if (const char* e = getenv("FG_SHARE")) share = atoi(e);
             if (re == 2) { if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 10) else FG_ROLL(27, 32, 64, 128, 2, 10) }
                            else { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 0) else FG_ROLL(27, 32, 64, 128, 2, 0) } }
+            else if (re == 16 && share) {
+                const int grid = (B + 15) / 16;
+                const int tunits = (3 * 27 * 9 + 3) & ~1;
+                const int lds = 16 * roll_block_floats(27) * (int)sizeof(float) + 16 +
+                                ((tw / 64) * 2 + 8) * tunits * (int)sizeof(float2);
+                static bool raised = false;
+                if (tw == 256) {
+                    if (!raised) { (void)hipFuncSetAttribute((const void*)&rollout_kernel<27, 32, 512, 256, 16, 10, true>,
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = true; }
+                    hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 256, 16, 10, true>), dim3(grid), dim3(768), lds, st, a);
+                } else {
+                    static bool raised2 = false;
+                    if (!raised2) { (void)hipFuncSetAttribute((const void*)&rollout_kernel<27, 32, 512, 128, 16, 10, true>,
+                                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised2 = true; }
+                    hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 128, 16, 10, true>), dim3(grid), dim3(640), lds, st, a);
+                }
+                err = hipGetLastError();
+            }
             else if (re == 16) { if (wr == 10) { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 10) else FG_ROLL(27, 32, 512, 512, 16, 10) }
                                  else { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 0) else FG_ROLL(27, 32, 512, 512, 16, 0) } }
             else if (re == 8 && tw == 512) { if (wr == 10) FG_ROLL(27, 32, 256, 512, 8, 10) else FG_ROLL(27, 32, 256, 512, 8, 0) }
