@@ -293,6 +293,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     const char* nopipe = getenv("FG_NOPIPE");
     if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
     if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
+        if (const char* e = getenv("FG_STRIDED")) a.strided = atoi(e);
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
         if (const char* e = getenv("FG_TW")) tw = atoi(e);
         hipStream_t st = (hipStream_t)stream;
