@@ -662,3 +662,37 @@ def test_vec_env_device_mt_matches_host_reset_mode():
         assert torch.equal(outs[0][1], outs[1][1])            # pre-reset reward
         assert torch.equal(outs[0][2], outs[1][2])            # pre-reset done
         assert torch.equal(envs[0][0].world.step_count, envs[1][0].world.step_count)
+
+
+def test_episode_statistics_match_oracle_over_100_steps():
+    """Chaotic fp32 trajectories cannot match fp64 pointwise over an episode, but nothing may
+    drift systematically: over 1024 envs x 100 steps the per-step batch means of reward, speed
+    and collision penalty of the GPU rollout agree with the fp64 oracle to 1e-3 relative."""
+    N, B, T = 27, 1024, 100
+    st = O.reset_hd(1 + 1000 * np.arange(B), N)
+    st["pos"] *= 0.5                                      # denser than the default: contacts matter
+    acts = np.random.RandomState(0).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
+    env = _make(N, B)
+    _load(env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    out = dict(obs=None, reward=torch.empty((T, B, N), device="cuda"), indiv=torch.empty((T, B, N), device="cuda"),
+               done=torch.zeros((T, B, N), dtype=torch.uint8, device="cuda"))
+    out = {k: v for k, v in out.items() if v is not None}
+    act_dev = torch.as_tensor(acts).cuda()
+    gpu_speed = []
+    for t0 in range(0, T, 20):
+        chunk = {k: v[t0:t0 + 20] for k, v in out.items()}
+        env.scenario.rollout_batch(env.world, act_dev[t0:t0 + 20], chunk)
+        gpu_speed.append(float(torch.stack(env.world.get_state()[1:]).norm(dim=-1).mean()))
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    s = dict(st, pos=f32(st["pos"]), ideal_shape=f32(st["ideal_shape"]), ideal_vel=f32(st["ideal_vel"]))
+    ref_rew, ref_pen, ref_speed = [], [], []
+    for t in range(T):
+        s, o = O.step_hd(s, acts[t].astype(np.float64))
+        ref_rew.append(o["shared"].mean()); ref_pen.append(o["cnt"].mean())
+        if (t + 1) % 20 == 0:
+            ref_speed.append(np.sqrt((s["vel"] ** 2).sum(-1)).mean())
+    gpu_rew = out["reward"][:, :, 0].double().mean(1).cpu().numpy()
+    np.testing.assert_allclose(gpu_rew, np.array(ref_rew), rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(np.array(gpu_speed), np.array(ref_speed), rtol=1e-3)
+    assert out["done"][-1].all() and not out["done"][-2].any()        # done flips exactly at step 100
+    assert np.mean(ref_pen) > 0.01                                    # collisions did occur
