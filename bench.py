@@ -146,7 +146,6 @@ def main():
 
     import formation_gym
     from formation_gym import _native
-    from oracle import formation_oracle as O      # cpu_baseline + initial-state generator only
 
     N, B = a.agents, a.envs
     env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
@@ -154,10 +153,9 @@ def main():
     # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
     from formation_gym import sharding
     lo, hi = sharding.env_slice(B * world_size, rank, world_size)
-    st = O.reset_hd(sharding.global_seeds(1, lo, hi), N)
-    env.world.set_state(st["pos"], st["vel"])
-    env.scenario.set_formation(env.world, st["ideal_shape"], st["ideal_vel"])
-    env.scenario._seed = 1 + rank
+    env.seed(int(sharding.global_seeds(1, lo, hi)[0]))      # env b of this rank: 1 + 1000 (lo + b)
+    env.reset()
+    env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
     env.world.step_count.zero_()
 
     N, B = a.agents, a.envs
@@ -201,8 +199,9 @@ def main():
         ev0.record()
         fn(steps, warmup)
         ev1.record()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0                        # this rank's K steps, start barrier -> local completion
         barrier()
-        wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)
         wall = sharding.max_over_ranks(wall, red_dev)          # slowest rank
         dev_ms = sharding.max_over_ranks(dev_ms, red_dev)
