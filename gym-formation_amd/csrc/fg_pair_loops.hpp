@@ -11,6 +11,10 @@ namespace fg {
 // pair loops, two partner agents per iteration with packed fp32 math (v_pk_*_f32)
 // ---------------------------------------------------------------------------
 // World.step contact force on agent i (core.py:289-322): sum over j != i on PRE-step positions.
+// NPC: the padded partner count when it is a small compile-time constant (<= 16), else 0.  With
+// NPC every partner is fetched from LDS up front (one round trip instead of one per iteration:
+// at small N the producer chain is latency-bound); the arithmetic and its order are the same.
+template <int NPC = 0>
 FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __restrict__ QY, int NP,
                                    int i, float2 p, float cf, float kmargin, float dmin, float cutoff2) {
     float fx = 0.0f, fy = 0.0f;
@@ -28,10 +32,7 @@ FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __
         fx += dx * c;
         fy += dy * c;
     };
-#pragma unroll 2
-    for (int j = 0; j < NP; j += 2) {
-        const f32x2 qx = *reinterpret_cast<const f32x2*>(QX + j);
-        const f32x2 qy = *reinterpret_cast<const f32x2*>(QY + j);
+    auto pair = [&](int j, f32x2 qx, f32x2 qy) {
         const f32x2 dx = px - qx, dy = py - qy;
         const f32x2 d2 = dx * dx + dy * dy;
         // beyond the cutoff the softplus penetration is below fp32 resolution of the force: skipped
@@ -41,13 +42,27 @@ FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __
             if (n0) add(dx.x, dy.x, d2.x);
             if (n1) add(dx.y, dy.y, d2.y);
         }
+    };
+    if constexpr (NPC > 0 && NPC <= 16) {
+        f32x2 qx[NPC / 2], qy[NPC / 2];
+#pragma unroll
+        for (int h = 0; h < NPC / 2; ++h) {
+            qx[h] = *reinterpret_cast<const f32x2*>(QX + 2 * h);
+            qy[h] = *reinterpret_cast<const f32x2*>(QY + 2 * h);
+        }
+#pragma unroll
+        for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h]);
+    } else {
+#pragma unroll 2
+        for (int j = 0; j < NP; j += 2)
+            pair(j, *reinterpret_cast<const f32x2*>(QX + j), *reinterpret_cast<const f32x2*>(QY + j));
     }
     return make_float2(fx, fy);
 }
 
 // Scenario.reward inner pass for agent i / ideal point i (formation_hd_env.py:61-75):
 //   rowmin = min_j |p~_i - s_j|^2,  colmin = min_j |p~_j - s_i|^2,  cnt = #{j != i : |p_j - p_i| < thr}
-template <bool IDX>
+template <bool IDX, int NPC = 0>
 FG_DEV void reward_pass_packed(const float* __restrict__ PX, const float* __restrict__ PY,
                                const float* __restrict__ SX, const float* __restrict__ SY, int NP,
                                float2 p, float ptx, float pty, float tx, float ty, float thr2,
@@ -55,12 +70,7 @@ FG_DEV void reward_pass_packed(const float* __restrict__ PX, const float* __rest
     const f32x2 px = {p.x, p.x}, py = {p.y, p.y};
     const f32x2 ptx2 = {ptx, ptx}, pty2 = {pty, pty}, tx2 = {tx, tx}, ty2 = {ty, ty};
     int c = -1;                                    // the self pair (distance 0) is counted below
-#pragma unroll 2
-    for (int j = 0; j < NP; j += 2) {
-        const f32x2 qx = *reinterpret_cast<const f32x2*>(PX + j);
-        const f32x2 qy = *reinterpret_cast<const f32x2*>(PY + j);
-        const f32x2 sx = *reinterpret_cast<const f32x2*>(SX + j);
-        const f32x2 sy = *reinterpret_cast<const f32x2*>(SY + j);
+    auto pair = [&](int j, f32x2 qx, f32x2 qy, f32x2 sx, f32x2 sy) {
         const f32x2 cx = qx - px, cy = qy - py;
         const f32x2 dc = cx * cx + cy * cy;
         c += (dc.x < thr2 ? 1 : 0) + (dc.y < thr2 ? 1 : 0);
@@ -77,6 +87,23 @@ FG_DEV void reward_pass_packed(const float* __restrict__ PX, const float* __rest
             rowmin = fminf(fminf(rowmin, dr.x), dr.y);
             colmin = fminf(fminf(colmin, dq.x), dq.y);
         }
+    };
+    if constexpr (NPC > 0 && NPC <= 16) {
+        f32x2 qx[NPC / 2], qy[NPC / 2], sx[NPC / 2], sy[NPC / 2];
+#pragma unroll
+        for (int h = 0; h < NPC / 2; ++h) {
+            qx[h] = *reinterpret_cast<const f32x2*>(PX + 2 * h);
+            qy[h] = *reinterpret_cast<const f32x2*>(PY + 2 * h);
+            sx[h] = *reinterpret_cast<const f32x2*>(SX + 2 * h);
+            sy[h] = *reinterpret_cast<const f32x2*>(SY + 2 * h);
+        }
+#pragma unroll
+        for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h], sx[h], sy[h]);
+    } else {
+#pragma unroll 2
+        for (int j = 0; j < NP; j += 2)
+            pair(j, *reinterpret_cast<const f32x2*>(PX + j), *reinterpret_cast<const f32x2*>(PY + j),
+                 *reinterpret_cast<const f32x2*>(SX + j), *reinterpret_cast<const f32x2*>(SY + j));
     }
     cnt = c + (thr2 > 0.0f ? 0 : 1);               // thr == 0: not even the self pair was counted
 }

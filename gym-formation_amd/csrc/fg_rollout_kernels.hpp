@@ -30,6 +30,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     // step is produced); needs WR >= 2 (LDS tiles).
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
+    constexpr int NPS = NP <= 16 ? NP : 0;              // small N: partners fetched up front (fg_pair_loops.hpp)
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float* const smemf = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x;
@@ -73,16 +74,28 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     }
     if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
 
-    // one producer step: World.step + reward of step k into table buffer (k & 1)
-    auto produce = [&](int k) {
+    // Actions are fetched one step ahead (small N leaves too little work between the load and its
+    // use to cover an HBM round trip inside one step).  Two registers alternate roles over a loop
+    // unrolled by two, so that no copy (and with it the load's wait) lands inside the issuing step.
+    float2 u_even = make_float2(0.f, 0.f), u_odd = u_even;
+    if (valid) u_even = reinterpret_cast<const float2*>(a.act)[sidx];
+    const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
+    const float2* act_next = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0) + (a.K > 1 ? act_stride : 0);
+
+    // one producer step: World.step + reward of step k into table buffer (k & 1);
+    // u_cur = action of step k (loaded during step k-1), u_nxt receives the action of step k+1
+    auto produce = [&](int k, const float2& u_cur, float2& u_nxt) {
         float2* const A = TB0 + (k & 1) * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (valid) {
-            const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
-            float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
-                                            a.p.dist_min, cutoff2);
-            f.x += a.p.mass * (a.p.sensitivity * u.x);
-            f.y += a.p.mass * (a.p.sensitivity * u.y);
+            // always issued (clamped to the last step): with a known number of younger loads the
+            // wait for u_cur can leave this prefetch in flight
+            u_nxt = *act_next;
+            act_next += (k + 2 < a.K) ? act_stride : 0;
+            float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                                                 a.p.dist_min, cutoff2);
+            f.x += a.p.mass * (a.p.sensitivity * u_cur.x);
+            f.y += a.p.mass * (a.p.sensitivity * u_cur.y);
             v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
             v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
             p.x += v.x * dt;
@@ -99,8 +112,8 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
         float rowmin = INFINITY, colmin = INFINITY;
         int cnt = 0, arg_lm = 0, arg_ag = 0;
         if (valid)
-            reward_pass_packed<false>(PX, PY, SX, SY, NP, p, p.x - mx, p.y - my, s.x + mx, s.y + my, thr2,
-                                      rowmin, colmin, cnt, arg_lm, arg_ag);
+            reward_pass_packed<false, NPS>(PX, PY, SX, SY, NP, p, p.x - mx, p.y - my, s.x + mx, s.y + my, thr2,
+                                           rowmin, colmin, cnt, arg_lm, arg_ag);
         float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
         env_reduce<G, G, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
         const float H = sqrtf(fmaxf(red[0], red[1]));
@@ -151,18 +164,22 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     int* const tile_ctr = reinterpret_cast<int*>(smemf + E * roll_block_floats(N));
     float2* const tile_base = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N) + 4);
     if (SHARE && tid == 0) { tile_ctr[0] = 0; tile_ctr[1] = 0; }
-    if (producer) produce(0);
+    if (producer) produce(0, u_even, u_odd);
 #if FG_WRITER_PRIO
     else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
 #endif
+    // every prologue load has landed before the loop: inside it the only loads in flight are the
+    // action prefetches, and no leftover prologue dependency makes the compiler drain them early
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
-    for (int k = 0; k < a.K; ++k) {
+    // hand-over step k: producers run step k+1 (consuming u_cur) while writers stream step k
+    auto pipeline_step = [&](int k, const float2& u_cur, float2& u_nxt) {
         if constexpr (SHARE) {
             if (tid == 0) tile_ctr[(k + 1) & 1] = 0;          // last used in step k-1, which the barrier closed
             int slot = k;
             bool want_obs = a.obs != nullptr;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
-            if (producer && k + 1 < a.K) produce(k + 1);
+            if (producer && k + 1 < a.K) produce(k + 1, u_cur, u_nxt);
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
                 const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
@@ -177,7 +194,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                         reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
             }
         } else if (producer) {
-            if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1);      // probe 1/2: writers only
+            if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1, u_cur, u_nxt);      // probe 1/2: writers only
         } else {
             int slot = k;
             bool want_obs = a.obs != nullptr;
@@ -195,6 +212,10 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
             }
         }
         if (!(FG_PROBES && a.probe == 2)) __syncthreads();                    // probe 2: no hand-over sync
+    };
+    for (int k = 0; k < a.K; k += 2) {
+        pipeline_step(k, u_odd, u_even);
+        if (k + 1 < a.K) pipeline_step(k + 1, u_even, u_odd);
     }
     if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
     if (a.step && env_ok && i == 0) a.step[b] = t_step;

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
     const int El = min(E, a.B - b0);
 
     const int NP = npad(N);
+    constexpr int NPS = (NC > 0 && npad(NC > 0 ? NC : 1) <= 16) ? npad(NC > 0 ? NC : 1) : 0;   // small N: partners fetched up front
     float2* const A = env_tables(smem, e < E ? e : 0, N);
     float2* const V = A + 3 * N;
     float2* const NV = A + 4 * N;             // -velocity, read by the row writer
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
         if (a.do_phys) {
             if (valid) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
-                float2 f = contact_force_packed(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
                     const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
             float rowmin = INFINITY, colmin = INFINITY;
             int cnt = 0, arg_lm = 0, arg_ag = 0;
             if (valid)
-                reward_pass_packed<IDX>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
+                reward_pass_packed<IDX, NPS>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
                                         rowmin, colmin, cnt, arg_lm, arg_ag);
             float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);

@@ -81,7 +81,7 @@ static const Variant kVariants[] = {
     FG_VARIANT_W(27, 32, 256, 4, 4), FG_VARIANT_W(27, 32, 128, 4, 4), FG_VARIANT_W(27, 32, 128, 2, 4), FG_VARIANT_W(27, 32, 64, 2, 4),
     FG_VARIANT_W(27, 32, 256, 4, 10), FG_VARIANT_W(27, 32, 128, 4, 10), FG_VARIANT_W(27, 32, 128, 2, 10), FG_VARIANT_W(27, 32, 64, 2, 10),
     FG_VARIANT_W(27, 32, 256, 2, 10), FG_VARIANT_W(27, 32, 256, 2, 4),
-    FG_VARIANT_W(9, 16, 128, 4, 10), FG_VARIANT_W(9, 16, 64, 4, 10),
+    FG_VARIANT_W(9, 16, 128, 4, 10), FG_VARIANT_W(9, 16, 64, 4, 10), FG_VARIANT_W(9, 16, 128, 8, 10), FG_VARIANT_W(9, 16, 256, 16, 10),
     FG_VARIANT_O(0, 4, 64, 16, 1), FG_VARIANT_O(0, 8, 64, 8, 1), FG_VARIANT_O(0, 16, 64, 4, 1), FG_VARIANT_O(0, 32, 128, 4, 1),
     FG_VARIANT_O(0, 64, 128, 2, 1), FG_VARIANT_O(0, 128, 128, 1, 1), FG_VARIANT_O(0, 256, 256, 1, 1),
     FG_VARIANT_O(0, 512, 512, 1, 1), FG_VARIANT_O(0, 1024, 1024, 1, 1),
@@ -98,6 +98,7 @@ static const Variant* variant_for(int N, int B = 0, bool need_opts = false) {
     // streams best with 8 envs per workgroup; a single-generation batch (27 x 4096 = 4 workgroups
     // per CU) is latency-bound and prefers one env per wave with spare writer waves.
     if (N == 27 && B >= 32768) { want_t = 256; want_e = 8; }
+    if (N == 9 && B >= 16384) { want_t = 128; want_e = 8; }
     if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
     if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
     const Variant* dflt = nullptr;
@@ -340,7 +341,19 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
             if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 10) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 10) else FG_ROLL(27, 32, 128, 128, 4, 10) }
             else { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 0) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 0) else FG_ROLL(27, 32, 128, 128, 4, 0) }
         }
-        else if (N == 9) FG_ROLL(9, 16, 64, 64, 4, 0)
+        else if (N == 9) {
+            // MI355X sweep (profiles/README.md): a batch of <= 4096 envs is bound by the producers'
+            // dependent chain (1.8 us/step) and wants many small workgroups; larger batches are
+            // store-bound and want 16-env workgroups (whole 128-byte lines per workgroup) with the
+            // LDS-tiled writer.  FG_ROLL9 overrides (tuning aid).
+            int v9 = B >= 8192 ? 4 : B > 4096 ? 6 : 5;
+            if (const char* e = getenv("FG_ROLL9")) v9 = atoi(e);
+            if (v9 == 1) FG_ROLL(9, 16, 64, 64, 4, 10)
+            else if (v9 == 4) FG_ROLL(9, 16, 256, 256, 16, 10)
+            else if (v9 == 6) FG_ROLL(9, 16, 128, 128, 8, 10)
+            else if (v9 == 0) FG_ROLL(9, 16, 64, 64, 4, 0)
+            else FG_ROLL(9, 16, 64, 128, 4, 0)
+        }
         else FG_ROLL(3, 4, 64, 64, 16, 0)
 #undef FG_ROLL
         if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
