@@ -144,6 +144,16 @@ def current_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def current_stream_fast(device):
+    """Raw handle of torch's current stream on `device` without building a Stream object
+    (the per-step API path calls this on every step)."""
+    import torch
+    try:
+        return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+    except AttributeError:                # private helper missing in this torch build
+        return torch.cuda.current_stream(device).cuda_stream
+
+
 def kernel_config(n):
     t, e, l = _I(), _I(), _I()
     check(load().fg_kernel_config(int(n), ctypes.byref(t), ctypes.byref(e), ctypes.byref(l)))

@@ -286,6 +286,13 @@ class World(object):
                                         width=float(w.width), reserved=0)
         return p
 
+    def params_signature(self):
+        """Cheap tuple of everything `native_params` reads from the world and from agent 0:
+        callers that cache an FgParams re-derive it when this changes."""
+        a0 = self.agents[0]
+        return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
+                len(self.agents), len(self.walls), a0.size, a0.initial_mass, a0.accel, a0.max_speed, a0.u_noise)
+
     def step(self, sensitivity=5.0):
         """World.step (core.py:206-225) for all envs: action force, all-pairs
         contact force, integration - one HIP launch.  `action_u` holds the RAW

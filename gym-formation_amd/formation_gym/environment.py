@@ -22,7 +22,7 @@ N observation / 2N reward / N done callbacks of environment.py:113-142.
 import numpy as np
 import torch
 
-from . import spaces
+from . import _native, spaces
 
 cam_range = 2
 
@@ -87,6 +87,7 @@ class MultiAgentEnv(object):
             done=torch.zeros((B, N), dtype=torch.uint8, device=dev),
         )
         self._act = torch.zeros((B, N, 2), **f)
+        self._launchers = {}              # pre-bound step launches, see _bound_step
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -98,6 +99,7 @@ class MultiAgentEnv(object):
     def enable_assignments(self, on=True):
         """Also emit the landmark-index assignments (nearest ideal point per
         agent, nearest agent per ideal point, Hausdorff witness pairs) each step."""
+        self._launchers.clear()           # bound launches hold the old output pointers
         B, N = self.num_envs, self.num_agents
         dev = self.world.device
         if on:
@@ -124,14 +126,36 @@ class MultiAgentEnv(object):
         else:
             act = self._stage_reference_actions(action_n)
         self._rng_offset += 1
-        self.scenario.step_batch(self.world, act, self._out, auto_reset=self.auto_reset,
-                                 rng_offset=self._rng_offset)
+        if not self._bound_step(act):
+            self.scenario.step_batch(self.world, act, self._out, auto_reset=self.auto_reset,
+                                     rng_offset=self._rng_offset)
         self.world.world_step += 1
         if self.post_step_callback is not None:
             self.post_step_callback(self.world)
         if batched:
             return self._batched_result()
         return self._reference_result()
+
+    def _bound_step(self, act):
+        """Per-step host work kept to one ctypes call: the scenario resolves every pointer and the
+        FgParams struct once (`bind_step`), keyed by everything the binding depends on - action
+        buffer, output buffers, stream, auto-reset flag and the world's physics constants - so a
+        change of any of them simply binds again.  Scenarios without `bind_step` take the generic
+        path.  Per-agent attributes other than agent 0's are validated when a binding is made
+        (and at every reset), not on every step."""
+        bind = getattr(self.scenario, "bind_step", None)
+        if bind is None:
+            return False
+        key = (act.data_ptr(), self.auto_reset, _native.current_stream_fast(self.world.device),
+               self.world.params_signature(), getattr(self.scenario, "_seed", 0))
+        launch = self._launchers.get(key)
+        if launch is None:
+            if len(self._launchers) >= 64:
+                self._launchers.clear()
+            launch = self._launchers[key] = bind(self.world, act, self._out, auto_reset=self.auto_reset)
+        launch(self._rng_offset)
+        self.scenario._cache = self._out
+        return True
 
     def _stage_reference_actions(self, action_n):
         """environment.py:121-122,187-236 for the continuous path, B == 1."""
@@ -156,7 +180,7 @@ class MultiAgentEnv(object):
         rew = o["reward"].unsqueeze(-1)
         if not self.shared_reward:
             rew = o["indiv"].unsqueeze(-1)
-        return o["obs"], rew, o["done"].bool(), {"individual_reward": o["indiv"]}
+        return o["obs"], rew, o["done"].view(torch.bool), {"individual_reward": o["indiv"]}   # 0/1 bytes: a view, no kernel
 
     def _reference_result(self):
         o = self._out

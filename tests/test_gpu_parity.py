@@ -696,3 +696,50 @@ def test_episode_statistics_match_oracle_over_100_steps():
     np.testing.assert_allclose(np.array(gpu_speed), np.array(ref_speed), rtol=1e-3)
     assert out["done"][-1].all() and not out["done"][-2].any()        # done flips exactly at step 100
     assert np.mean(ref_pen) > 0.01                                    # collisions did occur
+
+
+def test_env_step_rebinds_when_inputs_or_world_constants_change():
+    """env.step caches a pre-bound launch (pointers + FgParams).  A different action tensor, a changed
+    World constant, enable_assignments and a non-default stream must each take effect on the next step."""
+    N, B = 9, 33
+    st = O.reset_hd(1 + 1000 * np.arange(B), N)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    rs = np.random.RandomState(3)
+    acts = [rs.uniform(-1, 1, (B, N, 2)).astype(np.float32) for _ in range(4)]
+    env = _make(N, B)
+    _load(env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+    cur = dict(st, pos=f32(st["pos"]), ideal_shape=f32(st["ideal_shape"]), ideal_vel=f32(st["ideal_vel"]))
+
+    def check(act, **world_options):
+        nonlocal cur
+        obs, rew, done, info = env.step(act)
+        cur, out = O.step_hd(cur, _np(act), **world_options)
+        pos, vel = (_np(x) for x in env.world.get_state())
+        np.testing.assert_allclose(pos, cur["pos"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs), out["obs"], rtol=0, atol=2 * ATOL)
+        cur = dict(cur, pos=pos, vel=vel)                 # teacher-force the oracle with the fp32 state
+        return out
+
+    a0, a1 = torch.as_tensor(acts[0]).cuda(), torch.as_tensor(acts[1]).cuda()
+    check(a0)
+    check(a0)                                             # same binding again
+    assert len(env._launchers) == 1
+    check(a1)                                             # another action buffer: second binding
+    assert len(env._launchers) == 2
+    a0.copy_(torch.as_tensor(acts[2]))                    # new contents in a bound buffer
+    check(a0)
+    for a in env.world.agents:                            # a World option switches kernels and constants
+        a.max_speed = 0.3
+    check(a1, max_speed=0.3)
+    assert len(env._launchers) == 3
+    env.enable_assignments(True)                          # new output buffers
+    out = check(a1, max_speed=0.3)
+    _check_indices(env._out["near_lm"].cpu().numpy(), out["near_lm"], out["gap_lm"], "near_lm")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # launch follows torch's current stream
+        a3 = torch.as_tensor(acts[3]).cuda()
+        n_before = len(env._launchers)
+        check(a3, max_speed=0.3)
+        assert len(env._launchers) == n_before + 1
+    torch.cuda.current_stream().wait_stream(side)
