@@ -291,7 +291,9 @@ class World(object):
         callers that cache an FgParams re-derive it when this changes."""
         a0 = self.agents[0]
         return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
-                len(self.agents), len(self.walls), a0.size, a0.initial_mass, a0.accel, a0.max_speed, a0.u_noise)
+                len(self.agents), a0.size, a0.initial_mass, a0.accel, a0.max_speed, a0.u_noise,
+                tuple((w.orient, float(w.axis_pos), float(w.endpoints[0]), float(w.endpoints[1]), float(w.width), w.hard)
+                      for w in self.walls))
 
     def step(self, sensitivity=5.0):
         """World.step (core.py:206-225) for all envs: action force, all-pairs

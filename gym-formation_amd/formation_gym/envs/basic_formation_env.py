@@ -86,6 +86,29 @@ class Scenario(BaseScenario):
             _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream()))
         self._cache = out
 
+    def bind_step(self, world, act, out, auto_reset=False):
+        """Resolve FgParams and every pointer once; returns `launch(rng_offset)` (one ctypes call
+        per step, see MultiAgentEnv._bound_step)."""
+        if auto_reset:
+            raise NotImplementedError("device auto-reset is built for formation_hd_env only")
+        lib = _native.load()
+        p = self.params(world)
+        args = (world.num_envs, len(world.agents), len(world.landmarks), 1,
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                act.data_ptr(), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
+                out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream())
+        fn = lib.fg_step_basic
+        keep = (act, out)
+
+        def launch(rng_offset=0):
+            rc = fn(p, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        self._cache = None
+        return launch
+
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
         if auto_reset:
             raise NotImplementedError("device auto-reset is built for formation_hd_env only")

@@ -126,6 +126,33 @@ class LandmarkScenario(BaseScenario):
             _native.ptr(out.get("done")), _native.current_stream()))
         self._cache = out
 
+    def bind_step(self, world, act, out, auto_reset=False):
+        """Resolve the structs and every pointer once; returns `launch(rng_offset)` (one ctypes call
+        per step, see MultiAgentEnv._bound_step)."""
+        if auto_reset:
+            raise NotImplementedError("device auto-reset is built for formation_hd_env only; "
+                                      "use FormationVecEnv(reset_mode='host')")
+        lib = _native.load()
+        M = self.num_obstacles
+        p, d = self.params(world), self.descriptor()
+        args = (world.num_envs, len(world.agents), 1,
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                act.data_ptr(), world.landmark_pos.data_ptr(),
+                world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
+                world.step_count.data_ptr(),
+                out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), _native.current_stream())
+        fn = lib.fg_step_scenario
+        keep = (act, out)
+
+        def launch(rng_offset=0):
+            rc = fn(p, d, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        self._cache = None
+        return launch
+
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
         if auto_reset:
             raise NotImplementedError("device auto-reset is built for formation_hd_env only; "
