@@ -320,6 +320,30 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     if (a.do_phys && a.step && live && i == 0) a.step[b] = t_step;
 }
 
+// MultiAgentEnv._set_action for the non-default action modes (environment.py:187-215): one lane
+// per agent, raw u out (the step kernels scale by the sensitivity).
+__global__ __launch_bounds__(256) void decode_actions_kernel(int mode, int64_t count, void* action, float2* u_out) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= count) return;
+    float2 u = make_float2(0.f, 0.f);
+    if (mode == FG_ACT_ONEHOT5) {
+        const float* a = reinterpret_cast<const float*>(action) + g * 5;
+        u = make_float2(a[1] - a[2], a[3] - a[4]);
+    } else if (mode == FG_ACT_INDEX) {
+        const int k = reinterpret_cast<const int32_t*>(action)[g];
+        u.x = (k == 1) ? -1.0f : (k == 2) ? 1.0f : 0.0f;
+        u.y = (k == 3) ? -1.0f : (k == 4) ? 1.0f : 0.0f;
+    } else {
+        float2* a = reinterpret_cast<float2*>(action) + g;
+        const float2 v = *a;
+        u = (v.y > v.x) ? make_float2(0.f, 1.f) : make_float2(1.f, 0.f);   // np.argmax: first maximum; NaN first wins
+        if (v.x != v.x) u = make_float2(1.f, 0.f);
+        else if (v.y != v.y) u = make_float2(0.f, 1.f);
+        *a = u;
+    }
+    u_out[g] = u;
+}
+
 }  // namespace fg
 
 #endif  // FG_AUX_KERNELS_HPP_

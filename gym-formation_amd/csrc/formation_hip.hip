@@ -467,4 +467,19 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                            nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
 }
 
+int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream) {
+    if (mode != FG_ACT_ONEHOT5 && mode != FG_ACT_INDEX && mode != FG_ACT_ARGMAX)
+        return fail(FG_ERR_BAD_ARG, "fg_decode_actions: unknown mode%s");
+    if (count <= 0 || count > ((int64_t)1 << 38)) return fail(FG_ERR_BAD_ARG, "fg_decode_actions: count out of range%s");
+    if (!action || !u_out) return fail(FG_ERR_BAD_ARG, "fg_decode_actions: a required pointer is NULL%s");
+    if (((uintptr_t)u_out & 7) || (mode == FG_ACT_ARGMAX && ((uintptr_t)action & 7)))
+        return fail(FG_ERR_ALIGNMENT, "fg_decode_actions: buffers must be 8-byte aligned%s");
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(decode_actions_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mode, count, action,
+                       reinterpret_cast<float2*>(u_out));
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "decode launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
 }  // extern "C"

@@ -54,6 +54,7 @@ class FgParams(ctypes.Structure):
 
 
 FG_SCN_BASIC, FG_SCN_PARTIAL, FG_SCN_RANGE, FG_SCN_OBSTACLE = 1, 2, 3, 4
+FG_ACT_ONEHOT5, FG_ACT_INDEX, FG_ACT_ARGMAX = 1, 2, 3          # fg_decode_actions modes
 
 
 class FgScenario(ctypes.Structure):
@@ -96,6 +97,7 @@ SIGNATURES = {
     "fg_reset_hd_mt": (_I, [_I, _I] + [_P] * 11),
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
+    "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
 }
 
 _lib = None

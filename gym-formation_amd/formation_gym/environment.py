@@ -50,12 +50,10 @@ class MultiAgentEnv(object):
         if self.scenario is None:
             raise ValueError("world.scenario is not set: make_world() must attach the Scenario "
                              "that owns the batched kernels")
-        if discrete_action:
-            raise NotImplementedError("discrete action modes (environment.py:194-210) are unreachable "
-                                      "through make_env and not built")
-        self.discrete_action_space = False
-        self.discrete_action_input = False
-        self.force_discrete_action = False
+        # action modes (environment.py:39-47): make_env never sets them, direct construction may
+        self.discrete_action_space = bool(discrete_action)        # 5-vector per agent, u = (a1-a2, a3-a4)
+        self.discrete_action_input = False                        # an index 0..4 per agent
+        self.force_discrete_action = bool(getattr(world, 'discrete_action', False))   # arg-max one-hot
         self.shared_reward = world.collaborative if hasattr(world, 'collaborative') else False
         self.time = 0
         self.auto_reset = False           # vec-env worker semantics, see vec_env.py
@@ -69,8 +67,11 @@ class MultiAgentEnv(object):
         for agent in self.agents:
             if not agent.silent:
                 raise NotImplementedError("non-silent agents do not occur in the reference scenarios")
-            self.action_space.append(spaces.Box(low=-agent.u_range, high=+agent.u_range,
-                                                shape=(world.dim_p,), dtype=np.float32))
+            if self.discrete_action_space:                        # :64-65
+                self.action_space.append(spaces.Discrete(world.dim_p * 2 + 1))
+            else:
+                self.action_space.append(spaces.Box(low=-agent.u_range, high=+agent.u_range,
+                                                    shape=(world.dim_p,), dtype=np.float32))
             share_obs_dim += obs_dim
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf,
                                                      shape=(obs_dim,), dtype=np.float32))
@@ -115,7 +116,10 @@ class MultiAgentEnv(object):
         self.current_step += 1
         self.agents = self.world.policy_agents
         batched = torch.is_tensor(action_n)
-        if batched:
+        mode = self._action_mode()
+        if mode:
+            act = self._decode_actions(action_n, mode, batched)
+        elif batched:
             act = action_n
             if act.shape != self._act.shape:
                 raise ValueError("batched action must have shape %s, got %s"
@@ -156,6 +160,53 @@ class MultiAgentEnv(object):
         launch(self._rng_offset)
         self.scenario._cache = self._out
         return True
+
+    def _action_mode(self):
+        """Which branch of _set_action applies (environment.py:194-216); 0 = plain continuous."""
+        if self.discrete_action_input:
+            return _native.FG_ACT_INDEX
+        if self.discrete_action_space:
+            return _native.FG_ACT_ONEHOT5
+        if self.force_discrete_action:
+            return _native.FG_ACT_ARGMAX
+        return 0
+
+    def _decode_actions(self, action_n, mode, batched):
+        """Non-default action modes: stage the caller's actions on the device ([B,N,5] floats,
+        [B,N] indices or [B,N,2] floats) and decode them to raw u with `fg_decode_actions`."""
+        B, N = self.num_envs, self.num_agents
+        dev = self.world.device
+        shape, dtype = {_native.FG_ACT_ONEHOT5: ((B, N, 5), torch.float32),
+                        _native.FG_ACT_INDEX: ((B, N), torch.int32),
+                        _native.FG_ACT_ARGMAX: ((B, N, 2), torch.float32)}[mode]
+        if batched:
+            if tuple(action_n.shape) != shape:
+                raise ValueError("batched action must have shape %s in this action mode, got %s"
+                                 % (shape, tuple(action_n.shape)))
+            src = action_n
+            if src.dtype != dtype or src.device != dev or not src.is_contiguous():
+                src = src.to(device=dev, dtype=dtype).contiguous()
+        else:
+            if B != 1:
+                raise ValueError("a list of per-agent actions needs num_envs == 1; pass a batched tensor")
+            if len(action_n) != N:
+                raise ValueError("expected %d agent actions, got %d" % (N, len(action_n)))
+            host = np.asarray([np.asarray(a) for a in action_n]).reshape((1,) + shape[1:])
+            src = torch.as_tensor(host).to(device=dev, dtype=dtype).contiguous()
+        _native.check(_native.load().fg_decode_actions(mode, B * N, src.data_ptr(), self._act.data_ptr(),
+                                                       _native.current_stream()))
+        if mode == _native.FG_ACT_ARGMAX:
+            if batched:
+                if src is not action_n:
+                    action_n.copy_(src)           # the reference overwrites the caller's array (:213-215)
+            else:
+                sens = [a.accel if a.accel is not None else 5.0 for a in self.agents]
+                onehot = src[0].cpu().numpy()
+                for i, a in enumerate(action_n):  # ... and scales it through the `u` view (:216,:221)
+                    if isinstance(a, np.ndarray):
+                        a[:] = 0.0
+                        a[0:2] = onehot[i] * sens[i]
+        return self._act
 
     def _stage_reference_actions(self, action_n):
         """environment.py:121-122,187-236 for the continuous path, B == 1."""

@@ -212,6 +212,19 @@ int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, 
                      int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                      void* stream);
 
+/* Action decoding of MultiAgentEnv._set_action (environment.py:187-215) for the non-default action
+ * modes, before the sensitivity scaling (which the step kernels apply).  `count` = B*N agents.
+ *   FG_ACT_ONEHOT5 (discrete_action_space, :207-210): action float [count][5] -> u = (a1 - a2, a3 - a4)
+ *   FG_ACT_INDEX   (discrete_action_input, :194-205): action int32 [count], 1:-x 2:+x 3:-y 4:+y, else 0
+ *   FG_ACT_ARGMAX  (force_discrete_action, :212-216): action float [count][2] -> one-hot of the arg-max
+ *                   (first maximum, as np.argmax); the one-hot is also written back to `action`,
+ *                   as the reference overwrites the caller's array
+ * u_out float [count][2] is what fg_step_hd & co. take as `act`. */
+#define FG_ACT_ONEHOT5 1
+#define FG_ACT_INDEX 2
+#define FG_ACT_ARGMAX 3
+int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,30 @@ def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None,
     return pos, vel
 
 
+ACT_ONEHOT5, ACT_INDEX, ACT_ARGMAX = 1, 2, 3
+
+
+def decode_actions(action, mode):
+    """MultiAgentEnv._set_action for the non-default action modes, before the sensitivity
+    scaling (environment.py:187-216).  Returns raw u [..., 2] (float64).
+      ACT_ONEHOT5  discrete_action_space  (:207-210)  action [..., 5]: u = (a1 - a2, a3 - a4)
+      ACT_INDEX    discrete_action_input  (:194-205)  action [...] int: 1 -x, 2 +x, 3 -y, 4 +y
+      ACT_ARGMAX   force_discrete_action  (:212-216)  action [..., 2]: one-hot of np.argmax"""
+    a = np.asarray(action)
+    if mode == ACT_ONEHOT5:
+        a = a.astype(np.float64)
+        return np.stack([a[..., 1] - a[..., 2], a[..., 3] - a[..., 4]], -1)
+    if mode == ACT_INDEX:
+        u = np.zeros(a.shape + (2,))
+        u[..., 0] = np.where(a == 1, -1.0, np.where(a == 2, 1.0, 0.0))
+        u[..., 1] = np.where(a == 3, -1.0, np.where(a == 4, 1.0, 0.0))
+        return u
+    if mode == ACT_ARGMAX:
+        p = np.argmax(a[..., 0:2], axis=-1)
+        return np.stack([(p == 0).astype(np.float64), (p == 1).astype(np.float64)], -1)
+    raise ValueError("unknown action mode %r" % (mode,))
+
+
 def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64):
     """formation_hd_env.py:52-59 for every agent: [v_i | p_j - p_i (j != i, index
     order) | zeros 2(N-1) | ideal_shape.flatten() | ideal_vel] -> [B,N,6N]."""

@@ -180,6 +180,49 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
     return res
 
 
+def rollout_action_mode(fg, mode, N, T, seed, act_seed):
+    """formation_hd_env driven through the non-default branches of _set_action
+    (environment.py:187-216), which make_env never selects: `onehot5` = MultiAgentEnv(...,
+    discrete_action=True), `index` = discrete_action_input, `argmax` = world.discrete_action."""
+    rs = np.random.RandomState(act_seed)
+    base = fg.make_env("formation_hd_env", False, N)
+    sc = _scenario_of(base)
+    world = base.world
+    if mode == "argmax":
+        world.discrete_action = True
+    env = fg.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, shared_viewer=True,
+                           discrete_action=(mode == "onehot5"))
+    if mode == "index":
+        env.discrete_action_input = True
+    if mode == "onehot5":
+        acts = rs.uniform(0, 1, (T, N, 5))
+    elif mode == "index":
+        acts = rs.randint(0, 5, (T, N)).astype(np.int32)
+    else:
+        acts = rs.uniform(-1, 1, (T, N, 2))
+    env.seed(seed)
+    obs0 = np.array(env.reset(), dtype=np.float64)
+    pos0, vel0 = _state(env)
+    rec = {k: [] for k in ("pos", "vel", "indiv", "shared", "obs", "acts_after")}
+    for t in range(T):
+        if mode == "index":
+            act_n = [int(acts[t, i]) for i in range(N)]
+        else:
+            act_n = [acts[t, i].astype(np.float64).copy() for i in range(N)]
+        obs_n, rew_n, done_n, info_n = env.step(act_n)
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
+        rec["shared"].append(np.array([r[0] for r in rew_n]))
+        rec["obs"].append(np.array(obs_n, dtype=np.float64))
+        rec["acts_after"].append(np.array(act_n, dtype=np.float64))      # what the call left in the caller's arrays
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(acts=acts, pos0=pos0, vel0=vel0, obs0=obs0, ideal_shape=np.array(sc.ideal_shape, dtype=np.float64),
+               ideal_vel=np.array(sc.ideal_vel, dtype=np.float64), seed=np.array(seed),
+               action_space_n=np.array(getattr(env.action_space[0], "n", -1)))
+    return res
+
+
 def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None):
     """Seeded rollout of one of the remaining scenarios (formation_hd_partial_env,
     formation_hd_partial_range_env, formation_hd_obs_env) through the reference API."""
@@ -359,6 +402,10 @@ def main():
     save("policy_n9", lambda: policy_fixture(fg, 9, 30, seed=42))
     save("policy_n27", lambda: policy_fixture(fg, 27, 12, seed=43))
     save("hausdorff_kat", lambda: hausdorff_kat())
+    # non-default action modes of _set_action (environment.py:187-216)
+    save("act_onehot5_n3", lambda: rollout_action_mode(fg, "onehot5", 3, 8, seed=71, act_seed=81))
+    save("act_index_n9", lambda: rollout_action_mode(fg, "index", 9, 8, seed=72, act_seed=82))
+    save("act_argmax_n3", lambda: rollout_action_mode(fg, "argmax", 3, 8, seed=73, act_seed=83))
     # remaining scenarios ("next" row f3)
     save("partial_n5", lambda: rollout_scn(fg, "formation_hd_partial_env", 5, 3, 27, seed=51, act_seed=61))
     save("partial_n9_crowd", lambda: rollout_scn(fg, "formation_hd_partial_env", 9, 3, 12, seed=52, act_seed=62, crowd=0.15))

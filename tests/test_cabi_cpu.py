@@ -109,6 +109,10 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_step_scenario(P, sc, 4, 62, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 64
     assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_decode_actions(0, 12, p, p, None) == _native.FG_ERR_BAD_ARG           # unknown mode
+    assert lib.fg_decode_actions(_native.FG_ACT_INDEX, 0, p, p, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_decode_actions(_native.FG_ACT_ARGMAX, 12, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
     with pytest.raises(_native.FormationHipError):
         _native.check(lib.fg_step_hd(P, 0, 9, *ok_ptrs))
 

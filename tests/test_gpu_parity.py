@@ -743,3 +743,50 @@ def test_env_step_rebinds_when_inputs_or_world_constants_change():
         check(a3, max_speed=0.3)
         assert len(env._launchers) == n_before + 1
     torch.cuda.current_stream().wait_stream(side)
+
+
+@pytest.mark.parametrize("name,mode", [("act_onehot5_n3", "onehot5"), ("act_index_n9", "index"), ("act_argmax_n3", "argmax")])
+def test_action_modes_match_reference_fixtures(golden, name, mode):
+    """The non-default branches of _set_action (environment.py:187-216) through the reference-style
+    list API (one env) and the batched tensor API (the same env replicated), teacher-forced."""
+    import formation_gym
+    g = golden(name)
+    T, N = g["acts"].shape[0], g["pos0"].shape[0]
+
+    def build(B):
+        sc = formation_gym.load_scenario("formation_hd_env")
+        world = sc.make_world(N, num_envs=B, device="cuda:0")
+        if mode == "argmax":
+            world.discrete_action = True
+        env = formation_gym.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation,
+                                          discrete_action=(mode == "onehot5"))
+        env.discrete_action_input = mode == "index"
+        return env
+
+    env1, envB = build(1), build(5)
+    assert (getattr(env1.action_space[0], "n", -1) == 5) == (mode == "onehot5")
+    for t in range(T):
+        prev_pos, prev_vel = (g["pos0"], g["vel0"]) if t == 0 else (g["pos"][t - 1], g["vel"][t - 1])
+        for env, B in ((env1, 1), (envB, 5)):
+            _load(env, np.repeat(prev_pos[None], B, 0), np.repeat(prev_vel[None], B, 0),
+                  np.repeat(g["ideal_shape"][None], B, 0), np.repeat(g["ideal_vel"][None], B, 0), np.full(B, t))
+        # reference-style call
+        if mode == "index":
+            act_n = [int(a) for a in g["acts"][t]]
+        else:
+            act_n = [g["acts"][t, i].astype(np.float64).copy() for i in range(N)]
+        obs_n, rew_n, done_n, info_n = env1.step(act_n)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose([r[0] for r in rew_n], g["shared"][t], rtol=1e-5, atol=ATOL)
+        np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(env1.world.get_state()[0])[0], g["pos"][t], rtol=0, atol=ATOL)
+        if mode != "index":
+            np.testing.assert_array_equal(np.array(act_n), g["acts_after"][t])     # in-place effects on the caller's arrays
+        # batched call
+        dt = torch.int32 if mode == "index" else torch.float32
+        act = torch.as_tensor(np.repeat(g["acts"][t][None], 5, 0)).to(device="cuda", dtype=dt)
+        obs, rew, done, info = envB.step(act)
+        np.testing.assert_allclose(_np(obs), np.repeat(g["obs"][t][None], 5, 0), rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(envB.world.get_state()[0]), np.repeat(g["pos"][t][None], 5, 0), rtol=0, atol=ATOL)
+        if mode == "argmax":
+            np.testing.assert_array_equal(_np(act)[0] * 5.0, g["acts_after"][t])   # one-hot written back

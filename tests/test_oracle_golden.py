@@ -245,3 +245,28 @@ def test_world_options_match_reference(golden, name, opts):
         np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=1e-10)
         np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+ACT_MODES = [("act_onehot5_n3", O.ACT_ONEHOT5), ("act_index_n9", O.ACT_INDEX), ("act_argmax_n3", O.ACT_ARGMAX)]
+
+
+@pytest.mark.parametrize("name,mode", ACT_MODES)
+def test_action_modes_match_reference(golden, name, mode):
+    """The non-default branches of _set_action (environment.py:187-216), free-running from the
+    reference's reset state; also what the reference leaves in the caller's action arrays."""
+    g = golden(name)
+    st = dict(pos=g["pos0"][None], vel=g["vel0"][None], ideal_shape=g["ideal_shape"][None],
+              ideal_vel=g["ideal_vel"][None], step=np.zeros(1, dtype=np.int32))
+    for t in range(g["acts"].shape[0]):
+        u = O.decode_actions(g["acts"][t], mode)
+        st, out = O.step_hd(st, u[None])
+        np.testing.assert_allclose(st["pos"][0], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st["vel"][0], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"][0], g["indiv"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["reward"][0, :, 0], g["shared"][t], rtol=1e-12, atol=1e-10)
+        np.testing.assert_allclose(out["obs"][0], g["obs"][t], rtol=0, atol=1e-10)
+        if mode == O.ACT_ARGMAX:          # overwritten with the one-hot, then scaled through the u view
+            np.testing.assert_array_equal(g["acts_after"][t], 5.0 * u)
+        else:
+            np.testing.assert_array_equal(g["acts_after"][t], g["acts"][t].astype(np.float64))
+    assert int(g["action_space_n"]) == (5 if mode == O.ACT_ONEHOT5 else -1)
