@@ -790,3 +790,51 @@ def test_action_modes_match_reference_fixtures(golden, name, mode):
         np.testing.assert_allclose(_np(envB.world.get_state()[0]), np.repeat(g["pos"][t][None], 5, 0), rtol=0, atol=ATOL)
         if mode == "argmax":
             np.testing.assert_array_equal(_np(act)[0] * 5.0, g["acts_after"][t])   # one-hot written back
+
+
+@pytest.mark.parametrize("N,B", [(81, 2048), (243, 8192)])
+def test_baseline_full_size_per_gpu_properties(N, B):
+    """BASELINE configs 3 and 4 at their per-GPU batch (81 x 2048, 243 x 8192): size-independent
+    properties checked on the device for EVERY env, the fp64 oracle on a sample of envs, and the same
+    envs in a small batch bit for bit (the result of an env does not depend on the batch around it)."""
+    dev = "cuda:0"
+    env = _make(N, B)
+    env.seed(5); env.reset()
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    act = torch.rand((B, N, 2), generator=gen, device=dev) * 2 - 1
+    pos0, vel0 = env.world.get_state()
+    shape, ivel = env.scenario.ideal_shape.clone(), env.scenario.ideal_vel.clone()
+    obs, rew, done, info = env.step(act)
+    pos, vel = env.world.get_state()
+    ind = info["individual_reward"]
+    assert not bool(done.any())
+    assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(rew).all())
+    assert torch.allclose(ind.double().sum(1), rew[:, 0, 0].double(), rtol=2e-6, atol=1e-3)    # shared = sum of individuals
+    assert bool((rew[:, :, 0] == rew[:, :1, 0]).all())
+    assert bool((obs[:, :, 0:2] == vel).all())                                                 # own velocity
+    assert bool((obs[:, :, 2 * N:4 * N - 2] == 0).all())                                       # comm block
+    assert bool((obs[:, :, 4 * N - 2:6 * N - 2] == shape.reshape(B, 1, 2 * N)).all())           # ideal shape
+    assert bool((obs[:, :, 6 * N - 2:] == ivel[:, None]).all())                                # ideal velocity
+    # relative positions: row i holds p_j - p_i for j != i, in order; check two rows against the state exactly
+    for i in (0, N // 2, N - 1):
+        others = [j for j in range(N) if j != i]
+        want = pos[:, others] - pos[:, i:i + 1]
+        assert bool((obs[:, i, 2:2 * N].reshape(B, N - 1, 2) == want).all())
+    # the fp64 oracle on a sample
+    idx = np.random.RandomState(1).choice(B, 24, replace=False)
+    st = dict(pos=_np(pos0)[idx], vel=_np(vel0)[idx], ideal_shape=_np(shape)[idx], ideal_vel=_np(ivel)[idx],
+              step=np.zeros(len(idx), dtype=np.int32))
+    new, out = O.step_hd(st, _np(act)[idx])
+    np.testing.assert_allclose(_np(pos)[idx], new["pos"], rtol=0, atol=ATOL)
+    ok = out["cnt_margin"] > 1e-5
+    np.testing.assert_allclose(_np(ind)[idx][ok], out["indiv"][ok], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(rew)[idx][ok], out["reward"][ok], rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(_np(obs[torch.as_tensor(idx, device=dev)]), out["obs"], rtol=0, atol=2 * ATOL)
+    # batch independence, bit for bit
+    nb = 13
+    env2 = _make(N, nb)
+    sel = torch.as_tensor(idx[:nb], device=dev)
+    _load(env2, _np(pos0[sel]), _np(vel0[sel]), _np(shape[sel]), _np(ivel[sel]), np.zeros(nb))
+    obs2, rew2, _, info2 = env2.step(act[sel].contiguous())
+    assert torch.equal(obs2, obs[sel]) and torch.equal(rew2, rew[sel])
+    assert torch.equal(info2["individual_reward"], ind[sel])
