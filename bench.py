@@ -124,6 +124,18 @@ def main():
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started without a launcher: start one rank per GPU as child processes (this process has not
+        # touched the GPU and only relays the exit code)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+
     import numpy as np
     import torch
     import torch.distributed as dist

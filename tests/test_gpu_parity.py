@@ -455,6 +455,11 @@ def test_bench_json_contract_single_and_two_ranks():
     assert len(line) == 1
     d2 = json.loads(line[0])
     assert d2["n_gpus"] == 2 and d2["config"]["global_envs"] == 512 and d2["scaling"] == "weak"
+    # without a launcher, `--gpus 2` starts its own ranks
+    out = _run(["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256", "--agents", "9",
+                "--backend", "gloo", "--no-extra"])
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 2
 
 
 def test_demo_driver_runs():
