@@ -26,6 +26,8 @@
 // fg_aux_kernels.hpp (resets, landmark scenarios); this file holds the host side: variant
 // tables, dispatch and the extern "C" entry points.
 
+#include <climits>
+#include <cstdlib>
 #include "fg_common.hpp"
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
@@ -44,6 +46,13 @@ static int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
     return code;
 }
+
+// Tuning switches (profiles/README.md) are environment variables read ONCE per call site: a launch
+// costs no getenv, and a process sees one consistent configuration.
+static int read_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#define FG_OVERRIDE(var, name) \
+    do { static const int fg_o_ = read_env_int(name, INT_MIN); if (fg_o_ != INT_MIN) (var) = fg_o_; } while (0)
+struct GeomOverride { int t, e; bool set; };
 
 struct Geometry { int G, T, E, lds; };
 
@@ -99,8 +108,13 @@ static const Variant* variant_for(int N, int B = 0, bool need_opts = false) {
     // per CU) is latency-bound and prefers one env per wave with spare writer waves.
     if (N == 27 && B >= 32768) { want_t = 256; want_e = 8; }
     if (N == 9 && B >= 16384) { want_t = 128; want_e = 8; }
-    if (const char* s = getenv("FG_GEOM")) sscanf(s, "%d,%d", &want_t, &want_e);
-    if (const char* s = getenv("FG_FLAT")) want_flat = atoi(s);
+    {   // "T,E", parsed once
+        static const GeomOverride go = [] { GeomOverride g = {0, 0, false};
+                                            if (const char* s = getenv("FG_GEOM")) g.set = sscanf(s, "%d,%d", &g.t, &g.e) == 2;
+                                            return g; }();
+        if (go.set) { want_t = go.t; want_e = go.e; }
+    }
+    FG_OVERRIDE(want_flat, "FG_FLAT");
     const Variant* dflt = nullptr;
     for (const Variant& v : kVariants) {
         if (need_opts) break;
@@ -141,14 +155,14 @@ static int launch_wide(Args a, hipStream_t st) {
     const int N = a.N, B = a.B;
     hipError_t err = hipSuccess;
     int tw = 256;
-    if (const char* e = getenv("FG_TW")) tw = atoi(e);
+    FG_OVERRIDE(tw, "FG_TW");
     if (a.K == 1) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
         // stream, few enough to keep every CU busy (MI355X sweep, profiles/README.md)
         const int E = (N == 243 && tw == 128) ? 2 : ((N == 81 && tw == 512) ? 8 : 4);
         const int batches = (B + E - 1) / E;
         int target = 256;                                  // workgroups in the grid: one per CU
-        if (const char* e = getenv("FG_STEPWG")) target = atoi(e);
+        FG_OVERRIDE(target, "FG_STEPWG");
         a.groups = batches / (target > 0 ? target : 1);
         if (a.groups < 1) a.groups = 1;
         if (a.groups > 64) a.groups = 64;
@@ -221,9 +235,9 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
     {   // 81 / 243 agents: pipeline over env batches inside the launch (no index outputs, no World options)
-        const char* nopipe = getenv("FG_NOPIPE");
+        int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
         const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
-        if ((N == 81 || N == 243) && !(nopipe && atoi(nopipe)) && !opts && !near_lm && !near_ag && !hd_idx)
+        if ((N == 81 || N == 243) && !nopipe && !opts && !near_lm && !near_ag && !hd_idx)
             return launch_wide(a, (hipStream_t)stream);
     }
     return launch_step(a, (hipStream_t)stream);
@@ -290,17 +304,17 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised small N: producer / writer pipelined kernel
-    if (FG_PROBES) { if (const char* e = getenv("FG_PROBE")) a.probe = atoi(e); }
-    const char* nopipe = getenv("FG_NOPIPE");
-    if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
-    if (K >= 2 && !(nopipe && atoi(nopipe)) && (N == 27 || N == 9 || N == 3)) {
-        if (const char* e = getenv("FG_STRIDED")) a.strided = atoi(e);
+    if (FG_PROBES) { FG_OVERRIDE(a.probe, "FG_PROBE"); }
+    int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
+    if (K >= 2 && !nopipe && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
+    if (K >= 2 && !nopipe && (N == 27 || N == 9 || N == 3)) {
+        FG_OVERRIDE(a.strided, "FG_STRIDED");
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
-        if (const char* e = getenv("FG_TW")) tw = atoi(e);
+        FG_OVERRIDE(tw, "FG_TW");
         hipStream_t st = (hipStream_t)stream;
         hipError_t err = hipSuccess;
         int wr = 10;
-        if (const char* e = getenv("FG_ROLLWR")) wr = atoi(e);
+        FG_OVERRIDE(wr, "FG_ROLLWR");
 #define FG_ROLL(NCV, GV, TPV, TWV, EV, WRV)                                                              \
         {   const int grid = (B + (EV) - 1) / (EV);                                                      \
             int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                                \
@@ -309,9 +323,9 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
             err = hipGetLastError(); }
         if (N == 27) {
             int re = 16;                   // 16 envs per workgroup: 8 producer + 4 writer waves, one workgroup per CU
-            if (const char* e = getenv("FG_ROLLE")) re = atoi(e);
+            FG_OVERRIDE(re, "FG_ROLLE");
             int share = 0;                 // tuning: producers join the observation stream through an LDS tile counter
-            if (const char* e = getenv("FG_SHARE")) share = atoi(e);
+            FG_OVERRIDE(share, "FG_SHARE");
             if (re == 2) { if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 10) else FG_ROLL(27, 32, 64, 128, 2, 10) }
                            else { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 0) else FG_ROLL(27, 32, 64, 128, 2, 0) } }
             else if (re == 16 && share) {
@@ -347,7 +361,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
             // store-bound and want 16-env workgroups (whole 128-byte lines per workgroup) with the
             // LDS-tiled writer.  FG_ROLL9 overrides (tuning aid).
             int v9 = B >= 8192 ? 4 : B > 4096 ? 6 : 5;
-            if (const char* e = getenv("FG_ROLL9")) v9 = atoi(e);
+            FG_OVERRIDE(v9, "FG_ROLL9");
             if (v9 == 1) FG_ROLL(9, 16, 64, 64, 4, 10)
             else if (v9 == 4) FG_ROLL(9, 16, 256, 256, 16, 10)
             else if (v9 == 6) FG_ROLL(9, 16, 128, 128, 8, 10)
