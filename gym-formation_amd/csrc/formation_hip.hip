@@ -234,10 +234,13 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
-    {   // 81 / 243 agents: pipeline over env batches inside the launch (no index outputs, no World options)
+    {   // 243 agents: pipeline over env batches inside the launch (no index outputs, no World options):
+        // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192.  At 81 agents the plain kernel is as fast or faster
+        // (74 vs 80 us at 81 x 2048 on the same box); FG_PIPE81=1 selects the pipelined one.
         int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
+        int pipe81 = 0; FG_OVERRIDE(pipe81, "FG_PIPE81");
         const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
-        if ((N == 81 || N == 243) && !nopipe && !opts && !near_lm && !near_ag && !hd_idx)
+        if ((N == 243 || (N == 81 && pipe81)) && !nopipe && !opts && !near_lm && !near_ag && !hd_idx)
             return launch_wide(a, (hipStream_t)stream);
     }
     return launch_step(a, (hipStream_t)stream);
