@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
-rows = [r for r in csv.DictReader(open(f)) if "fg::step_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(f)) if "fg::" in r["Kernel_Name"] and "reset" not in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = ["physics_only", "step_without_obs", "full_step"]
 n = len(rows) // 3
