@@ -120,6 +120,8 @@ def main():
                     help="tuning aid (rollout mode): write an observation only every n-th step; the JSON line is "
                          "then NOT a valid benchmark result")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of the other BASELINE per-GPU shapes (9 x 4096, 81 x 2048, 243 x 8192)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
@@ -149,104 +151,137 @@ def main():
     ndev = max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
+    # The only communication of this benchmark is the timing barrier and a MAX (no data-path
+    # collective: environments are independent).  The default group is gloo over 127.0.0.1, always
+    # available; with --backend nccl an RCCL group is created on top and used for the barrier if every
+    # rank can bring it up (ranks sharing one GPU cannot: then all ranks agree to stay on gloo).
+    sync_group, red_dev, sync_backend = None, None, "none"
     if world_size > 1:
+        import datetime
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        sync_backend = "gloo"
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-    red_dev = dev if a.backend == "nccl" else None
+            ok, why = 1, ""
+            try:
+                g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe, group=g)
+                torch.cuda.synchronize()
+                ok = int(float(probe[0]) == world_size)
+            except Exception as exc:              # noqa: BLE001 - any RCCL bring-up failure means "use gloo"
+                ok, why = 0, "%s: %s" % (type(exc).__name__, str(exc).splitlines()[0][:200] if str(exc) else "")
+            agreed = torch.tensor([ok])
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+            if int(agreed[0]) == 1:
+                sync_group, red_dev, sync_backend = g, dev, "rccl"
+            elif rank == 0:
+                print("bench: RCCL group not available on every rank (%s); timing barrier stays on gloo" % why,
+                      file=sys.stderr, flush=True)
 
     import formation_gym
-    from formation_gym import _native
-
-    N, B = a.agents, a.envs
-    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
-    # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
-    # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
-    from formation_gym import sharding
-    lo, hi = sharding.env_slice(B * world_size, rank, world_size)
-    env.seed(int(sharding.global_seeds(1, lo, hi)[0]))      # env b of this rank: 1 + 1000 (lo + b)
-    env.reset()
-    env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
-    env.world.step_count.zero_()
-
-    N, B = a.agents, a.envs
-    # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
-    chunk = max(1, min(a.chunk, int(48e9 // (B * N * 6 * N * 4)) or 1))
-    P = 3 * chunk if chunk >= 8 else 64                # pre-staged action pool (whole launches), cycled
-    gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
-    act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
-    out = env._out
-    bytes_per_env_step = _native.step_hd_bytes(N)
+    from formation_gym import _native, sharding
 
     def barrier():
         torch.cuda.synchronize()
         if world_size > 1:
-            dist.barrier()
+            dist.barrier(group=sync_group)
         torch.cuda.synchronize()
 
-    def run_steps(n, start):
-        launchers = run_steps.launchers
-        for t in range(start, start + n):
-            launchers[t % P](t)
+    def measure(N, B, mode, steps, warmup, chunk_req, other_steps):
+        """Times `steps` env steps of N agents x B envs per GPU in `mode` (and, if other_steps > 0, the
+        other launch mode beside it).  Returns wall seconds and HIP-event milliseconds, MAX over ranks."""
+        env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
+        # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
+        # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
+        lo, hi = sharding.env_slice(B * world_size, rank, world_size)
+        env.seed(int(sharding.global_seeds(1, lo, hi)[0]))      # env b of this rank: 1 + 1000 (lo + b)
+        env.reset()
+        env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
+        env.world.step_count.zero_()
 
-    run_steps.launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=not a.no_auto_reset) for i in range(P)]
+        # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
+        chunk = max(1, min(chunk_req, int(48e9 // (B * N * 6 * N * 4)) or 1))
+        P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
+        gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
+        act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
+        out = env._out
+        launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=not a.no_auto_reset) for i in range(P)]
 
-    def run_rollout(n, start, chunk, seq):
-        t = start
-        while t < start + n:
-            k = min(chunk, start + n - t)
-            lo = t % P
-            if lo + k > P:
-                k = P - lo
-            env.scenario.rollout_batch(env.world, act_pool[lo:lo + k], {k2: v[:k] for k2, v in seq.items()},
-                                       obs_every=a.obs_every, auto_reset=not a.no_auto_reset, rng_offset=t)
-            t += k
+        def run_steps(n, start):
+            for t in range(start, start + n):
+                launchers[t % P](t)
 
-    def timed(fn, steps, warmup):
-        fn(warmup, 0)
-        barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        fn(steps, warmup)
-        ev1.record()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0                        # this rank's K steps, start barrier -> local completion
-        barrier()
-        dev_ms = ev0.elapsed_time(ev1)
-        wall = sharding.max_over_ranks(wall, red_dev)          # slowest rank
-        dev_ms = sharding.max_over_ranks(dev_ms, red_dev)
-        return wall, dev_ms
+        def run_rollout(n, start):
+            t = start
+            while t < start + n:
+                k = min(chunk, start + n - t)
+                lo_ = t % P
+                if lo_ + k > P:
+                    k = P - lo_
+                env.scenario.rollout_batch(env.world, act_pool[lo_:lo_ + k], {k2: v[:k] for k2, v in seq.items()},
+                                           obs_every=a.obs_every, auto_reset=not a.no_auto_reset, rng_offset=t)
+                t += k
 
-    seq = None
-    if a.mode == "rollout" or not a.no_extra:
-        f = dict(dtype=torch.float32, device=dev)
-        seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
-                   indiv=torch.empty((chunk, B, N), **f),
-                   done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
+        def timed(fn, n, w):
+            fn(w, 0)
+            barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            fn(n, w)
+            ev1.record()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0                    # this rank's steps, start barrier -> local completion
+            barrier()
+            dev_ms = ev0.elapsed_time(ev1)
+            wall = sharding.max_over_ranks(wall, red_dev, sync_group)          # slowest rank
+            dev_ms = sharding.max_over_ranks(dev_ms, red_dev, sync_group)
+            return wall, dev_ms
 
-    if a.mode == "step":
-        wall, dev_ms = timed(run_steps, a.steps, a.warmup)
-    else:
-        wall, dev_ms = timed(lambda n, s: run_rollout(n, s, chunk, seq), a.steps, a.warmup)
+        seq = None
+        if mode == "rollout" or other_steps > 0:
+            f = dict(dtype=torch.float32, device=dev)
+            seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
+                       indiv=torch.empty((chunk, B, N), **f),
+                       done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
+        fns = {"step": run_steps, "rollout": run_rollout}
+        wall, dev_ms = timed(fns[mode], steps, warmup)
+        bytes_per_env_step = _native.step_hd_bytes(N)
+        r = {"wall": wall, "dev_ms": dev_ms, "chunk": chunk, "bytes_per_env_step": bytes_per_env_step, "extra": None}
+        if other_steps > 0:
+            other = "rollout" if mode == "step" else "step"
+            w2, d2 = timed(fns[other], other_steps, min(warmup, 40))
+            r["extra"] = {"mode": other, "steps": other_steps,
+                          "env_steps_per_s": round(world_size * B * other_steps / w2, 1),
+                          "ms_per_step": round(w2 * 1e3 / other_steps, 5),
+                          "achieved_GBps": round(bytes_per_env_step * B * other_steps / (d2 * 1e-3) / 1e9, 1)}
+            if other == "rollout":
+                r["extra"]["chunk"] = chunk
+        pos, _ = env.world.get_state()
+        r["finite"] = bool(torch.isfinite(pos).all())
+        del env, act_pool, launchers, seq, out
+        torch.cuda.empty_cache()
+        return r
 
-    extra = None
-    if not a.no_extra:
-        other = "rollout" if a.mode == "step" else "step"
-        k2 = min(a.steps, 400)
-        if other == "rollout":
-            w2, d2 = timed(lambda n, s: run_rollout(n, s, chunk, seq), k2, min(a.warmup, 40))
-        else:
-            w2, d2 = timed(run_steps, k2, min(a.warmup, 40))
-        extra = {"mode": other, "steps": k2, "env_steps_per_s": round(world_size * B * k2 / w2, 1),
-                 "ms_per_step": round(w2 * 1e3 / k2, 5),
-                 "achieved_GBps": round(bytes_per_env_step * B * k2 / (d2 * 1e-3) / 1e9, 1)}
-        if other == "rollout":
-            extra["chunk"] = chunk
+    N, B = a.agents, a.envs
+    m = measure(N, B, a.mode, a.steps, a.warmup, a.chunk, 0 if a.no_extra else min(a.steps, 400))
+    wall, dev_ms, chunk, extra, finite = m["wall"], m["dev_ms"], m["chunk"], m["extra"], m["finite"]
+    bytes_per_env_step = m["bytes_per_env_step"]
 
-    pos, _ = env.world.get_state()
-    finite = bool(torch.isfinite(pos).all())
+    # the other BASELINE.json per-GPU shapes, short runs in the same process (N = 1 only; reported beside the
+    # headline workload, never as `value`)
+    others = []
+    if world_size == 1 and not a.no_extra and not a.no_other_configs and (N, B) == (27, 4096):
+        for n2, b2, st2 in ((9, 4096, 400), (81, 2048, 200), (243, 8192, 24)):
+            m2 = measure(n2, b2, a.mode, st2, max(4, st2 // 10), a.chunk, st2)
+            g = m2["bytes_per_env_step"] * b2 * st2 / (m2["dev_ms"] * 1e-3) / 1e9
+            others.append({"workload": "formation_hd_env, %d agents x %d envs per GPU" % (n2, b2), "mode": a.mode,
+                           "steps": st2, "steps_per_launch": 1 if a.mode == "step" else m2["chunk"],
+                           "env_steps_per_s": round(b2 * st2 / m2["wall"], 1),
+                           "agent_steps_per_s": round(b2 * n2 * st2 / m2["wall"], 1),
+                           "ms_per_step": round(m2["wall"] * 1e3 / st2, 5), "achieved_GBps": round(g, 1),
+                           "frac_of_hbm_peak": round(g / HBM_PEAK_GBPS, 4), "other_mode": m2["extra"],
+                           "state_finite": m2["finite"]})
 
     if rank == 0:
         launches = a.steps if a.mode == "step" else None
@@ -262,6 +297,7 @@ def main():
                                    "episode 100 with device auto-reset" % (N, B),
                        "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
+                       "timing_barrier": sync_backend,
                        "steps_per_launch": 1 if a.mode == "step" else chunk,
                        "kernel": ("fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"]))
                        if a.mode == "step" else "fg::rollout_kernel<%d> (producer/writer pipelined)" % N},
@@ -278,6 +314,8 @@ def main():
             res["INVALID"] = "observations written only every %d-th step (tuning run)" % a.obs_every
         if extra:
             res["other_mode"] = extra
+        if others:
+            res["other_configs"] = others
         if world_size == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(res), flush=True)

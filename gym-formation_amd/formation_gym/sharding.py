@@ -29,12 +29,13 @@ def global_seeds(seed, lo, hi):
     return int(seed) + 1000 * np.arange(lo, hi, dtype=np.int64)
 
 
-def max_over_ranks(value, device=None):
-    """MAX of a python float over all ranks (the bench's slowest-rank time)."""
+def max_over_ranks(value, device=None, group=None):
+    """MAX of a python float over all ranks (the bench's slowest-rank time).  `group` / `device`:
+    the process group to reduce over and the device its backend wants the tensor on (RCCL: the GPU)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t[0])
 
 

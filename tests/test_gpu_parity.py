@@ -455,6 +455,15 @@ def test_bench_json_contract_single_and_two_ranks():
     assert len(line) == 1
     d2 = json.loads(line[0])
     assert d2["n_gpus"] == 2 and d2["config"]["global_envs"] == 512 and d2["scaling"] == "weak"
+    # default backend with two ranks on ONE GPU: RCCL cannot come up (duplicate device), every rank agrees to
+    # keep the timing barrier on gloo and the run still completes
+    out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29573", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
+                "--agents", "9", "--no-extra"], timeout=600)
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d3 = json.loads(line[0])
+    assert d3["n_gpus"] == 2 and d3["config"]["timing_barrier"] in ("gloo", "rccl")
     # without a launcher, `--gpus 2` starts its own ranks
     out = _run(["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256", "--agents", "9",
                 "--backend", "gloo", "--no-extra"])
