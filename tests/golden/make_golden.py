@@ -140,6 +140,13 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
                 a.accel = options.get("accel")
             if options.get("walls"):
                 env.world.walls = [rcore.Wall(o, ax, ep, w) for (o, ax, ep, w) in WALLS]
+            wc = options.get("world")                     # non-default World constants (core.py:119-139)
+            if wc:
+                env.world.dt = wc["dt"]; env.world.damping = wc["damping"]
+                env.world.contact_force = wc["contact_force"]; env.world.contact_margin = wc["contact_margin"]
+                env.world.world_length = wc["world_length"]; env.world_length = wc["world_length"]   # environment.py:22
+                for a in env.world.agents:
+                    a.initial_mass = wc["mass"]; a.size = wc["size"]
         env.seed(seed + 1000 * b)
         o0 = env.reset()
         sc = _scenario_of(env)
@@ -177,6 +184,8 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
                obs_steps=np.array(sorted(obs_at), dtype=np.int32))
     for t, lst in obs_store.items():
         res["obs_t%d" % t] = np.array(lst)                     # [B,N,6N]
+    if options and options.get("world"):
+        res.update({"world_" + k: np.array(v) for k, v in options["world"].items()})
     return res
 
 
@@ -393,6 +402,11 @@ def main():
     # done flip of formation_hd_env at world_length = 100
     save("hd_n9_options", lambda: rollout_hd(fg, 9, 4, 30, seed=23, act_seed=33, options=dict(max_speed=0.6, accel=3.0, walls=True)))
     save("hd_n27_walls", lambda: rollout_hd(fg, 27, 2, 20, seed=24, act_seed=34, options=dict(walls=True)))
+    # non-default World constants (dt, damping, contact force / margin, agent mass and size, episode length)
+    save("hd_n9_constants", lambda: rollout_hd(fg, 9, 3, 12, seed=25, act_seed=35, crowd=0.3, obs_at=[1, 12], options=dict(
+        world=dict(dt=0.05, damping=0.4, contact_force=60.0, contact_margin=4e-3, mass=2.5, size=0.08, world_length=7))))
+    save("hd_n27_constants", lambda: rollout_hd(fg, 27, 2, 8, seed=26, act_seed=36, crowd=0.4, obs_at=[8], options=dict(
+        world=dict(dt=0.2, damping=0.1, contact_force=150.0, contact_margin=2e-3, mass=0.5, size=0.05, world_length=5))))
     save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
     # config 1: basic_formation_env, N=3, incl. the done flip at step 50
     save("basic_n3", lambda: rollout_basic(fg, 3, 52, seed=1, act_seed=20))

@@ -503,6 +503,51 @@ def test_world_options_teacher_forced(golden, name, opts):
         assert float(torch.stack(env.world.get_state()[1:]).norm(dim=-1).max()) <= opts["max_speed"] * (1 + 1e-5)
 
 
+@pytest.mark.parametrize("name", ["hd_n9_constants", "hd_n27_constants"])
+def test_non_default_world_constants_teacher_forced(golden, name):
+    """dt, damping, contact force / margin, agent mass and size, episode length away from the defaults
+    (core.py:119-139), set on the World exactly as a reference user would; fixtures from the reference."""
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    w = env.world
+    w.dt, w.damping = float(g["world_dt"]), float(g["world_damping"])
+    w.contact_force, w.contact_margin = float(g["world_contact_force"]), float(g["world_contact_margin"])
+    w.world_length = env.world_length = int(g["world_world_length"])
+    for a in w.agents:
+        a.initial_mass = float(g["world_mass"])
+        a.size = float(g["world_size"])
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        _load(env, prev_pos, prev_vel, g["ideal_shape"], g["ideal_vel"], np.full(B, t))
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        ok = g["cnt_margin"][t] > 1e-5
+        np.testing.assert_allclose(_np(info["individual_reward"])[ok], g["indiv"][t][ok], rtol=0, atol=5 * ATOL)
+        np.testing.assert_allclose(_np(rew)[ok, :, 0], g["shared"][t][ok], rtol=1e-5, atol=5 * ATOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=2 * ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    # the same constants through a K-step rollout launch: bit-identical to single steps
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    acts = torch.as_tensor(g["acts"][:4]).cuda().contiguous()
+    singles = []
+    for t in range(4):
+        o, r, d, _ = env.step(acts[t])
+        singles.append((o.clone(), r.clone(), d.clone()))
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    ro = dict(obs=torch.empty((4, B, N, 6 * N), device="cuda"), reward=torch.empty((4, B, N), device="cuda"),
+              done=torch.zeros((4, B, N), dtype=torch.uint8, device="cuda"))
+    env.scenario.rollout_batch(env.world, acts, ro)
+    for t in range(4):
+        assert torch.equal(ro["obs"][t], singles[t][0])
+        assert torch.equal(ro["reward"][t], singles[t][1][..., 0])
+        assert torch.equal(ro["done"][t].bool(), singles[t][2])
+
+
 def test_motor_noise_is_gaussian_with_the_requested_scale():
     """u_noise (core.py:232-233): device counter RNG, distributional parity only."""
     N, B = 9, 2048

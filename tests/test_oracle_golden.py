@@ -247,6 +247,38 @@ def test_world_options_match_reference(golden, name, opts):
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
 
 
+def _params_from_fixture(g):
+    """HdParams carrying the non-default World constants a `*_constants` fixture was made with."""
+    P = O.HdParams()
+    P.dt = float(g["world_dt"]); P.damping = float(g["world_damping"])
+    P.contact_force = float(g["world_contact_force"]); P.contact_margin = float(g["world_contact_margin"])
+    P.mass = float(g["world_mass"]); P.agent_size = float(g["world_size"]); P.world_length = int(g["world_world_length"])
+    return P
+
+
+@pytest.mark.parametrize("name", ["hd_n9_constants", "hd_n27_constants"])
+def test_non_default_world_constants_match_reference(golden, name):
+    """dt, damping, contact force / margin, agent mass and size, episode length away from the
+    defaults of core.py:119-139 (set on the reference's World before the rollout)."""
+    g = golden(name)
+    P = _params_from_fixture(g)
+    B = g["pos0"].shape[0]
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    assert g["cnt"].sum() > 0 and g["done"].any() and not g["done"].all()
+    for t in range(g["acts"].shape[0]):
+        st = dict(pos=prev_pos, vel=prev_vel, ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"],
+                  step=np.full(B, t, dtype=np.int32))
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64), P)
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["reward"][..., 0], g["shared"][t], rtol=1e-12, atol=1e-10)
+        np.testing.assert_array_equal(out["done"], g["done"][t])
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(out["obs"], g["obs_t%d" % (t + 1)], rtol=0, atol=1e-10)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
 ACT_MODES = [("act_onehot5_n3", O.ACT_ONEHOT5), ("act_index_n9", O.ACT_INDEX), ("act_argmax_n3", O.ACT_ARGMAX)]
 
 
