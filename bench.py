@@ -197,6 +197,7 @@ def main():
         env.seed(int(sharding.global_seeds(1, lo, hi)[0]))      # env b of this rank: 1 + 1000 (lo + b)
         env.reset()
         env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
+        env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device
         env.world.step_count.zero_()
 
         # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
@@ -218,8 +219,8 @@ def main():
                 lo_ = t % P
                 if lo_ + k > P:
                     k = P - lo_
-                env.scenario.rollout_batch(env.world, act_pool[lo_:lo_ + k], {k2: v[:k] for k2, v in seq.items()},
-                                           obs_every=a.obs_every, auto_reset=not a.no_auto_reset, rng_offset=t)
+                env.rollout(act_pool[lo_:lo_ + k], out={k2: v[:k // (a.obs_every if k2 == "obs" else 1)] for k2, v in seq.items()},
+                            obs_every=a.obs_every)
                 t += k
 
         def timed(fn, n, w):

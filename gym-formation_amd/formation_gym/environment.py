@@ -140,6 +140,50 @@ class MultiAgentEnv(object):
             return self._batched_result()
         return self._reference_result()
 
+    def rollout(self, action_seq, out=None, obs_every=1):
+        """K consecutive `step` calls in ONE launch (`fg_rollout_hd`): for policies that hand over a
+        whole action sequence (open-loop / pre-staged random policies, model-predictive candidates).
+        `action_seq` is a [K, B, N, 2] tensor of raw continuous actions.  Results are bit-identical to
+        K calls of `step` (device auto-reset included, when `self.auto_reset` is set) and come back
+        stacked along a leading step axis:
+            obs [K // obs_every, B, N, D]  (every obs_every-th step; obs_every = 1: every step)
+            reward [K, B, N, 1], done [K, B, N] bool, info {'individual_reward': [K, B, N]}
+        `out` may hold pre-allocated buffers (keys obs, reward, indiv, done with those shapes, done as
+        uint8), so that a training loop re-uses them."""
+        roll = getattr(self.scenario, "rollout_batch", None)
+        if roll is None:
+            raise NotImplementedError("%s has no multi-step launch; call step()" % type(self.scenario).__name__)
+        if self._action_mode():
+            raise NotImplementedError("rollout launches take raw continuous actions (discrete action modes: call step())")
+        if self.post_step_callback is not None:
+            raise NotImplementedError("post_step_callback runs on the host after every step; call step()")
+        if not torch.is_tensor(action_seq) or action_seq.dim() != 4 or tuple(action_seq.shape[1:]) != tuple(self._act.shape):
+            raise ValueError("action_seq must be a tensor of shape [K, %d, %d, 2]" % tuple(self._act.shape[:2]))
+        obs_every = int(obs_every)
+        K = int(action_seq.shape[0])
+        if K < 1 or obs_every < 1:
+            raise ValueError("need K >= 1 steps and obs_every >= 1")
+        act = action_seq
+        if act.dtype != torch.float32 or act.device != self._act.device or not act.is_contiguous():
+            act = act.to(device=self._act.device, dtype=torch.float32).contiguous()
+        B, N = self.num_envs, self.num_agents
+        D = self._out["obs"].shape[-1]
+        if out is None:
+            f = dict(dtype=torch.float32, device=self._act.device)
+            out = dict(obs=torch.empty((K // obs_every, B, N, D), **f), reward=torch.empty((K, B, N), **f),
+                       indiv=torch.empty((K, B, N), **f),
+                       done=torch.zeros((K, B, N), dtype=torch.uint8, device=self._act.device))
+        want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N))
+        for k, shp in want.items():
+            if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
+                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
+        roll(self.world, act, out, obs_every=obs_every, auto_reset=self.auto_reset, rng_offset=self._rng_offset + 1)
+        self._rng_offset += K
+        self.current_step += K
+        self.world.world_step += K
+        rew = out["reward"] if self.shared_reward else out["indiv"]
+        return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), {"individual_reward": out["indiv"]}
+
     def _bound_step(self, act):
         """Per-step host work kept to one ctypes call: the scenario resolves every pointer and the
         FgParams struct once (`bind_step`), keyed by everything the binding depends on - action

@@ -548,6 +548,38 @@ def test_non_default_world_constants_teacher_forced(golden, name):
         assert torch.equal(ro["done"][t].bool(), singles[t][2])
 
 
+@pytest.mark.parametrize("N,B,K,every", [(27, 33, 8, 1), (9, 20, 7, 2), (81, 3, 4, 1)])
+def test_env_rollout_api_equals_step_calls(N, B, K, every):
+    """`env.rollout(action_seq)` = K `env.step` calls bit for bit, episode ends and device resets included."""
+    rs = np.random.RandomState(31 + N)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (K, B, N, 2)).astype(np.float32)).cuda()
+    step0 = np.where(np.arange(B) % 2 == 0, 97, 3)
+    a = _make(N, B); _load(a, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], step0)
+    b = _make(N, B); _load(b, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], step0)
+    for e in (a, b):
+        e.scenario.seed(5); e.auto_reset = True
+    obs, rew, done, info = b.rollout(acts, obs_every=every)
+    assert obs.shape == (K // every, B, N, 6 * N) and rew.shape == (K, B, N, 1) and done.dtype == torch.bool
+    for k in range(K):
+        o, r, d, i = a.step(acts[k])
+        if (k + 1) % every == 0:
+            assert torch.equal(o, obs[k // every])
+        assert torch.equal(r, rew[k]) and torch.equal(d, done[k])
+        assert torch.equal(i["individual_reward"], info["individual_reward"][k])
+    assert done.any() and not done.all()
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    assert a.current_step == b.current_step == K and a._rng_offset == b._rng_offset
+    # a second launch continues exactly where K more step calls would
+    acts2 = torch.as_tensor(rs.uniform(-1, 1, (2, B, N, 2)).astype(np.float32)).cuda()
+    o2 = b.rollout(acts2)[0]
+    a.step(acts2[0]); o1 = a.step(acts2[1])[0]
+    assert torch.equal(o1, o2[1])
+    with pytest.raises(ValueError):
+        b.rollout(acts[:, :1])
+
+
 def test_motor_noise_is_gaussian_with_the_requested_scale():
     """u_noise (core.py:232-233): device counter RNG, distributional parity only."""
     N, B = 9, 2048
