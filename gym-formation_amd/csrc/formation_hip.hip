@@ -56,6 +56,17 @@ struct GeomOverride { int t, e; bool set; };
 
 struct Geometry { int G, T, E, lds; };
 
+// Kernels that need more than the default 64 KiB of dynamic LDS opt in once per (kernel, device): the
+// attribute belongs to the device the function is loaded on, and a process may drive several GPUs.
+static void raise_lds_limit(const void* fn, int lds, unsigned long long* done_mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!((*done_mask >> dev) & 1ull)) {
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        *done_mask |= 1ull << dev;
+    }
+}
+
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
@@ -173,9 +184,8 @@ static int launch_wide(Args a, hipStream_t st) {
     {   const int grid = (B + (EV) * a.groups - 1) / ((EV) * a.groups);                                  \
         const int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                              \
         if (lds > 64 * 1024) {   /* more than the default dynamic-LDS limit: opt in (once per kernel) */  \
-            static bool raised = false;                                                                  \
-            if (!raised) { (void)hipFuncSetAttribute((const void*)&rollout_kernel_wide<NCV, AV, EV, TWV>,          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = true; } }      \
+            static unsigned long long raised = 0;                                                        \
+            raise_lds_limit((const void*)&rollout_kernel_wide<NCV, AV, EV, TWV>, lds, &raised); }         \
         hipLaunchKernelGGL((rollout_kernel_wide<NCV, AV, EV, TWV>), dim3(grid), dim3((EV) * 64 + (TWV)), lds, st, a); \
         err = hipGetLastError(); }
     if (N == 81) { if (tw == 128) FG_ROLLW(81, 2, 4, 128) else if (tw == 512) FG_ROLLW(81, 2, 8, 512) else FG_ROLLW(81, 2, 4, 256) }
@@ -222,7 +232,8 @@ int fg_step_hd(const FgParams* params, int B, int N,
                int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !act || !ideal_shape || !ideal_vel || !step || !obs || !reward)
         return fail(FG_ERR_BAD_ARG, "fg_step_hd: a required pointer is NULL%s");
@@ -251,7 +262,8 @@ int fg_physics_step(const FgParams* params, int B, int N,
                     const float* act, void* stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !act)
         return fail(FG_ERR_BAD_ARG, "fg_physics_step: a required pointer is NULL%s");
@@ -269,7 +281,8 @@ int fg_observe_hd(const FgParams* params, int B, int N,
                   int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
         return fail(FG_ERR_BAD_ARG, "fg_observe_hd: a required pointer is NULL%s");
@@ -294,7 +307,8 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
                   int obs_every, void* stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B <= 0 || K <= 0) return fail(FG_ERR_BAD_ARG, "B and K must be > 0%s");
+    if (B == 0 || K == 0) return FG_OK;               // empty batch / zero steps: nothing to do
+    if (B < 0 || K < 0) return fail(FG_ERR_BAD_ARG, "B and K must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !act_seq || !ideal_shape || !ideal_vel || !step || !reward_seq)
         return fail(FG_ERR_BAD_ARG, "fg_rollout_hd: a required pointer is NULL%s");
@@ -336,15 +350,13 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
                 const int tunits = (3 * 27 * 9 + 3) & ~1;
                 const int lds = 16 * roll_block_floats(27) * (int)sizeof(float) + 16 +
                                 ((tw / 64) * 2 + 8) * tunits * (int)sizeof(float2);
-                static bool raised = false;
                 if (tw == 256) {
-                    if (!raised) { (void)hipFuncSetAttribute((const void*)&rollout_kernel<27, 32, 512, 256, 16, 10, true>,
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised = true; }
+                    static unsigned long long raised = 0;
+                    raise_lds_limit((const void*)&rollout_kernel<27, 32, 512, 256, 16, 10, true>, lds, &raised);
                     hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 256, 16, 10, true>), dim3(grid), dim3(768), lds, st, a);
                 } else {
-                    static bool raised2 = false;
-                    if (!raised2) { (void)hipFuncSetAttribute((const void*)&rollout_kernel<27, 32, 512, 128, 16, 10, true>,
-                                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds); raised2 = true; }
+                    static unsigned long long raised2 = 0;
+                    raise_lds_limit((const void*)&rollout_kernel<27, 32, 512, 128, 16, 10, true>, lds, &raised2);
                     hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 128, 16, 10, true>), dim3(grid), dim3(640), lds, st, a);
                 }
                 err = hipGetLastError();
@@ -384,7 +396,8 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
                 float* ideal_shape, float* ideal_vel, int32_t* step, void* stream) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     Geometry g;
     if (!geometry_for(N, &g)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
@@ -419,7 +432,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     if (!sc) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
     const int L = sc->num_landmarks, M = sc->num_obstacles;
     if (sc->kind < FG_SCN_BASIC || sc->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
-    if (B <= 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B and L must be > 0, M >= 0%s");
+    if (B == 0) return FG_OK;
+    if (B < 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B >= 0, L > 0, M >= 0 required%s");
     if (N < 2 || N + M > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 64%s");
     if (sc->kind == FG_SCN_PARTIAL && (sc->num_obs < 0 || sc->num_obs > 1024)) return fail(FG_ERR_BAD_ARG, "bad num_obs%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || (do_physics && (!act || !reward)) ||
@@ -451,7 +465,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
 int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                    float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
-    if (B <= 0) return fail(FG_ERR_BAD_ARG, "B must be > 0%s");
+    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     if (!mt_state || !pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
         return fail(FG_ERR_BAD_ARG, "fg_reset_hd_mt: a required pointer is NULL%s");
@@ -487,7 +502,8 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
 int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream) {
     if (mode != FG_ACT_ONEHOT5 && mode != FG_ACT_INDEX && mode != FG_ACT_ARGMAX)
         return fail(FG_ERR_BAD_ARG, "fg_decode_actions: unknown mode%s");
-    if (count <= 0 || count > ((int64_t)1 << 38)) return fail(FG_ERR_BAD_ARG, "fg_decode_actions: count out of range%s");
+    if (count == 0) return FG_OK;
+    if (count < 0 || count > ((int64_t)1 << 38)) return fail(FG_ERR_BAD_ARG, "fg_decode_actions: count out of range%s");
     if (!action || !u_out) return fail(FG_ERR_BAD_ARG, "fg_decode_actions: a required pointer is NULL%s");
     if (((uintptr_t)u_out & 7) || (mode == FG_ACT_ARGMAX && ((uintptr_t)action & 7)))
         return fail(FG_ERR_ALIGNMENT, "fg_decode_actions: buffers must be 8-byte aligned%s");

@@ -20,6 +20,8 @@
  *     void*, NULL = the default stream); no device synchronisation inside, so
  *     every entry point may be captured into a hipGraph.
  *   - return value: FG_OK (0) or a negative FgStatus; nothing throws or exits.
+ *     An empty batch (B = 0), zero steps (K = 0) or count = 0 is a successful no-op:
+ *     no launch, buffers may be NULL.
  *     fg_last_error() returns a thread-local description of the last failure.
  *   - layouts are env-major and contiguous.  B = number of independent
  *     environments (the data-parallel unit), N = agents per environment.
@@ -50,7 +52,7 @@ extern "C" {
 
 typedef enum FgStatus {
     FG_OK = 0,
-    FG_ERR_BAD_ARG = -1,        /* NULL pointer, B <= 0, K <= 0, bad params            */
+    FG_ERR_BAD_ARG = -1,        /* NULL pointer, B < 0, K < 0, bad params              */
     FG_ERR_UNSUPPORTED_N = -2,  /* N < 2 or N > FG_MAX_AGENTS                          */
     FG_ERR_ALIGNMENT = -3,      /* obs base not 16-byte aligned                        */
     FG_ERR_HIP = -4             /* a HIP runtime call failed (see fg_last_error)       */

@@ -86,8 +86,15 @@ def test_argument_validation_before_any_launch(lib):
     p = buf.ctypes.data          # host pointer: validation must reject before it is ever used
     P = _params()
     ok_ptrs = [p] * 16
-    assert lib.fg_step_hd(P, 0, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG                 # B <= 0
+    assert lib.fg_step_hd(P, -1, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG                # B < 0
     assert b"B must be" in lib.fg_last_error()
+    # an empty batch (B = 0), zero steps (K = 0) and zero agents to decode are successful no-ops, NULL buffers allowed
+    assert lib.fg_step_hd(P, 0, 9, *([None] * 16)) == _native.FG_OK
+    assert lib.fg_physics_step(P, 0, 9, *([None] * 6)) == _native.FG_OK
+    assert lib.fg_rollout_hd(P, 0, 9, 5, *([None] * 12), 1, None) == _native.FG_OK
+    assert lib.fg_rollout_hd(P, 4, 9, 0, *([None] * 12), 1, None) == _native.FG_OK
+    assert lib.fg_reset_hd(P, 0, 9, *([None] * 9)) == _native.FG_OK
+    assert lib.fg_decode_actions(_native.FG_ACT_INDEX, 0, None, None, None) == _native.FG_OK
     assert lib.fg_step_hd(P, 4, 2, *ok_ptrs) == _native.FG_ERR_UNSUPPORTED_N           # obs needs N >= 3
     assert lib.fg_step_hd(P, 4, 2000, *ok_ptrs) == _native.FG_ERR_UNSUPPORTED_N
     null_obs = list(ok_ptrs); null_obs[8] = None
@@ -102,7 +109,7 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_physics_step(P, 4, 1, *([p] * 6)) == _native.FG_ERR_UNSUPPORTED_N
     assert lib.fg_observe_hd(P, 4, 9, p, p, p, p, p, p, p, None, None, None, None, None, None, None, None) \
         == _native.FG_ERR_BAD_ARG                                                      # nothing to write
-    assert lib.fg_rollout_hd(P, 4, 9, 0, *([p] * 12), 1, None) == _native.FG_ERR_BAD_ARG   # K <= 0
+    assert lib.fg_rollout_hd(P, 4, 9, -1, *([p] * 12), 1, None) == _native.FG_ERR_BAD_ARG   # K < 0
     assert lib.fg_reset_hd(P, 4, 5000, *([p] * 9)) == _native.FG_ERR_UNSUPPORTED_N
     assert lib.fg_step_basic(P, 4, 100, 3, 1, *([p] * 13)) == _native.FG_ERR_UNSUPPORTED_N
     sc = _native.FgScenario(kind=_native.FG_SCN_OBSTACLE, num_landmarks=4, num_obstacles=3, penalty=2.0)
@@ -110,11 +117,11 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(0, 12, p, p, None) == _native.FG_ERR_BAD_ARG           # unknown mode
-    assert lib.fg_decode_actions(_native.FG_ACT_INDEX, 0, p, p, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_decode_actions(_native.FG_ACT_INDEX, -3, p, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ARGMAX, 12, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
     with pytest.raises(_native.FormationHipError):
-        _native.check(lib.fg_step_hd(P, 0, 9, *ok_ptrs))
+        _native.check(lib.fg_step_hd(P, -1, 9, *ok_ptrs))
 
 
 def test_no_cpu_fallback(monkeypatch):

@@ -580,6 +580,21 @@ def test_env_rollout_api_equals_step_calls(N, B, K, every):
         b.rollout(acts[:, :1])
 
 
+def test_empty_batch_is_a_noop():
+    """num_envs = 0 (e.g. a rank that owns no envs when the batch is smaller than the world): every call
+    succeeds and returns empty tensors of the right shapes."""
+    N = 9
+    env = _make(N, 0)
+    env.seed(3)
+    obs = env.reset()
+    assert obs.shape == (0, N, 6 * N)
+    o, r, d, i = env.step(torch.zeros((0, N, 2), device="cuda"))
+    assert o.shape == (0, N, 6 * N) and r.shape == (0, N, 1) and d.shape == (0, N) and i["individual_reward"].shape == (0, N)
+    o, r, d, i = env.rollout(torch.zeros((3, 0, N, 2), device="cuda"))
+    assert o.shape == (3, 0, N, 6 * N) and r.shape == (3, 0, N, 1)
+    torch.cuda.synchronize()
+
+
 def test_motor_noise_is_gaussian_with_the_requested_scale():
     """u_noise (core.py:232-233): device counter RNG, distributional parity only."""
     N, B = 9, 2048
