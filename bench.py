@@ -120,6 +120,8 @@ def main():
                     help="tuning aid (rollout mode): write an observation only every n-th step; the JSON line is "
                          "then NOT a valid benchmark result")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    ap.add_argument("--prewarm-ms", type=float, default=150.0,
+                    help="untimed stepping before the W warm-up steps, so that short runs are not measured during the clock ramp")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of the other BASELINE per-GPU shapes (9 x 4096, 81 x 2048, 243 x 8192)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -224,7 +226,17 @@ def main():
                 t += k
 
         def timed(fn, n, w):
-            fn(w, 0)
+            # untimed: bring the GPU to its running clocks first (a short --steps/--warmup pair would otherwise
+            # be measured during the DVFS ramp), then the W warm-up steps the caller asked for
+            t_end = time.perf_counter() + a.prewarm_ms * 1e-3
+            pre = 0
+            while time.perf_counter() < t_end:
+                fn(chunk, pre)
+                pre += chunk
+                if pre % (8 * chunk) == 0:
+                    torch.cuda.synchronize()
+            fn(w, pre)
+            w += pre
             barrier()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
