@@ -227,6 +227,38 @@ __global__ __launch_bounds__(T) void k_expand(const f32x2* __restrict__ tables, 
     }
 }
 
+
+// paced variants: does spacing a wave's store instructions (s_sleep) change what the memory system delivers?
+template <int SLEEP>
+__global__ void k_roll_paced(char* out, int K, int mode) {
+    const int nw = blockDim.x >> 6, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    constexpr unsigned SPAN = 16 * 17496, SPAN16 = SPAN / 16;
+    for (int k = 0; k < K; ++k) {
+        f32x4* span = reinterpret_cast<f32x4*>(out + ((size_t)k * gridDim.x + blockIdx.x) * SPAN);
+        if (mode == 0) {
+            for (int e = w; e < 16; e += nw) {
+                char* eb = reinterpret_cast<char*>(span) + (size_t)e * 17496;
+                const int head = (e & 1) ? 8 : 0;
+                if (head && lane == 0) *reinterpret_cast<f32x2*>(eb) = f32x2{1.f, 2.f};
+                f32x4* d = reinterpret_cast<f32x4*>(eb + head);
+                const unsigned n16 = (17496 - head) / 16;
+                for (unsigned q = lane; q < n16; q += 64) { d[q] = v; if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP); }
+                if (((17496 - head) & 8) && lane == 63) *reinterpret_cast<f32x2*>(eb + head + n16 * 16) = f32x2{1.f, 2.f};
+            }
+        } else if (mode == 1) {
+            const unsigned pieces = (SPAN16 + 63) / 64;
+            const unsigned per = (pieces + nw - 1) / nw;
+            const unsigned q0 = w * per * 64, q1 = min((w + 1) * per * 64, SPAN16);
+            for (unsigned q = q0 + lane; q < q1; q += 64) { span[q] = v; if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP); }
+        } else {
+            const unsigned run = 256;
+            for (unsigned r0 = w * run; r0 < SPAN16; r0 += nw * run)
+                for (unsigned q = r0 + lane; q < min(r0 + run, SPAN16); q += 64) { span[q] = v; if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP); }
+        }
+    }
+}
+
 static float time_it(std::function<void()> fn, int rep) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -370,6 +402,28 @@ int main(int argc, char** argv) {
         }
         CHECK(hipFree(tables));
     }
+
+    printf("-- paced store issue (s_sleep n = 64 n cycles after every 1 KiB store instruction), 256 WGs, 20 steps\n");
+    for (int pass = 0; pass < 2; ++pass)
+        for (int nw : {4, 8})
+            for (int mode : {0, 1, 2}) {
+                static const char* mn[] = {"whole envs per wave (today)", "one contiguous aligned share per wave", "aligned 4 KiB runs interleaved"};
+                char nm[200];
+#define PACED(SL) snprintf(nm, sizeof nm, "paced: %d waves, %s, s_sleep %d (pass %d)", nw, mn[mode], SL, pass); \
+                report(nm, time_it([&] { hipLaunchKernelGGL(k_roll_paced<SL>, dim3(256), dim3(nw * 64), 0, 0, buf, K, mode); }, 30), bytes);
+                PACED(0) PACED(1) PACED(2) PACED(3) PACED(4) PACED(6)
+#undef PACED
+            }
+
+    printf("-- head to head: the same addresses from two kernels (k_chunks vs k_roll mode 2), alternating\n");
+    for (int pass = 0; pass < 3; ++pass)
+        for (int nw : {4, 8}) {
+            char nm[200];
+            snprintf(nm, sizeof nm, "h2h k_chunks chunk 279936 pieces 4096, %d waves (pass %d)", nw, pass);
+            report(nm, time_it([&] { hipLaunchKernelGGL(k_chunks, dim3(256), dim3(nw * 64), 0, 0, buf, bytes, (size_t)279936, 4096); }, 30), bytes);
+            snprintf(nm, sizeof nm, "h2h k_roll mode 2 (aligned 4 KiB runs), %d waves (pass %d)", nw, pass);
+            report(nm, time_it([&] { hipLaunchKernelGGL(k_roll, dim3(256), dim3(nw * 64), 0, 0, buf, K, 2); }, 30), bytes);
+        }
     CHECK(hipDeviceSynchronize());
     CHECK(hipFree(buf));
     return 0;
