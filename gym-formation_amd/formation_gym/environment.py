@@ -81,13 +81,21 @@ class MultiAgentEnv(object):
         B, N = self.num_envs, self.num_agents
         dev = world.device
         f = dict(dtype=torch.float32, device=dev)
+        # the four per-step outputs are views of ONE allocation, so that the reference-style API
+        # (num_envs == 1: NumPy lists in and out) brings a whole step back in a single device-to-host copy
+        n_obs, n_bn = B * N * obs_dim, B * N
+        self._flat = torch.zeros(n_obs + 2 * n_bn + (n_bn + 3) // 4, **f)
         self._out = dict(
-            obs=torch.empty((B, N, obs_dim), **f),
-            reward=torch.empty((B, N), **f),
-            indiv=torch.empty((B, N), **f),
-            done=torch.zeros((B, N), dtype=torch.uint8, device=dev),
+            obs=self._flat[:n_obs].view(B, N, obs_dim),
+            reward=self._flat[n_obs:n_obs + n_bn].view(B, N),
+            indiv=self._flat[n_obs + n_bn:n_obs + 2 * n_bn].view(B, N),
+            done=self._flat[n_obs + 2 * n_bn:].view(torch.uint8)[:n_bn].view(B, N),
         )
         self._act = torch.zeros((B, N, 2), **f)
+        self._host = self._act_host = None
+        if B == 1 and torch.device(dev).type == "cuda":       # pinned mirrors for the single-env list API
+            self._host = torch.empty(self._flat.shape, dtype=torch.float32).pin_memory()
+            self._act_host = torch.zeros((1, N, 2), dtype=torch.float32).pin_memory()
         self._launchers = {}              # pre-bound step launches, see _bound_step
         self.shared_viewer = shared_viewer
         self.viewers = [None]
@@ -258,7 +266,8 @@ class MultiAgentEnv(object):
             raise ValueError("a list of per-agent actions needs num_envs == 1; pass a [B,N,2] tensor")
         if len(action_n) != self.num_agents:
             raise ValueError("expected %d agent actions, got %d" % (self.num_agents, len(action_n)))
-        host = np.empty((1, self.num_agents, 2), dtype=np.float32)
+        pinned = self._act_host is not None
+        host = self._act_host.numpy() if pinned else np.empty((1, self.num_agents, 2), dtype=np.float32)
         for i, (a, agent) in enumerate(zip(action_n, self.agents)):
             if isinstance(a, (list, tuple)):
                 # the reference fails at `agent.action.u *= sensitivity` (:221)
@@ -267,7 +276,10 @@ class MultiAgentEnv(object):
             host[0, i] = a[0:2]
             sens = agent.accel if agent.accel is not None else 5.0
             a[0:2] *= sens            # the reference scales the caller's array in place (:216,:221)
-        self._act.copy_(torch.from_numpy(host))
+        if pinned:         # the previous step's copy has completed: every reference-style step ends with a stream sync
+            self._act.copy_(self._act_host, non_blocking=True)
+        else:
+            self._act.copy_(torch.from_numpy(host))
         return self._act
 
     def _batched_result(self):
@@ -279,11 +291,21 @@ class MultiAgentEnv(object):
 
     def _reference_result(self):
         o = self._out
-        obs = o["obs"][0].double().cpu().numpy()
-        indiv = o["indiv"][0].double().cpu().numpy()
-        shared = float(o["reward"][0, 0].double().cpu())
-        done = bool(o["done"][0, 0].cpu())
         N = self.num_agents
+        if self._host is not None:        # one pinned device-to-host copy + one stream sync for the whole step
+            self._host.copy_(self._flat, non_blocking=True)
+            torch.cuda.current_stream(self._flat.device).synchronize()
+            h = self._host.numpy()
+            n_obs = o["obs"].numel()
+            obs = h[:n_obs].reshape(N, -1).astype(np.float64)
+            shared = float(h[n_obs])
+            indiv = h[n_obs + N:n_obs + 2 * N].astype(np.float64)
+            done = bool(h[n_obs + 2 * N:].view(np.uint8)[0])
+        else:
+            obs = o["obs"][0].double().cpu().numpy()
+            indiv = o["indiv"][0].double().cpu().numpy()
+            shared = float(o["reward"][0, 0].double().cpu())
+            done = bool(o["done"][0, 0].cpu())
         obs_n = [obs[i] for i in range(N)]
         if self.shared_reward:
             reward_n = [[shared]] * N                     # :136-138
