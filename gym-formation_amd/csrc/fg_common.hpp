@@ -48,7 +48,6 @@ struct Args {
     FgParams p;
     int B, N, K, obs_every;
     int do_phys, do_post;
-    int strided;               // rollout_kernel (N <= 32): envs dealt round-robin over the workgroups
     int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
     int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)
     float* px; float* py; float* vx; float* vy;

@@ -126,10 +126,7 @@ template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 +
 // `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
 template <int NC, int NW, int E, int RT>
 FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
-                            float2* __restrict__ out_env0, size_t unit0, int El,
-                            size_t out_env_stride = (size_t)(3 * NC * NC)) {
-    // out_env_stride: distance (units) between the blocks of consecutive envs of the group
-    // (3 N^2 = contiguous group; grid * 3 N^2 = envs dealt round-robin over the workgroups)
+                            float2* __restrict__ out_env0, size_t unit0, int El) {
     constexpr int N = NC;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
@@ -168,7 +165,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             Pu = lds_if(act && u >= 1, AA, u);
             sv = lds_if(ssub < RS, AA, N + sidx);
         }
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * out_env_stride + (size_t)r0 * ROWU) & 1);
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
         float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;     // no restrict: the two tiles alternate
 #pragma unroll
         for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
@@ -189,9 +186,9 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     auto stream = [&](int t) {
         int ee, r0; locate(t, ee, r0);
         if (r0 >= N) return;
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * out_env_stride + (size_t)r0 * ROWU) & 1);
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
         const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
-        float2* __restrict__ out = out_env0 + (size_t)ee * out_env_stride + (size_t)r0 * ROWU;
+        float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
         if (par && lane == 0) out[0] = img[0];
         constexpr unsigned NPMAX = TU >> 1;
         const unsigned npair = (TU - par) >> 1;

@@ -37,16 +37,13 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     const bool producer = tid < TP;
     const int e = producer ? tid / G : 0;
     const int i = tid % G;
-    // env -> workgroup mapping: blocked (envs b0 .. b0+E-1) or, with `strided`, dealt round-robin
-    // (env = block + e * grid): then all workgroups write neighbouring env blocks at the same time
-    // and the chip-wide store stream sweeps each observation slot like one linear copy.
-    const bool strided = a.strided != 0;
-    const int b0 = strided ? (int)blockIdx.x : (int)blockIdx.x * E;
-    const int b = strided ? (int)(blockIdx.x + e * gridDim.x) : b0 + e;
+    // env -> workgroup mapping: blocked (envs b0 .. b0+E-1), one contiguous span of observations per workgroup
+    // (dealing envs round-robin over the workgroups was measured slower and is gone: profiles/README.md)
+    const int b0 = (int)blockIdx.x * E;
+    const int b = b0 + e;
     const bool env_ok = producer && (b < a.B);
     const bool valid = env_ok && (i < N);
-    const int El = strided ? min(E, (a.B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x) : min(E, a.B - b0);
-    const size_t out_stride = (size_t)(strided ? gridDim.x : 1) * (size_t)(3 * NC * NC);
+    const int El = min(E, a.B - b0);
     float* const blk = smemf + e * roll_block_floats(N);
     float2* const TB0 = reinterpret_cast<float2*>(blk);                 // tables of buffer 0; buffer 1 at + 5N
     float* const QX = blk + 20 * N;
@@ -208,7 +205,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                         reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
-                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El, out_stride);
+                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
             }
         }
         if (!(FG_PROBES && a.probe == 2)) __syncthreads();                    // probe 2: no hand-over sync

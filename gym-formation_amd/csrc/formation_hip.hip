@@ -325,7 +325,6 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
     if (K >= 2 && !nopipe && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
     if (K >= 2 && !nopipe && (N == 27 || N == 9 || N == 3)) {
-        FG_OVERRIDE(a.strided, "FG_STRIDED");
         int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
         FG_OVERRIDE(tw, "FG_TW");
         hipStream_t st = (hipStream_t)stream;
