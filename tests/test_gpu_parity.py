@@ -471,6 +471,23 @@ def test_bench_json_contract_single_and_two_ranks():
     assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 2
 
 
+def test_c_abi_from_plain_cpp_without_python_or_torch(tmp_path):
+    """examples/c_abi_rollout.cpp: hipMalloc'd buffers, the caller's stream, fg_reset_hd / fg_observe_hd /
+    fg_rollout_hd / fg_step_hd through the header alone; checks its own results and prints throughput."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "gym-formation_amd", "lib")
+    exe = str(tmp_path / "c_abi_rollout")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_abi_rollout.cpp"), "-L", lib, "-lformation_hip",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True, capture_output=True, timeout=600)
+    for args in (["9", "512", "100"], ["27", "256", "60"], ["10", "64", "40"]):
+        out = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert "sanity ok" in out.stdout and "fg_rollout_hd" in out.stdout and "fg_step_hd" in out.stdout
+
+
 def test_demo_driver_runs():
     out = _run(["gym-formation_amd/demo.py", "-n", "3", "--num-layer", "2", "--num-envs", "64", "--steps", "120"])
     assert "env-steps/s" in out
