@@ -308,6 +308,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "formation_hd_env, %d agents x %d envs per GPU, random policy, "
                                    "episode 100 with device auto-reset" % (N, B),
+                       "baseline_config": "BASELINE.json configs[2] (27 agents x 4096 envs, the shape the north-star target "
+                                          "is quoted on); configs[1] and the per-GPU shapes of configs[3], configs[4] are "
+                                          "under other_configs at N = 1" if (N, B) == (27, 4096) else "custom shape",
                        "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
                        "timing_barrier": sync_backend,
