@@ -243,8 +243,10 @@ def main():
             ev0.record()
             fn(n, w)
             ev1.record()
+            while not ev1.query():                             # completion seen by polling the closing event: the clock
+                pass                                           # is read when the K steps are done, not when a blocked
+            wall = time.perf_counter() - t0                    # host thread has been woken up; start barrier -> local completion
             torch.cuda.synchronize()
-            wall = time.perf_counter() - t0                    # this rank's steps, start barrier -> local completion
             barrier()
             dev_ms = ev0.elapsed_time(ev1)
             wall = sharding.max_over_ranks(wall, red_dev, sync_group)          # slowest rank
