@@ -74,6 +74,14 @@ class FormationVecEnv(object):
                 obs = self.env._out["obs"]
         return obs, rew, done, info
 
+    def rollout(self, action_seq, out=None, obs_every=1):
+        """K vec-env steps in ONE launch (`env.rollout`): action_seq [K,B,N,2] -> obs [K//obs_every,B,N,D],
+        rews [K,B,N,1], dones [K,B,N], infos.  Episodes that end inside the launch restart on the device
+        exactly as K `step` calls would ('device' reset mode only: the other modes reset between launches)."""
+        if self.reset_mode != "device":
+            raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
+        return self.env.rollout(action_seq, out=out, obs_every=obs_every)
+
     def step_async(self, actions):
         self._pending = self.step(actions)
 

@@ -595,6 +595,17 @@ def test_env_rollout_api_equals_step_calls(N, B, K, every):
     assert torch.equal(o1, o2[1])
     with pytest.raises(ValueError):
         b.rollout(acts[:, :1])
+    # the vec-env adapter exposes the same launch
+    from formation_gym.vec_env import FormationVecEnv
+    va, vb = FormationVecEnv(_make(N, B)), FormationVecEnv(_make(N, B))
+    for e in (va, vb):
+        e.env.seed(9); e.reset(); e.env.scenario.seed(4)
+    o_seq, r_seq, d_seq, _ = vb.rollout(acts)
+    for k in range(K):
+        o, r, d, _ = va.step(acts[k])
+        assert torch.equal(o, o_seq[k]) and torch.equal(r, r_seq[k]) and torch.equal(d, d_seq[k])
+    with pytest.raises(NotImplementedError):
+        FormationVecEnv(_make(N, B), reset_mode="host").rollout(acts)
 
 
 def test_empty_batch_is_a_noop():
