@@ -623,6 +623,32 @@ def test_empty_batch_is_a_noop():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("N,B,K,L", [(27, 20, 47, 11), (9, 37, 60, 7), (81, 3, 23, 6), (3, 50, 64, 5)])
+def test_one_launch_spanning_several_episodes(N, B, K, L):
+    """K > several episode lengths: every env restarts more than once INSIDE one rollout launch; obs, rewards,
+    dones and the reset draws equal K single-step launches bit for bit, and done fires exactly every L steps."""
+    rs = np.random.RandomState(77 + N)
+    st = O.reset_hd(rs.randint(0, 10000, B), N)
+    acts = torch.as_tensor(rs.uniform(-1, 1, (K, B, N, 2)).astype(np.float32)).cuda()
+    step0 = rs.randint(0, L, B)
+    envs = []
+    for _ in range(2):
+        e = _make(N, B)
+        e.world.world_length = e.world_length = L
+        _load(e, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], step0)
+        e.scenario.seed(21); e.auto_reset = True
+        envs.append(e)
+    a, b = envs
+    obs, rew, done, info = b.rollout(acts)
+    for k in range(K):
+        o, r, d, i = a.step(acts[k])
+        assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k])
+    want_done = ((step0[None, :] + 1 + np.arange(K)[:, None]) % L) == 0          # [K, B]
+    np.testing.assert_array_equal(done[:, :, 0].cpu().numpy(), want_done)
+    assert want_done.sum(0).min() >= 2                                           # every env restarted at least twice
+    assert torch.equal(a.scenario.ideal_shape, b.scenario.ideal_shape) and torch.equal(a.world.step_count, b.world.step_count)
+
+
 def test_motor_noise_is_gaussian_with_the_requested_scale():
     """u_noise (core.py:232-233): device counter RNG, distributional parity only."""
     N, B = 9, 2048
