@@ -730,6 +730,48 @@ def test_generic_agent_counts_against_oracle(N, B):
     assert not done.any() and (env.world.step_count == 1).all()
 
 
+def test_randomised_shapes_and_constants_against_oracle():
+    """A seeded sweep over agent counts (specialised and run-time N), batch sizes, crowding and World constants,
+    three free-running steps each, against the fp64 oracle with the same constants."""
+    rs = np.random.RandomState(2024)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    for case in range(24):
+        N = int(rs.choice([3, 4, 5, 7, 9, 12, 16, 20, 27, 31, 40, 64, 81, 90]))
+        B = int(rs.randint(1, 24))
+        P = O.HdParams()
+        P.dt = float(rs.uniform(0.03, 0.2)); P.damping = float(rs.uniform(0.05, 0.6))
+        P.contact_force = float(rs.uniform(30, 200)); P.contact_margin = float(rs.uniform(5e-4, 5e-3))
+        P.mass = float(rs.uniform(0.5, 3.0)); P.agent_size = float(rs.uniform(0.02, 0.1))
+        P.world_length = int(rs.randint(2, 6))
+        st = O.reset_hd(rs.randint(0, 100000, B), N)
+        st["pos"] *= rs.uniform(0.2, 1.0)
+        st["vel"] = rs.uniform(-0.5, 0.5, (B, N, 2))
+        st = {k: (f32(v) if v.dtype != np.int32 else v) for k, v in st.items()}
+        env = _make(N, B)
+        w = env.world
+        w.dt, w.damping, w.contact_force, w.contact_margin = P.dt, P.damping, P.contact_force, P.contact_margin
+        w.world_length = env.world_length = P.world_length
+        for a in w.agents:
+            a.initial_mass, a.size = P.mass, P.agent_size
+        _load(env, st["pos"], st["vel"], st["ideal_shape"], st["ideal_vel"], st["step"])
+        for t in range(3):
+            act = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+            obs, rew, done, info = env.step(torch.as_tensor(act).cuda())
+            st, out = O.step_hd(st, act.astype(np.float64), P)
+            pos, vel = (_np(x) for x in env.world.get_state())
+            scale = max(1.0, float(np.abs(st["vel"]).max()))
+            msg = "case %d N=%d B=%d t=%d" % (case, N, B, t)
+            np.testing.assert_allclose(pos, st["pos"], rtol=0, atol=ATOL * scale, err_msg=msg)
+            np.testing.assert_allclose(vel, st["vel"], rtol=0, atol=10 * ATOL * scale, err_msg=msg)
+            r = O.reward_hd(pos, vel, st["ideal_shape"], st["ideal_vel"], P)       # on the GPU's own fp32 state
+            ok = r["cnt_margin"] > 1e-6
+            np.testing.assert_allclose(_np(info["individual_reward"])[ok], r["indiv"][ok], rtol=0, atol=ATOL * scale, err_msg=msg)
+            np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=1e-5, atol=ATOL * scale, err_msg=msg)
+            np.testing.assert_allclose(_np(obs), O.observation_hd(pos, vel, st["ideal_shape"], st["ideal_vel"]), rtol=0, atol=5e-7 * scale, err_msg=msg)
+            np.testing.assert_array_equal(done.cpu().numpy(), out["done"], err_msg=msg)
+            st = dict(st, pos=pos, vel=vel)            # continue from the GPU's state: one-step comparisons, no chaotic drift
+
+
 def test_entry_points_are_graph_capturable():
     """The C ABI enqueues on the caller's stream and never synchronises or allocates, so a
     sequence of env steps can be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
