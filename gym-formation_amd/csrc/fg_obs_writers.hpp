@@ -91,8 +91,12 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             }
 #pragma unroll
             for (int c = 0; c < CS; ++c) sv[c] = lds_if(lane + 64 * c < 2 * N, AA, N + lane + 64 * c);
+            // the WPE waves that share an env take contiguous row ranges (one contiguous run of the observation
+            // block per wave; every WPE-th row measured 2-3 % slower at 81 x 2048, profiles/README.md)
+            constexpr int PER = (N + WPE - 1) / WPE;
+            const int r_end = min(N, (row0 + 1) * PER);
 #pragma unroll 2
-            for (int r = row0; r < N; r += WPE) {
+            for (int r = row0 * PER; r < r_end; ++r) {
                 const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
                 const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
                 float2* __restrict__ orow = out + (unsigned)r * ROWU;
