@@ -192,11 +192,10 @@ def main():
     def measure(N, B, mode, steps, warmup, chunk_req, other_steps):
         """Times `steps` env steps of N agents x B envs per GPU in `mode` (and, if other_steps > 0, the
         other launch mode beside it).  Returns wall seconds and HIP-event milliseconds, MAX over ranks."""
-        env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
         # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
         # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
-        lo, hi = sharding.env_slice(B * world_size, rank, world_size)
-        env.seed(int(sharding.global_seeds(1, lo, hi)[0]))      # env b of this rank: 1 + 1000 (lo + b)
+        env, lo, hi = sharding.make_env_shard("formation_hd_env", N, B * world_size, seed=1, rank=rank,
+                                              world_size=world_size, local_rank=local_rank)
         env.reset()
         env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
         env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device

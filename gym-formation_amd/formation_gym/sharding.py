@@ -29,6 +29,25 @@ def global_seeds(seed, lo, hi):
     return int(seed) + 1000 * np.arange(lo, hi, dtype=np.int64)
 
 
+def make_env_shard(scenario_name, num_agents, global_envs, seed=1, rank=None, world_size=None, local_rank=None,
+                   **scenario_kwargs):
+    """This rank's slice of a batch of `global_envs` environments, on this rank's GPU: one process per GPU
+    (rank / world size / local rank from the launcher's RANK, WORLD_SIZE, LOCAL_RANK unless given).  Env g of
+    the GLOBAL batch draws its reset stream from `seed + 1000 g` wherever it lives, so results do not depend
+    on the number of GPUs.  Returns (env, lo, hi): the env owns global envs [lo, hi)."""
+    import os
+    import formation_gym
+    rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if local_rank is None else int(local_rank)
+    lo, hi = env_slice(global_envs, rank, world_size)
+    ndev = max(1, torch.cuda.device_count())
+    env = formation_gym.make_env(scenario_name, False, num_agents, num_envs=hi - lo,
+                                 device=torch.device("cuda", local_rank % ndev), **scenario_kwargs)
+    env.seed(int(seed) + 1000 * lo)              # env b of this rank: seed + 1000 (lo + b)
+    return env, lo, hi
+
+
 def max_over_ranks(value, device=None, group=None):
     """MAX of a python float over all ranks (the bench's slowest-rank time).  `group` / `device`:
     the process group to reduce over and the device its backend wants the tensor on (RCCL: the GPU)."""

@@ -488,6 +488,27 @@ def test_c_abi_from_plain_cpp_without_python_or_torch(tmp_path):
         assert "sanity ok" in out.stdout and "fg_rollout_hd" in out.stdout and "fg_step_hd" in out.stdout
 
 
+def test_env_shards_reproduce_the_global_batch():
+    """sharding.make_env_shard: the slices of 2 and of 3 ranks (sizes differ by one) concatenate to exactly what
+    one process with the whole batch computes - reset streams follow the GLOBAL env index."""
+    from formation_gym import sharding
+    N, G = 9, 11
+    whole, lo, hi = sharding.make_env_shard("formation_hd_env", N, G, seed=5, rank=0, world_size=1, local_rank=0)
+    assert (lo, hi) == (0, G)
+    obs_w = whole.reset().clone()
+    act = torch.rand((G, N, 2), device="cuda") * 2 - 1
+    step_w = [t.clone() for t in whole.step(act)[:3]]
+    for world in (2, 3):
+        parts = [sharding.make_env_shard("formation_hd_env", N, G, seed=5, rank=r, world_size=world, local_rank=0)
+                 for r in range(world)]
+        assert [p[1] for p in parts] + [G] == [p[1] for p in parts][:1] + [p[2] for p in parts]      # contiguous cover
+        obs = torch.cat([e.reset() for e, _, _ in parts])
+        assert torch.equal(obs, obs_w)
+        outs = [e.step(act[l:h].contiguous())[:3] for e, l, h in parts]
+        for k in range(3):
+            assert torch.equal(torch.cat([o[k] for o in outs]), step_w[k])
+
+
 def test_demo_driver_runs():
     out = _run(["gym-formation_amd/demo.py", "-n", "3", "--num-layer", "2", "--num-envs", "64", "--steps", "120"])
     assert "env-steps/s" in out
