@@ -10,7 +10,9 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 #   v_log_f32, ~1 ulp) without the math library's fix-up code for denormal-range arguments and results.  On this path a
 #   denormal can only be exp(-|x|) of a pair far outside contact (a penetration below 1e-38).  NaN / inf behaviour is
 #   untouched (no -ffinite-math-only): coincident agents still give NaN as in core.py:312.  9 x 4096 rollout: -11 %.
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -fapprox-func -fPIC -shared \
+# -amdgpu-kernarg-preload-count=16: the first 16 dwords of a kernel's arguments arrive in SGPRs at wave start
+#   (fg::step_kernel lists its state pointers first for this; see fg_step_kernel.hpp).
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -fapprox-func -mllvm -amdgpu-kernarg-preload-count=16 -fPIC -shared \
     -I"$ROOT/include" ${FG_EXTRA_FLAGS:-} \
     -o "$OUT/libformation_hip.so" "$HERE/formation_hip.hip"
 echo "built $OUT/libformation_hip.so"

@@ -22,21 +22,28 @@ namespace fg {
 #define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
 #endif
 template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
-__global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) void step_kernel(const Args a) {
+__global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1)
+void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre_px, const float* __restrict__ pre_py,
+                 const float* __restrict__ pre_vx, const float* __restrict__ pre_vy, const float* __restrict__ pre_shape,
+                 const float* __restrict__ pre_ivel, const int32_t* __restrict__ pre_step, const Args a) {
+    // The leading scalar arguments repeat what phase 1 needs (batch size, agent count, state pointers): with
+    // -amdgpu-kernarg-preload-count=16 the command processor hands them over in SGPRs at wave start, so the state
+    // loads go out at once instead of behind a cold s_load of the argument block (one memory round trip off the
+    // launch -> first-store chain of a single-step launch).  Everything else is read from `a` as before.
     // OPTS: World options no reference scenario enables (accel, max_speed, u_noise, walls);
     // compiled into a separate instantiation so that the common path keeps its registers.
     constexpr bool FLAT = (WR == 1);
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    const int N = NC ? NC : a.N;
+    const int N = NC ? NC : pre_N;
     const int tid = threadIdx.x;
     const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
     const int i = (E == 1) ? tid : tid % G;
     const int b0 = blockIdx.x * E;
     const int b = b0 + e;
-    const bool env_ok = (e < E) && (b < a.B);     // this thread's lane group owns a live env
+    const bool env_ok = (e < E) && (b < pre_B);   // this thread's lane group owns a live env
     const bool valid = env_ok && (i < N);
-    const int El = min(E, a.B - b0);
+    const int El = min(E, pre_B - b0);
 
     const int NP = npad(N);
     constexpr int NPS = (NC > 0 && npad(NC > 0 ? NC : 1) <= 16) ? npad(NC > 0 ? NC : 1) : 0;   // small N: partners fetched up front
@@ -64,21 +71,21 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
     int t_step = 0;
     const size_t sidx = (size_t)b * N + i;
     if (valid) {
-        p = make_float2(a.px[sidx], a.py[sidx]);
-        v = make_float2(a.vx[sidx], a.vy[sidx]);
+        p = make_float2(pre_px[sidx], pre_py[sidx]);
+        v = make_float2(pre_vx[sidx], pre_vy[sidx]);
         A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
         QX[i] = p.x; QY[i] = p.y; PX[i] = p.x; PY[i] = p.y;
         if (a.do_post) {
-            s = reinterpret_cast<const float2*>(a.shape)[sidx];
+            s = reinterpret_cast<const float2*>(pre_shape)[sidx];
             A[2 * N - 1 + i] = s;
             SX[i] = s.x; SY[i] = s.y;
             if (i < N - 1) A[N + i] = make_float2(0.f, 0.f);
-            if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(a.ivel)[b];
+            if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(pre_ivel)[b];
         }
     } else if (env_ok && i < NP) {              // sentinel partners of the packed pair loops
         QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
     }
-    if (env_ok && a.step) t_step = a.step[b];
+    if (env_ok && pre_step) t_step = pre_step[b];
     if (tid < 2) reset_flag[tid] = 0;
     __syncthreads();
 
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
         // ---- phase 2: World.step ------------------------------------------
         if (a.do_phys) {
             if (valid) {
-                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * pre_B + b) * N + i];
                 float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
             const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
             const bool is_done = t_step >= a.p.world_length;
             if (valid) {
-                const size_t o = ((size_t)k * a.B + b) * N + i;
+                const size_t o = ((size_t)k * pre_B + b) * N + i;
                 if (a.rew) a.rew[o] = shared;
                 if (a.indiv) a.indiv[o] = indiv;
                 if (a.done) a.done[o] = is_done ? 1 : 0;
@@ -196,9 +203,9 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
                 if constexpr (NC > 0 && WR == 0)
                     write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
                                                   reinterpret_cast<float2*>(a.obs) +
-                                                  ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC), El, 3);
+                                                  ((size_t)slot * pre_B + b0) * (size_t)(3 * NC * NC), El, 3);
                 if constexpr (NC > 0 && WR >= 2) {
-                    const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                    const size_t unit0 = ((size_t)slot * pre_B + b0) * (size_t)(3 * NC * NC);
                     float2* tiles = env_tables(smem, E, N) + 36;            // after env blocks + 72 floats of scratch
                     write_obs_tiled<NC, T / 64, E, WR - 2 + 1>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6, tiles,
                                                                reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1) 
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows
-                const size_t U0 = ((size_t)slot * a.B + b0) * nenv;
+                const size_t U0 = ((size_t)slot * pre_B + b0) * nenv;
                 const unsigned total = (unsigned)El * nenv;
                 const unsigned head = (unsigned)(U0 & 1);  // region start not 16-byte aligned
                 float2* const out2 = reinterpret_cast<float2*>(a.obs) + U0;

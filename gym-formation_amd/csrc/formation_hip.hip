@@ -71,7 +71,9 @@ static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
 template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR, OPTS>), dim3(grid), dim3(T), lds, st, a);
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR, OPTS>), dim3(grid), dim3(T), lds, st,
+                       a.B, a.N, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
+                       (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
     return hipGetLastError();
 }
 
