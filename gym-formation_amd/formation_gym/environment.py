@@ -97,6 +97,7 @@ class MultiAgentEnv(object):
             self._host = torch.empty(self._flat.shape, dtype=torch.float32).pin_memory()
             self._act_host = torch.zeros((1, N, 2), dtype=torch.float32).pin_memory()
         self._launchers = {}              # pre-bound step launches, see _bound_step
+        self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -176,16 +177,37 @@ class MultiAgentEnv(object):
             act = act.to(device=self._act.device, dtype=torch.float32).contiguous()
         B, N = self.num_envs, self.num_agents
         D = self._out["obs"].shape[-1]
+        own_buffers = out is not None
         if out is None:
             f = dict(dtype=torch.float32, device=self._act.device)
             out = dict(obs=torch.empty((K // obs_every, B, N, D), **f), reward=torch.empty((K, B, N), **f),
                        indiv=torch.empty((K, B, N), **f),
                        done=torch.zeros((K, B, N), dtype=torch.uint8, device=self._act.device))
-        want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N))
-        for k, shp in want.items():
-            if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
-                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
-        roll(self.world, act, out, obs_every=obs_every, auto_reset=self.auto_reset, rng_offset=self._rng_offset + 1)
+        # launches into CALLER-OWNED buffers are bound once per (actions, buffers, stream, constants): a training
+        # loop that re-uses its buffers pays one ctypes call per launch (cf. _bound_step).  A binding keeps its
+        # tensors alive (their addresses are baked in), so the cache is small and skips internally allocated outputs.
+        bind = getattr(self.scenario, "bind_rollout", None)
+        key = None
+        if own_buffers and bind is not None and all(k in out for k in ("obs", "reward", "indiv", "done")):
+            key = ("roll", act.data_ptr(), K, out["obs"].data_ptr(), out["reward"].data_ptr(), out["indiv"].data_ptr(),
+                   out["done"].data_ptr(), obs_every, self.auto_reset, _native.current_stream_fast(self.world.device),
+                   self.world.params_signature(), getattr(self.scenario, "_seed", 0))
+        launch = self._roll_launchers.get(key) if key is not None else None
+        if launch is None:
+            want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N))
+            for k, shp in want.items():
+                if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
+                    raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
+            if key is not None:
+                if len(self._roll_launchers) >= 8:
+                    self._roll_launchers.clear()
+                launch = self._roll_launchers[key] = bind(self.world, act, out, obs_every=obs_every,
+                                                          auto_reset=self.auto_reset)
+        if launch is not None:
+            launch(self._rng_offset + 1)
+            self.scenario._cache = None
+        else:
+            roll(self.world, act, out, obs_every=obs_every, auto_reset=self.auto_reset, rng_offset=self._rng_offset + 1)
         self._rng_offset += K
         self.current_step += K
         self.world.world_step += K

@@ -168,6 +168,29 @@ class Scenario(BaseScenario):
             _native.ptr(out.get("done")), int(obs_every), _native.current_stream()))
         self._cache = None
 
+    def bind_rollout(self, world, act_seq, out, obs_every=1, auto_reset=False):
+        """`rollout_batch` with every pointer and the FgParams struct resolved once: returns
+        `launch(rng_offset)`, one ctypes call per K-step launch (a 9 x 4096 launch lasts ~35 us on the GPU,
+        less than the generic path spends in Python)."""
+        lib = _native.load()
+        p = self.params(world, auto_reset, 0)
+        args = (world.num_envs, len(world.agents), int(act_seq.shape[0]),
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+                world.step_count.data_ptr(),
+                _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), int(obs_every), _native.current_stream())
+        fn = lib.fg_rollout_hd
+        keep = (act_seq, out)
+
+        def launch(rng_offset=0):
+            p.rng_offset = rng_offset
+            rc = fn(p, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        return launch
+
     def upload_mt_streams(self, world):
         """Copy every env's legacy MT19937 state (RandomState(seed + 1000 b), at its CURRENT
         position) to the device; from here on `reset_mt` continues those streams on the GPU."""
