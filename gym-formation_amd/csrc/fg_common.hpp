@@ -134,6 +134,10 @@ FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
 // counter-based RNG for the device-side reset (Philox4x32-10, Salmon et al. 2011)
 // ---------------------------------------------------------------------------
 FG_DEV void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    // The keys are wave-uniform launch constants, so the compiler would hoist the ten round keys (20 SGPRs) out of
+    // whatever loop the call sits in - here the rarely taken episode-reset branch of the step loop - and pay for
+    // them with SGPR spills on the hot path.  Opaque keys keep the schedule inside the branch.
+    asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t m0 = (uint64_t)0xD2511F53u * c[0];
