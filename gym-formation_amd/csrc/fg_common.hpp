@@ -18,6 +18,9 @@
 #ifndef FG_WRITER_PRIO
 #define FG_WRITER_PRIO 0   // tuning: s_setprio level of the rollout writer waves
 #endif
+#ifndef FG_PRODUCER_PRIO
+#define FG_PRODUCER_PRIO 2   // s_setprio level of the rollout producer waves: their dependent chain bounds small-N rollouts (9 x 4096: 1.68 -> 1.58 us/step; levels 1-3 alike; store-bound shapes unaffected)
+#endif
 #ifndef FG_TILE_NT
 #define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer (measured: -6 %, profiles/README.md)
 #endif

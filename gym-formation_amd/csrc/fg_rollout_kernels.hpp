@@ -161,6 +161,9 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     int* const tile_ctr = reinterpret_cast<int*>(smemf + E * roll_block_floats(N));
     float2* const tile_base = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N) + 4);
     if (SHARE && tid == 0) { tile_ctr[0] = 0; tile_ctr[1] = 0; }
+#if FG_PRODUCER_PRIO
+    if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
+#endif
     if (producer) produce(0, u_even, u_odd);
 #if FG_WRITER_PRIO
     else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
