@@ -29,7 +29,7 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
     env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
     if (mine) {
         const size_t sidx = (size_t)b * N + i;
-        const float invN = 1.0f / (float)N;
+        const float invN = a.inv_n;
         a.px[sidx] = u_pm1(c[0]); a.py[sidx] = u_pm1(c[1]);
         a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
         reinterpret_cast<float2*>(a.shape)[sidx] = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));

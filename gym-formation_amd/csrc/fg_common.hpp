@@ -50,6 +50,8 @@ constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances 
 struct Args {
     FgParams p;
     int B, N, K, obs_every;
+    float inv_n;               // 1 / N, correctly rounded on the host: run-time-N kernels must use the very value that
+                               // compile-time-N kernels constant-fold (-fapprox-func turns a device-side division into v_rcp_f32)
     int do_phys, do_post;
     int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
     int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)

@@ -64,7 +64,7 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
     const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;   // force beyond: < 1e2 k e^-18 ~ 1.5e-9
     const float cutoff2 = cutoff * cutoff;
     const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
-    const float invN = 1.0f / (float)N;
+    const float invN = NC ? 1.0f / (float)(NC ? NC : 1) : a.inv_n;      // compile-time N: folded to the same correctly rounded value
 
     // ---- phase 1: state -> registers + LDS --------------------------------
     float2 p = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f), s = make_float2(0.f, 0.f);

@@ -242,7 +242,7 @@ int fg_step_hd(const FgParams* params, int B, int N,
     if (((uintptr_t)obs & 15u) || ((uintptr_t)act & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
         return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, act/ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 1;
+    a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 1;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
@@ -271,7 +271,7 @@ int fg_physics_step(const FgParams* params, int B, int N,
         return fail(FG_ERR_BAD_ARG, "fg_physics_step: a required pointer is NULL%s");
     if ((uintptr_t)act & 7u) return fail(FG_ERR_ALIGNMENT, "act must be 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 0;
+    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 0;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
     return launch_step(a, (hipStream_t)stream);
 }
@@ -292,7 +292,7 @@ int fg_observe_hd(const FgParams* params, int B, int N,
     if (((uintptr_t)obs & 15u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
         return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.K = 1; a.obs_every = 1; a.do_phys = 0; a.do_post = 1;
+    a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 0; a.do_post = 1;
     a.px = const_cast<float*>(pos_x); a.py = const_cast<float*>(pos_y);
     a.vx = const_cast<float*>(vel_x); a.vy = const_cast<float*>(vel_y);
     a.shape = const_cast<float*>(ideal_shape); a.ivel = const_cast<float*>(ideal_vel);
@@ -317,7 +317,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     if (((uintptr_t)obs_seq & 15u) || ((uintptr_t)act_seq & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
         return fail(FG_ERR_ALIGNMENT, "obs_seq must be 16-byte, act_seq/ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.B = B; a.N = N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+    a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
     a.do_phys = 1; a.do_post = 1;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
@@ -404,7 +404,7 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
     if (!pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
         return fail(FG_ERR_BAD_ARG, "fg_reset_hd: a required pointer is NULL%s");
     Args a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.B = B; a.N = N;
+    a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     hipStream_t st = (hipStream_t)stream;
