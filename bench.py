@@ -120,6 +120,8 @@ def main():
                     help="tuning aid (rollout mode): write an observation only every n-th step; the JSON line is "
                          "then NOT a valid benchmark result")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    ap.add_argument("--no-small-buffer", action="store_true",
+                    help="skip the extra 4-steps-per-launch (Infinity-Cache-sized buffer) measurement")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed stepping before the W warm-up steps, so that short runs are not measured during the clock ramp")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -287,7 +289,8 @@ def main():
     # HBM, so this is NOT an HBM-roofline number; reported beside the headline (never as `value`) because a consumer
     # that reads the observations right after each launch sees this rate.
     small = None
-    if world_size == 1 and not a.no_extra and a.mode == "rollout" and a.chunk > 4 and a.obs_every == 1:
+    if world_size == 1 and not a.no_extra and not a.no_small_buffer and a.mode == "rollout" and a.chunk > 4 \
+            and a.obs_every == 1 and (N, B) == (27, 4096):
         m4 = measure(N, B, "rollout", min(a.steps, 400), min(a.warmup, 40), 4, 0)
         g4 = m4["bytes_per_env_step"] * B * min(a.steps, 400) / (m4["dev_ms"] * 1e-3) / 1e9
         small = {"steps_per_launch": m4["chunk"], "buffer_MB": round(m4["chunk"] * B * N * 6 * N * 4 / 1e6, 1),

@@ -8,7 +8,7 @@ for cfg in "27 4096 400 40" "9 4096 800 80" "81 2048 200 20" "243 8192 40 8"; do
   set -- $cfg
   O=$R/gpurun_out/shapes_${TAG}/n$1
   mkdir -p $O
-  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --agents $1 --envs $2 --steps $3 --warmup $4 --no-cpu-baseline --no-other-configs > $O/bench.json 2> $O/bench.err)
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --agents $1 --envs $2 --steps $3 --warmup $4 --no-cpu-baseline --no-other-configs --no-small-buffer > $O/bench.json 2> $O/bench.err)
   echo "profiled N=$1 B=$2"
 done
 python3 $R/profiles/summarize_shapes.py "$R/gpurun_out/shapes_${TAG}" "$R/gpurun_out/${TAG}_all_shapes.md"

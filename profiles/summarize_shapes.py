@@ -24,7 +24,9 @@ for d in sorted(glob.glob(os.path.join(src, "n*")), key=lambda p: int(os.path.ba
     for name, durs in groups.items():
         if len(durs) < 5:
             continue
-        short = name.replace("void ", "").replace("(fg::Args)", "")
+        short = name.replace("void ", "")
+        if ">(" in short:
+            short = short[:short.index(">(") + 1]          # drop the argument list
         parts = [(durs, chunk if "rollout_kernel" in name else 1)]
         if "rollout_kernel_wide<243" in name:
             thr = 2.0 * min(durs)
