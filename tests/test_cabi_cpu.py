@@ -145,3 +145,25 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".hpp", ".sh")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, "%s mentions the oracle" % f
+
+
+def test_bench_cli_and_cpp_example_build(tmp_path):
+    """bench.py parses its contract flags without touching a GPU, and the plain C++ consumer of the C ABI
+    (examples/c_abi_rollout.cpp) compiles and links against the header and the built library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--mode", "--chunk"):
+        assert flag in out.stdout
+    lib = os.path.join(root, "gym-formation_amd", "lib")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "c_abi_rollout")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_abi_rollout.cpp"), "-L", lib, "-lformation_hip",
+                    "-Wl,-rpath," + lib, "-o", exe], check=True, capture_output=True, timeout=600)
+    assert os.path.getsize(exe) > 0
