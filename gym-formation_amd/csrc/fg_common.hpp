@@ -12,17 +12,8 @@
 
 #include "formation_hip.h"
 
-#ifndef FG_PROBES
-#define FG_PROBES 0        // 1: honour the FG_PROBE timing experiments (results are then NOT valid)
-#endif
-#ifndef FG_WRITER_PRIO
-#define FG_WRITER_PRIO 0   // tuning: s_setprio level of the rollout writer waves
-#endif
 #ifndef FG_PRODUCER_PRIO
 #define FG_PRODUCER_PRIO 2   // s_setprio level of the rollout producer waves: their dependent chain bounds small-N rollouts (9 x 4096: 1.68 -> 1.58 us/step; levels 1-3 alike; store-bound shapes unaffected)
-#endif
-#ifndef FG_TILE_NT
-#define FG_TILE_NT 0     // tuning: non-temporal stores in the LDS-tiled writer (measured: -6 %, profiles/README.md)
 #endif
 
 namespace fg {
@@ -47,6 +38,16 @@ FG_DEV const float2* env_tables(const float2* smem, int ee, int n) {
 }
 constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances stay finite (2e36)
 
+// Constants of the demo controller's hierarchy (fg_policy_kernels.hpp), rounded ONCE on the host so that kernels
+// with a compile-time and with a run-time agent count multiply by the very same values (-fapprox-func turns a
+// device-side division into v_rcp_f32, a compile-time one is folded exactly).
+constexpr int FG_POLICY_MAX_LEVELS = 10;       // 2^10 = FG_MAX_AGENTS
+struct FgPolicyLevels {
+    int per, L;                                // agents per group of a level, number of levels: N = per^L
+    float inv_per;                             // (float)(1.0 / per)
+    float inv_sub[FG_POLICY_MAX_LEVELS];       // inv_sub[l] = (float)(1.0 / per^l): sub-group sums -> centroids
+};
+
 struct Args {
     FgParams p;
     int B, N, K, obs_every;
@@ -54,7 +55,6 @@ struct Args {
                                // compile-time-N kernels constant-fold (-fapprox-func turns a device-side division into v_rcp_f32)
     int do_phys, do_post;
     int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
-    int probe;                 // timing probes, only honoured in -DFG_PROBES=1 builds (profiles/README.md)
     float* px; float* py; float* vx; float* vy;
     const float* act;          // [K][B][N][2]
     float* shape;              // [B][N][2]

@@ -172,7 +172,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
         const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
         float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;     // no restrict: the two tiles alternate
 #pragma unroll
-        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RW) {
+        for (int rb = 0; rb < RT; rb += RW) {
             const int rl = rb + rsub;
             if (act && rl < RT) {
                 const int r = r0 + rl;
@@ -182,7 +182,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             }
         }
 #pragma unroll
-        for (int rb = 0; rb < (FG_TILE_NT == 2 ? 0 : RT); rb += RS) {
+        for (int rb = 0; rb < RT; rb += RS) {
             const int rl = rb + ssub;
             if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
         }
@@ -201,11 +201,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
 #pragma unroll
         for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
             const unsigned q = q0 + lane;
-            if (q < npair) {
-                if (FG_TILE_NT == 1) __builtin_nontemporal_store(src4[q], &dst4[q]);
-                else if (FG_TILE_NT == 2) { const f32x4 cst = {1.f, 2.f, 3.f, 4.f}; dst4[q] = cst; }   // timing probe
-                else dst4[q] = src4[q];
-            }
+            if (q < npair) dst4[q] = src4[q];
         }
         if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
     };
@@ -213,96 +209,6 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     for (int t = 0; t < total; ++t) {
         if (t + 1 < total) compose(t + 1);
         stream(t);
-    }
-}
-
-// Work-sharing variant for the pipelined rollout kernel: every wave of the workgroup (writer
-// waves at once, producer waves when their step is done) pulls the next tile of the group from
-// an LDS counter.  NBUF tiles of LDS per calling wave (2: compose t+1 while t drains).
-template <int NC, int E, int RT, int NBUF>
-FG_DEV void write_obs_tiled_shared(const float2* __restrict__ tables0, int env_stride, float2* my_tiles, int* ctr,
-                                   float2* __restrict__ out_env0, size_t unit0, int El) {
-    constexpr int N = NC;
-    static_assert(N <= 32 && N % RT == 0 && (NBUF == 1 || NBUF == 2), "tiled writer: N <= 32, RT divides N");
-    constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
-    constexpr int TILES_ENV = N / RT;
-    const int lane = threadIdx.x & 63;
-    constexpr int RW = 64 / N;
-    const int rsub = lane / N, u = lane - rsub * N;
-    const bool act = rsub < RW;
-    const int xoff = (u == 0) ? 4 * N : 0;
-    constexpr int RS = 64 / (2 * N);
-    const int ssub = lane / (2 * N), sidx = lane - ssub * 2 * N;
-    const int total = El * TILES_ENV;
-    int cur_env = -1;
-    const float2* __restrict__ AA = tables0;
-    float2 Pm = make_float2(0.f, 0.f), Pu = Pm, sv = Pm;
-    auto grab = [&]() -> int {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(ctr, 1);
-        return __builtin_amdgcn_readfirstlane(t);
-    };
-    auto compose = [&](int t, int buf) {
-        const int ee = t / TILES_ENV, r0 = (t - ee * TILES_ENV) * RT;
-        if (ee != cur_env) {
-            cur_env = ee;
-            AA = tables0 + (size_t)ee * env_stride;
-            Pm = lds_if(act && u >= 1, AA, u - 1);
-            Pu = lds_if(act && u >= 1, AA, u);
-            sv = lds_if(ssub < RS, AA, N + sidx);
-        }
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
-        float2* img = my_tiles + buf * tile_units<NC, RT>() + par;
-#pragma unroll
-        for (int rb = 0; rb < RT; rb += RW) {
-            const int rl = rb + rsub;
-            if (act && rl < RT) {
-                const int r = r0 + rl;
-                const float2 x = AA[xoff + r];
-                const float2 c = (u - 1 >= r) ? Pu : Pm;
-                img[(unsigned)rl * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
-            }
-        }
-#pragma unroll
-        for (int rb = 0; rb < RT; rb += RS) {
-            const int rl = rb + ssub;
-            if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
-        }
-    };
-    auto stream = [&](int t, int buf) {
-        const int ee = t / TILES_ENV, r0 = (t - ee * TILES_ENV) * RT;
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
-        const float2* img = my_tiles + buf * tile_units<NC, RT>() + par;
-        float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
-        if (par && lane == 0) out[0] = img[0];
-        constexpr unsigned NPMAX = TU >> 1;
-        const unsigned npair = (TU - par) >> 1;
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + par);
-        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
-#pragma unroll
-        for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
-            const unsigned q = q0 + lane;
-            if (q < npair) dst4[q] = src4[q];
-        }
-        if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
-    };
-    int t = grab();
-    if (t >= total) return;
-    compose(t, 0);
-    int buf = 0;
-    for (;;) {
-        if (NBUF == 2) {
-            const int tn = grab();
-            if (tn < total) compose(tn, buf ^ 1);
-            stream(t, buf);
-            if (tn >= total) break;
-            t = tn; buf ^= 1;
-        } else {
-            stream(t, 0);
-            t = grab();
-            if (t >= total) break;
-            compose(t, 0);
-        }
     }
 }
 

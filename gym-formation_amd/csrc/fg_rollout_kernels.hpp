@@ -24,10 +24,9 @@ namespace fg {
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
 
-template <int NC, int G, int TP, int TW, int E, int WR, bool SHARE = false>
+template <int NC, int G, int TP, int TW, int E, int WR>
 __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
-    // SHARE: all waves pull observation tiles from an LDS counter (producers join once their
-    // step is produced); needs WR >= 2 (LDS tiles).
+    // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
     constexpr int NPS = NP <= 16 ? NP : 0;              // small N: partners fetched up front (fg_pair_loops.hpp)
@@ -157,44 +156,18 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
         }
     };
 
-    // SHARE layout after the env blocks: int ctr[2] (16 bytes), then tiles: 2 per writer wave, 1 per producer wave
-    int* const tile_ctr = reinterpret_cast<int*>(smemf + E * roll_block_floats(N));
-    float2* const tile_base = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N) + 4);
-    if (SHARE && tid == 0) { tile_ctr[0] = 0; tile_ctr[1] = 0; }
 #if FG_PRODUCER_PRIO
     if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
 #endif
     if (producer) produce(0, u_even, u_odd);
-#if FG_WRITER_PRIO
-    else __builtin_amdgcn_s_setprio(FG_WRITER_PRIO);       // writer waves win issue arbitration over producers
-#endif
     // every prologue load has landed before the loop: inside it the only loads in flight are the
     // action prefetches, and no leftover prologue dependency makes the compiler drain them early
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
     // hand-over step k: producers run step k+1 (consuming u_cur) while writers stream step k
     auto pipeline_step = [&](int k, const float2& u_cur, float2& u_nxt) {
-        if constexpr (SHARE) {
-            if (tid == 0) tile_ctr[(k + 1) & 1] = 0;          // last used in step k-1, which the barrier closed
-            int slot = k;
-            bool want_obs = a.obs != nullptr;
-            if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
-            if (producer && k + 1 < a.K) produce(k + 1, u_cur, u_nxt);
-            if (want_obs) {
-                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
-                const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
-                constexpr int TUNITS = tile_units<NC, WR - 1>();
-                if (producer)
-                    write_obs_tiled_shared<NC, E, WR - 1, 1>(tables0, roll_block_floats(N) / 2,
-                        tile_base + (NWW * 2 + (tid >> 6)) * TUNITS, &tile_ctr[k & 1],
-                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
-                else
-                    write_obs_tiled_shared<NC, E, WR - 1, 2>(tables0, roll_block_floats(N) / 2,
-                        tile_base + ((tid - TP) >> 6) * 2 * TUNITS, &tile_ctr[k & 1],
-                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
-            }
-        } else if (producer) {
-            if (k + 1 < a.K && !(FG_PROBES && a.probe)) produce(k + 1, u_cur, u_nxt);      // probe 1/2: writers only
+        if (producer) {
+            if (k + 1 < a.K) produce(k + 1, u_cur, u_nxt);
         } else {
             int slot = k;
             bool want_obs = a.obs != nullptr;
@@ -211,7 +184,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                                                         reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
             }
         }
-        if (!(FG_PROBES && a.probe == 2)) __syncthreads();                    // probe 2: no hand-over sync
+        __syncthreads();
     };
     for (int k = 0; k < a.K; k += 2) {
         pipeline_step(k, u_odd, u_even);

@@ -18,11 +18,8 @@ namespace fg {
 //   IDX also emit the landmark-index assignments
 // LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-#ifndef FG_WPS
-#define FG_WPS 0          // tuning: minimum waves per SIMD requested from the register allocator (0 = none)
-#endif
-template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
-__global__ __launch_bounds__(T, ((FG_WPS) > 0 && !IDX && !OPTS) ? (FG_WPS) : 1)
+template <int NC, int G, int T, int E, bool IDX, bool OPTS>
+__global__ __launch_bounds__(T)
 void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre_px, const float* __restrict__ pre_py,
                  const float* __restrict__ pre_vx, const float* __restrict__ pre_vy, const float* __restrict__ pre_shape,
                  const float* __restrict__ pre_ivel, const int32_t* __restrict__ pre_step, const Args a) {
@@ -32,7 +29,7 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
     // launch -> first-store chain of a single-step launch).  Everything else is read from `a` as before.
     // OPTS: World options no reference scenario enables (accel, max_speed, u_noise, walls);
     // compiled into a separate instantiation so that the common path keeps its registers.
-    constexpr bool FLAT = (WR == 1);
+    constexpr bool FLAT = (NC == 0);          // observation writer: register-cached rows (compile-time N) or flat decode
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     const int N = NC ? NC : pre_N;
@@ -121,6 +118,9 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
             // so the common no-reset step pays no extra barrier later.
             if (a.p.auto_reset && env_ok && i == 0 && t_step >= a.p.world_length) reset_flag[k & 1] = 1;
             __syncthreads();
+            // the other parity slot is re-armed every step (it was last read in step k-1, which the barrier above
+            // closed, and is next written in step k+1, after the barrier that ends this step)
+            if (tid == 0) reset_flag[(k + 1) & 1] = 0;
         }
 
         if (a.do_post) {
@@ -168,7 +168,6 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
 
             // ---- phase 4: vec-env auto reset --------------------------------
             if (a.p.auto_reset && reset_flag[k & 1] != 0) {          // workgroup-uniform
-                if (tid == 0) reset_flag[(k + 1) & 1] = 0;
                 const bool mine = is_done && env_ok;
                 if (G > 64 ? mine : (__any(mine) != 0)) {
                     uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
@@ -199,17 +198,11 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
             }
 
             // ---- phase 5: observations --------------------------------------
-            if (want_obs && NC > 0 && !FLAT) {
-                if constexpr (NC > 0 && WR == 0)
+            if (want_obs && !FLAT) {
+                if constexpr (NC > 0)
                     write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
                                                   reinterpret_cast<float2*>(a.obs) +
                                                   ((size_t)slot * pre_B + b0) * (size_t)(3 * NC * NC), El, 3);
-                if constexpr (NC > 0 && WR >= 2) {
-                    const size_t unit0 = ((size_t)slot * pre_B + b0) * (size_t)(3 * NC * NC);
-                    float2* tiles = env_tables(smem, E, N) + 36;            // after env blocks + 72 floats of scratch
-                    write_obs_tiled<NC, T / 64, E, WR - 2 + 1>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6, tiles,
-                                                               reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
-                }
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows

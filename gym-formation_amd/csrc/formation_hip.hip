@@ -26,14 +26,14 @@
 // fg_aux_kernels.hpp (resets, landmark scenarios); this file holds the host side: variant
 // tables, dispatch and the extern "C" entry points.
 
-#include <climits>
-#include <cstdlib>
+#include <atomic>
 #include "fg_common.hpp"
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
 #include "fg_step_kernel.hpp"
 #include "fg_rollout_kernels.hpp"
 #include "fg_aux_kernels.hpp"
+#include "fg_policy_kernels.hpp"
 
 namespace fg {
 
@@ -47,116 +47,101 @@ static int fail(int code, const char* fmt, const char* detail = "") {
     return code;
 }
 
-// Tuning switches (profiles/README.md) are environment variables read ONCE per call site: a launch
-// costs no getenv, and a process sees one consistent configuration.
-static int read_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-#define FG_OVERRIDE(var, name) \
-    do { static const int fg_o_ = read_env_int(name, INT_MIN); if (fg_o_ != INT_MIN) (var) = fg_o_; } while (0)
-struct GeomOverride { int t, e; bool set; };
-
 struct Geometry { int G, T, E, lds; };
 
+// A launch goes to the device its stream belongs to: if that is not the calling thread's current device (an env
+// living on cuda:1 driven from a thread whose current device is cuda:0), switch for the duration of the call.
+// The NULL stream means "the current device's default stream" and needs no switch.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(void* stream) {
+        hipDevice_t sdev = -1;
+        if (!stream || hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != (int)sdev) switched = hipSetDevice((int)sdev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // Kernels that need more than the default 64 KiB of dynamic LDS opt in once per (kernel, device): the
-// attribute belongs to the device the function is loaded on, and a process may drive several GPUs.
-static void raise_lds_limit(const void* fn, int lds, unsigned long long* done_mask) {
+// attribute belongs to the device the function is loaded on, and a process may drive several GPUs (one
+// thread each: the bookkeeping is atomic).
+static hipError_t raise_lds_limit(const void* fn, int lds, std::atomic<unsigned long long>* done_mask) {
+    if (lds <= 64 * 1024) return hipSuccess;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!((*done_mask >> dev) & 1ull)) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        *done_mask |= 1ull << dev;
-    }
+    if ((done_mask->load(std::memory_order_acquire) >> dev) & 1ull) return hipSuccess;
+    const hipError_t err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (err == hipSuccess) done_mask->fetch_or(1ull << dev, std::memory_order_release);
+    return err;
 }
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-template <int NC, int G, int T, int E, bool IDX, int WR, bool OPTS>
+template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
-    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, WR, OPTS>), dim3(grid), dim3(T), lds, st,
+    hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, OPTS>), dim3(grid), dim3(T), lds, st,
                        a.B, a.N, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
                        (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
     return hipGetLastError();
 }
 
 using LaunchFn = hipError_t (*)(const Args&, int, int, hipStream_t);
-// wr: observation writer 0 = register-cached rows, 1 = flat decode (run-time N), 1 + RT = LDS tiles of RT rows
-struct Variant { int NC, G, T, E, wr; LaunchFn plain, idx, opts; };   // opts: IDX + World options
-#define FG_VARIANT_W(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W, false>, \
-                                      &launch_v<NC, G, T, E, true, W, false>, nullptr}
-#define FG_VARIANT_O(NC, G, T, E, W) {NC, G, T, E, W, &launch_v<NC, G, T, E, false, W, false>, \
-                                      &launch_v<NC, G, T, E, true, W, false>, &launch_v<NC, G, T, E, true, W, true>}
-#define FG_VARIANT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, ((NC) == 0 ? 1 : 0))
-#define FG_VARIANT_FLAT(NC, G, T, E) FG_VARIANT_W(NC, G, T, E, 1)
+// One entry per (agent count, workgroup shape).  plain / idx (+ landmark-index outputs) / opts (idx + World options
+// no reference scenario enables).  min_B: the entry is the default from that batch size up (MI355X sweeps,
+// profiles/README.md: a batch that fills the chip many times over streams best with 8 envs per workgroup, a
+// single-generation batch prefers one env per wave with spare writer waves).  NC = 0 entries take N at run time.
+struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
+#define FG_VARIANT(NC, G, T, E, MINB) {NC, G, T, E, MINB, &launch_v<NC, G, T, E, false, false>, \
+                                       &launch_v<NC, G, T, E, true, false>, &launch_v<NC, G, T, E, true, true>}
+#define FG_VARIANT_BIG(NC, G, T, E, MINB) {NC, G, T, E, MINB, &launch_v<NC, G, T, E, false, false>, nullptr, nullptr}
 
-// The first entry of a given NC is the default; the others are selectable with
-// FG_GEOM="T,E" (tuning aid, see profiles/).  NC = 0 entries take N at run time.
 static const Variant kVariants[] = {
-    FG_VARIANT_O(3, 4, 128, 16, 0), FG_VARIANT(3, 4, 64, 16), FG_VARIANT(3, 4, 64, 8),
-    FG_VARIANT_O(9, 16, 128, 4, 0), FG_VARIANT(9, 16, 64, 4), FG_VARIANT(9, 16, 64, 2), FG_VARIANT(9, 16, 128, 8),
-    FG_VARIANT_O(27, 32, 256, 4, 0), FG_VARIANT(27, 32, 128, 4), FG_VARIANT(27, 32, 64, 2), FG_VARIANT(27, 32, 256, 8),
-    FG_VARIANT(27, 32, 128, 2), FG_VARIANT(27, 32, 256, 2), FG_VARIANT(27, 32, 512, 4),
-    FG_VARIANT_O(81, 128, 128, 1, 0), FG_VARIANT(81, 128, 256, 1), FG_VARIANT(81, 128, 512, 1),
-    FG_VARIANT_O(243, 256, 256, 1, 0), FG_VARIANT(243, 256, 512, 1),
-    // flat float4 writer kept for A/B runs (FG_FLAT=1)
-    FG_VARIANT_FLAT(27, 32, 256, 4), FG_VARIANT_FLAT(27, 32, 128, 4), FG_VARIANT_FLAT(9, 16, 128, 4),
-    FG_VARIANT_FLAT(81, 128, 128, 1), FG_VARIANT_FLAT(243, 256, 256, 1),
-    // LDS-tiled writer, RT rows per tile (FG_FLAT = 1 + RT)
-    FG_VARIANT_W(27, 32, 256, 4, 4), FG_VARIANT_W(27, 32, 128, 4, 4), FG_VARIANT_W(27, 32, 128, 2, 4), FG_VARIANT_W(27, 32, 64, 2, 4),
-    FG_VARIANT_W(27, 32, 256, 4, 10), FG_VARIANT_W(27, 32, 128, 4, 10), FG_VARIANT_W(27, 32, 128, 2, 10), FG_VARIANT_W(27, 32, 64, 2, 10),
-    FG_VARIANT_W(27, 32, 256, 2, 10), FG_VARIANT_W(27, 32, 256, 2, 4),
-    FG_VARIANT_W(9, 16, 128, 4, 10), FG_VARIANT_W(9, 16, 64, 4, 10), FG_VARIANT_W(9, 16, 128, 8, 10), FG_VARIANT_W(9, 16, 256, 16, 10),
-    FG_VARIANT_O(0, 4, 64, 16, 1), FG_VARIANT_O(0, 8, 64, 8, 1), FG_VARIANT_O(0, 16, 64, 4, 1), FG_VARIANT_O(0, 32, 128, 4, 1),
-    FG_VARIANT_O(0, 64, 128, 2, 1), FG_VARIANT_O(0, 128, 128, 1, 1), FG_VARIANT_O(0, 256, 256, 1, 1),
-    FG_VARIANT_O(0, 512, 512, 1, 1), FG_VARIANT_O(0, 1024, 1024, 1, 1),
+    FG_VARIANT(3, 4, 128, 16, 0),
+    FG_VARIANT(9, 16, 128, 4, 0), FG_VARIANT_BIG(9, 16, 128, 8, 16384),
+    FG_VARIANT(27, 32, 256, 4, 0), FG_VARIANT_BIG(27, 32, 256, 8, 32768),
+    FG_VARIANT(81, 128, 128, 1, 0),
+    FG_VARIANT(243, 256, 256, 1, 0),
+    FG_VARIANT(0, 4, 64, 16, 0), FG_VARIANT(0, 8, 64, 8, 0), FG_VARIANT(0, 16, 64, 4, 0), FG_VARIANT(0, 32, 128, 4, 0),
+    FG_VARIANT(0, 64, 128, 2, 0), FG_VARIANT(0, 128, 128, 1, 0), FG_VARIANT(0, 256, 256, 1, 0),
+    FG_VARIANT(0, 512, 512, 1, 0), FG_VARIANT(0, 1024, 1024, 1, 0),
 };
 
-static const Variant* variant_for(int N, int B = 0, bool need_opts = false) {
+// need_full: the launch wants the idx / opts instantiation (only the first entry of an agent count has them)
+static const Variant* variant_for(int N, int B = 0, bool need_full = false) {
     if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
-    int want_t = 0, want_e = 0, want_flat = 0;
-    if (need_opts) {                      // the first entry of every NC (and every generic one) carries OPTS
-        for (const Variant& v : kVariants) if (v.NC == N && v.opts) return &v;
-        B = 0;
-    }
-    // Size-aware default (MI355X sweep, profiles/): a batch that fills the chip many times over
-    // streams best with 8 envs per workgroup; a single-generation batch (27 x 4096 = 4 workgroups
-    // per CU) is latency-bound and prefers one env per wave with spare writer waves.
-    if (N == 27 && B >= 32768) { want_t = 256; want_e = 8; }
-    if (N == 9 && B >= 16384) { want_t = 128; want_e = 8; }
-    {   // "T,E", parsed once
-        static const GeomOverride go = [] { GeomOverride g = {0, 0, false};
-                                            if (const char* s = getenv("FG_GEOM")) g.set = sscanf(s, "%d,%d", &g.t, &g.e) == 2;
-                                            return g; }();
-        if (go.set) { want_t = go.t; want_e = go.e; }
-    }
-    FG_OVERRIDE(want_flat, "FG_FLAT");
-    const Variant* dflt = nullptr;
+    const Variant* best = nullptr;
     for (const Variant& v : kVariants) {
-        if (need_opts) break;
-        if (v.NC != N || v.wr != want_flat) continue;
-        if (!dflt) dflt = &v;
-        if (v.T == want_t && v.E == want_e) return &v;
+        if (v.NC != N || B < v.min_B || (need_full && !v.opts)) continue;
+        if (!best || v.min_B > best->min_B) best = &v;
     }
-    if (dflt) return dflt;
+    if (best) return best;
     const int G = N <= 64 ? (pow2ceil(N) < 4 ? 4 : pow2ceil(N)) : (pow2ceil(N) < 128 ? 128 : pow2ceil(N));
     for (const Variant& v : kVariants)
         if (v.NC == 0 && v.G == G) return &v;
     return nullptr;
 }
 
-static bool geometry_for(int N, Geometry* g, int B = 0, bool need_opts = false) {
-    const Variant* v = variant_for(N, B, need_opts);
+static bool geometry_for(int N, Geometry* g, int B = 0, bool need_full = false) {
+    const Variant* v = variant_for(N, B, need_full);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
     g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
-    if (v->wr >= 2) g->lds += 2 * (v->T / 64) * ((3 * N * (v->wr - 1) + 3) & ~1) * (int)sizeof(float2);
     return true;
+}
+
+static bool world_options_set(const FgParams& p) {
+    return p.num_walls > 0 || p.u_noise > 0.f || p.max_speed > 0.f || p.accel > 0.f;
 }
 
 static int launch_step(Args a, hipStream_t st) {
     Geometry g;
-    const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
-    const Variant* v = variant_for(a.N, a.B, opts);
-    if (!v || !geometry_for(a.N, &g, a.B, opts)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const bool opts = world_options_set(a.p);
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
+    const Variant* v = variant_for(a.N, a.B, opts || idx);
+    if (!v || !geometry_for(a.N, &g, a.B, opts || idx)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const int grid = (a.B + g.E - 1) / g.E;
     const hipError_t err = (opts ? v->opts : idx ? v->idx : v->plain)(a, grid, g.lds, st);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
@@ -164,37 +149,72 @@ static int launch_step(Args a, hipStream_t st) {
 }
 
 // 64 < N <= 256: producer / writer pipelined kernel (rollout: over steps; single step: over env batches)
-static int launch_wide(Args a, hipStream_t st) {
-    const int N = a.N, B = a.B;
-    hipError_t err = hipSuccess;
-    int tw = 256;
-    FG_OVERRIDE(tw, "FG_TW");
+template <int NC, int A, int E, int TW>
+static int launch_wide_v(Args a, hipStream_t st) {
     if (a.K == 1) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
-        // stream, few enough to keep every CU busy (MI355X sweep, profiles/README.md)
-        const int E = (N == 243 && tw == 128) ? 2 : ((N == 81 && tw == 512) ? 8 : 4);
-        const int batches = (B + E - 1) / E;
-        int target = 256;                                  // workgroups in the grid: one per CU
-        FG_OVERRIDE(target, "FG_STEPWG");
-        a.groups = batches / (target > 0 ? target : 1);
+        // stream, few enough to keep every CU busy (one workgroup per CU; MI355X sweep, profiles/README.md)
+        const int batches = (a.B + E - 1) / E;
+        a.groups = batches / 256;
         if (a.groups < 1) a.groups = 1;
         if (a.groups > 64) a.groups = 64;
     } else {
         a.groups = 1;
     }
-#define FG_ROLLW(NCV, AV, EV, TWV)                                                                        \
-    {   const int grid = (B + (EV) * a.groups - 1) / ((EV) * a.groups);                                  \
-        const int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                              \
-        if (lds > 64 * 1024) {   /* more than the default dynamic-LDS limit: opt in (once per kernel) */  \
-            static unsigned long long raised = 0;                                                        \
-            raise_lds_limit((const void*)&rollout_kernel_wide<NCV, AV, EV, TWV>, lds, &raised); }         \
-        hipLaunchKernelGGL((rollout_kernel_wide<NCV, AV, EV, TWV>), dim3(grid), dim3((EV) * 64 + (TWV)), lds, st, a); \
-        err = hipGetLastError(); }
-    if (N == 81) { if (tw == 128) FG_ROLLW(81, 2, 4, 128) else if (tw == 512) FG_ROLLW(81, 2, 8, 512) else FG_ROLLW(81, 2, 4, 256) }
-    else { if (tw == 128) FG_ROLLW(243, 4, 2, 128) else if (tw == 512) FG_ROLLW(243, 4, 4, 512) else FG_ROLLW(243, 4, 4, 256) }
-#undef FG_ROLLW
+    const int grid = (a.B + E * a.groups - 1) / (E * a.groups);
+    const int lds = E * roll_block_floats(NC) * (int)sizeof(float);
+    static std::atomic<unsigned long long> raised{0};
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW>, lds, &raised);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
+        err = hipGetLastError();
+    }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
     return FG_OK;
+}
+static int launch_wide(const Args& a, hipStream_t st) {
+    return a.N == 81 ? launch_wide_v<81, 2, 4, 256>(a, st) : launch_wide_v<243, 4, 4, 256>(a, st);
+}
+
+// N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
+template <int NC, int G, int TP, int TW, int E, int WR>
+static int launch_roll_v(const Args& a, hipStream_t st) {
+    const int grid = (a.B + E - 1) / E;
+    int lds = E * roll_block_floats(NC) * (int)sizeof(float);
+    if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
+    static std::atomic<unsigned long long> raised{0};
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR>, lds, &raised);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR>), dim3(grid), dim3(TP + TW), lds, st, a);
+        err = hipGetLastError();
+    }
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+static int launch_roll(const Args& a, hipStream_t st) {
+    // Defaults from the MI355X sweeps (profiles/README.md).  27 agents: 16 envs per workgroup = 8 producer + 4
+    // writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.  9 agents: a batch of <= 4096 envs is
+    // bound by the producers' dependent chain and wants many small workgroups with the row writer; larger
+    // batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
+    if (a.N == 27) return launch_roll_v<27, 32, 512, 256, 16, 10>(a, st);
+    if (a.N == 9) {
+        if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10>(a, st);
+        if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10>(a, st);
+        return launch_roll_v<9, 16, 64, 128, 4, 0>(a, st);
+    }
+    return launch_roll_v<3, 4, 64, 64, 16, 0>(a, st);
+}
+
+// N = per^L with 2 <= per <= 8: fills the host-rounded constants of the hierarchy
+static bool policy_levels_for(int N, int per, FgPolicyLevels* pl) {
+    if (per < 2 || per > 8 || N < per) return false;
+    memset(pl, 0, sizeof(*pl));
+    long long n = 1;
+    int L = 0;
+    while (n < N && L < FG_POLICY_MAX_LEVELS) { pl->inv_sub[L] = (float)(1.0 / (double)n); n *= per; ++L; }
+    if (n != N) return false;
+    pl->per = per; pl->L = L; pl->inv_per = (float)(1.0 / (double)per);
+    return true;
 }
 
 static int check_params(const FgParams* p) {
@@ -232,6 +252,7 @@ int fg_step_hd(const FgParams* params, int B, int N,
                const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
                float* obs, float* reward, float* indiv_reward, uint8_t* done,
                int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -247,21 +268,18 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
-    {   // 243 agents: pipeline over env batches inside the launch (no index outputs, no World options):
-        // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192.  At 81 agents the plain kernel is as fast or faster
-        // (74 vs 80 us at 81 x 2048 on the same box); FG_PIPE81=1 selects the pipelined one.
-        int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
-        int pipe81 = 0; FG_OVERRIDE(pipe81, "FG_PIPE81");
-        const bool opts = a.p.num_walls > 0 || a.p.u_noise > 0.f || a.p.max_speed > 0.f || a.p.accel > 0.f;
-        if ((N == 243 || (N == 81 && pipe81)) && !nopipe && !opts && !near_lm && !near_ag && !hd_idx)
-            return launch_wide(a, (hipStream_t)stream);
-    }
+    // 243 agents: pipeline over env batches inside the launch (no index outputs, no World options):
+    // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192.  At 81 agents the plain kernel is as fast or faster
+    // (74 vs 80 us at 81 x 2048 on the same box, profiles/README.md).
+    if (N == 243 && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
+        return launch_wide(a, (hipStream_t)stream);
     return launch_step(a, (hipStream_t)stream);
 }
 
 int fg_physics_step(const FgParams* params, int B, int N,
                     float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                     const float* act, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -281,6 +299,7 @@ int fg_observe_hd(const FgParams* params, int B, int N,
                   const float* ideal_shape, const float* ideal_vel, const int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -307,6 +326,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
                   const float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
                   float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
                   int obs_every, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0 || K == 0) return FG_OK;               // empty batch / zero steps: nothing to do
@@ -322,72 +342,11 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
-    // K >= 2 at the specialised small N: producer / writer pipelined kernel
-    if (FG_PROBES) { FG_OVERRIDE(a.probe, "FG_PROBE"); }
-    int nopipe = 0; FG_OVERRIDE(nopipe, "FG_NOPIPE");
-    if (K >= 2 && !nopipe && (N == 81 || N == 243)) return launch_wide(a, (hipStream_t)stream);
-    if (K >= 2 && !nopipe && (N == 27 || N == 9 || N == 3)) {
-        int tw = 256;                      // defaults from the MI355X sweep (profiles/README.md)
-        FG_OVERRIDE(tw, "FG_TW");
-        hipStream_t st = (hipStream_t)stream;
-        hipError_t err = hipSuccess;
-        int wr = 10;
-        FG_OVERRIDE(wr, "FG_ROLLWR");
-#define FG_ROLL(NCV, GV, TPV, TWV, EV, WRV)                                                              \
-        {   const int grid = (B + (EV) - 1) / (EV);                                                      \
-            int lds = (EV) * roll_block_floats(NCV) * (int)sizeof(float);                                \
-            if ((WRV) > 0) lds += 2 * ((TWV) / 64) * ((3 * (NCV) * ((WRV) - 1) + 3) & ~1) * (int)sizeof(float2); \
-            hipLaunchKernelGGL((rollout_kernel<NCV, GV, TPV, TWV, EV, WRV>), dim3(grid), dim3((TPV) + (TWV)), lds, st, a); \
-            err = hipGetLastError(); }
-        if (N == 27) {
-            int re = 16;                   // 16 envs per workgroup: 8 producer + 4 writer waves, one workgroup per CU
-            FG_OVERRIDE(re, "FG_ROLLE");
-            int share = 0;                 // tuning: producers join the observation stream through an LDS tile counter
-            FG_OVERRIDE(share, "FG_SHARE");
-            if (re == 2) { if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 10) else FG_ROLL(27, 32, 64, 128, 2, 10) }
-                           else { if (tw == 64) FG_ROLL(27, 32, 64, 64, 2, 0) else FG_ROLL(27, 32, 64, 128, 2, 0) } }
-            else if (re == 16 && share) {
-                const int grid = (B + 15) / 16;
-                const int tunits = (3 * 27 * 9 + 3) & ~1;
-                const int lds = 16 * roll_block_floats(27) * (int)sizeof(float) + 16 +
-                                ((tw / 64) * 2 + 8) * tunits * (int)sizeof(float2);
-                if (tw == 256) {
-                    static unsigned long long raised = 0;
-                    raise_lds_limit((const void*)&rollout_kernel<27, 32, 512, 256, 16, 10, true>, lds, &raised);
-                    hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 256, 16, 10, true>), dim3(grid), dim3(768), lds, st, a);
-                } else {
-                    static unsigned long long raised2 = 0;
-                    raise_lds_limit((const void*)&rollout_kernel<27, 32, 512, 128, 16, 10, true>, lds, &raised2);
-                    hipLaunchKernelGGL((rollout_kernel<27, 32, 512, 128, 16, 10, true>), dim3(grid), dim3(640), lds, st, a);
-                }
-                err = hipGetLastError();
-            }
-            else if (re == 16) { if (wr == 10) { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 10) else FG_ROLL(27, 32, 512, 512, 16, 10) }
-                                 else { if (tw == 256) FG_ROLL(27, 32, 512, 256, 16, 0) else FG_ROLL(27, 32, 512, 512, 16, 0) } }
-            else if (re == 8 && tw == 512) { if (wr == 10) FG_ROLL(27, 32, 256, 512, 8, 10) else FG_ROLL(27, 32, 256, 512, 8, 0) }
-            else if (re == 8) { if (wr == 10) { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 10) else FG_ROLL(27, 32, 256, 256, 8, 10) }
-                                else { if (tw == 128) FG_ROLL(27, 32, 256, 128, 8, 0) else FG_ROLL(27, 32, 256, 256, 8, 0) } }
-            else
-            if (wr == 10) { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 10) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 10) else FG_ROLL(27, 32, 128, 128, 4, 10) }
-            else { if (tw == 64) FG_ROLL(27, 32, 128, 64, 4, 0) else if (tw == 256) FG_ROLL(27, 32, 128, 256, 4, 0) else FG_ROLL(27, 32, 128, 128, 4, 0) }
-        }
-        else if (N == 9) {
-            // MI355X sweep (profiles/README.md): a batch of <= 4096 envs is bound by the producers'
-            // dependent chain (1.8 us/step) and wants many small workgroups; larger batches are
-            // store-bound and want 16-env workgroups (whole 128-byte lines per workgroup) with the
-            // LDS-tiled writer.  FG_ROLL9 overrides (tuning aid).
-            int v9 = B >= 8192 ? 4 : B > 4096 ? 6 : 5;
-            FG_OVERRIDE(v9, "FG_ROLL9");
-            if (v9 == 1) FG_ROLL(9, 16, 64, 64, 4, 10)
-            else if (v9 == 4) FG_ROLL(9, 16, 256, 256, 16, 10)
-            else if (v9 == 6) FG_ROLL(9, 16, 128, 128, 8, 10)
-            else if (v9 == 0) FG_ROLL(9, 16, 64, 64, 4, 0)
-            else FG_ROLL(9, 16, 64, 128, 4, 0)
-        }
-        else FG_ROLL(3, 4, 64, 64, 16, 0)
-#undef FG_ROLL
-        if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
-        return FG_OK;
+    // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
+    // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
+    if (K >= 2 && !world_options_set(a.p)) {
+        if (N == 81 || N == 243) return launch_wide(a, (hipStream_t)stream);
+        if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);
     }
     return launch_step(a, (hipStream_t)stream);
 }
@@ -395,6 +354,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
 int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
                 float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                 float* ideal_shape, float* ideal_vel, int32_t* step, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -428,6 +388,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
                            const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
                            int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                            int32_t* near_ag, void* stream) {
+    const DeviceGuard device_guard(stream);
     int rc = check_params(params);
     if (rc) return rc;
     if (!sc) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
@@ -466,6 +427,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
 int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                    float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
+    const DeviceGuard device_guard(stream);
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
@@ -500,7 +462,34 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                            nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
 }
 
+int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream) {
+    const DeviceGuard device_guard(stream);
+    if (B == 0) return FG_OK;
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    FgPolicyLevels pl;
+    if (!policy_levels_for(N, per_layer, &pl))
+        return fail(FG_ERR_UNSUPPORTED_N, "fg_policy_bfs: N must be per_layer^L with 2 <= per_layer <= 8%s");
+    if (!obs || !act) return fail(FG_ERR_BAD_ARG, "fg_policy_bfs: a required pointer is NULL%s");
+    const int64_t stride = obs_env_stride ? obs_env_stride : 6LL * N * N;
+    if (stride < 6LL * N || (stride & 1)) return fail(FG_ERR_BAD_ARG, "fg_policy_bfs: obs_env_stride must be even and >= 6 N%s");
+    if (((uintptr_t)obs & 7u) || ((uintptr_t)act & 7u)) return fail(FG_ERR_ALIGNMENT, "obs and act must be 8-byte aligned%s");
+    const int lpe = N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 256;      // lanes per env
+    const int E = 256 / lpe;
+    const int grid = (B + E - 1) / E;
+    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 48 KiB
+    hipStream_t st = (hipStream_t)stream;
+#define FG_POLICY(PER) case PER: hipLaunchKernelGGL((policy_bfs_kernel<PER>), dim3(grid), dim3(256), lds, st, B, N, lpe, pl, \
+                                                   obs, (long long)stride, act); break;
+    switch (per_layer) { FG_POLICY(2) FG_POLICY(3) FG_POLICY(4) FG_POLICY(5) FG_POLICY(6) FG_POLICY(7) FG_POLICY(8) }
+#undef FG_POLICY
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "policy launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
 int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream) {
+    const DeviceGuard device_guard(stream);
     if (mode != FG_ACT_ONEHOT5 && mode != FG_ACT_INDEX && mode != FG_ACT_ARGMAX)
         return fail(FG_ERR_BAD_ARG, "fg_decode_actions: unknown mode%s");
     if (count == 0) return FG_OK;

@@ -14,7 +14,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_WALLS = 4
 
 FG_OK = 0
@@ -98,6 +98,7 @@ SIGNATURES = {
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
+    "fg_policy_bfs": (_I, [_I, _I, _I, _P, ctypes.c_int64, _P, _P]),
 }
 
 _lib = None
@@ -141,9 +142,11 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def current_stream():
+def current_stream(device=None):
+    """Raw handle of torch's current stream ON `device` (the device the env's tensors live on, which need
+    not be the process's current device: the library switches to the stream's device for the launch)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def current_stream_fast(device):

@@ -305,4 +305,4 @@ class World(object):
         _native.check(lib.fg_physics_step(
             p, self.num_envs, len(self.agents),
             self.pos_x.data_ptr(), self.pos_y.data_ptr(), self.vel_x.data_ptr(), self.vel_y.data_ptr(),
-            self.action_u.data_ptr(), _native.current_stream()))
+            self.action_u.data_ptr(), _native.current_stream(self.device)))

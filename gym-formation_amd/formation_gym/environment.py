@@ -268,7 +268,7 @@ class MultiAgentEnv(object):
             host = np.asarray([np.asarray(a) for a in action_n]).reshape((1,) + shape[1:])
             src = torch.as_tensor(host).to(device=dev, dtype=dtype).contiguous()
         _native.check(_native.load().fg_decode_actions(mode, B * N, src.data_ptr(), self._act.data_ptr(),
-                                                       _native.current_stream()))
+                                                       _native.current_stream(self.world.device)))
         if mode == _native.FG_ACT_ARGMAX:
             if batched:
                 if src is not action_n:

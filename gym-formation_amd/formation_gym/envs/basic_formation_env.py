@@ -83,7 +83,7 @@ class Scenario(BaseScenario):
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
             out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
-            _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream()))
+            _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream(world.device)))
         self._cache = out
 
     def bind_step(self, world, act, out, auto_reset=False):
@@ -97,7 +97,7 @@ class Scenario(BaseScenario):
                 world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
                 act.data_ptr(), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
                 out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
-                _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream())
+                _native.ptr(out.get("done")), _native.ptr(out.get("near_ag")), _native.current_stream(world.device))
         fn = lib.fg_step_basic
         keep = (act, out)
 

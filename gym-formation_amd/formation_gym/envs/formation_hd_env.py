@@ -117,7 +117,7 @@ class Scenario(BaseScenario):
             world.step_count.data_ptr(),
             out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
             _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
-            _native.ptr(out.get("hd_idx")), _native.current_stream()))
+            _native.ptr(out.get("hd_idx")), _native.current_stream(world.device)))
         self._cache = out
 
     def bind_step(self, world, act, out, auto_reset=False):
@@ -131,7 +131,7 @@ class Scenario(BaseScenario):
                 world.step_count.data_ptr(),
                 out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
                 _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
-                _native.ptr(out.get("hd_idx")), _native.current_stream())
+                _native.ptr(out.get("hd_idx")), _native.current_stream(world.device))
         fn = lib.fg_step_hd
         keep = (act, out)
 
@@ -152,7 +152,7 @@ class Scenario(BaseScenario):
             self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
             _native.ptr(out.get("obs")), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
             _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
-            _native.ptr(out.get("hd_idx")), _native.current_stream()))
+            _native.ptr(out.get("hd_idx")), _native.current_stream(world.device)))
         self._cache = out
 
     def rollout_batch(self, world, act_seq, out, obs_every=1, auto_reset=False, rng_offset=0):
@@ -165,7 +165,7 @@ class Scenario(BaseScenario):
             act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
             world.step_count.data_ptr(),
             _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
-            _native.ptr(out.get("done")), int(obs_every), _native.current_stream()))
+            _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device)))
         self._cache = None
 
     def bind_rollout(self, world, act_seq, out, obs_every=1, auto_reset=False):
@@ -179,7 +179,7 @@ class Scenario(BaseScenario):
                 act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
                 world.step_count.data_ptr(),
                 _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
-                _native.ptr(out.get("done")), int(obs_every), _native.current_stream())
+                _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device))
         fn = lib.fg_rollout_hd
         keep = (act_seq, out)
 
@@ -214,7 +214,7 @@ class Scenario(BaseScenario):
             world.num_envs, len(world.agents), _native.ptr(mask), self._mt_state.data_ptr(),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.landmark_pos.data_ptr(),
-            world.step_count.data_ptr(), _native.current_stream()))
+            world.step_count.data_ptr(), _native.current_stream(world.device)))
         self._cache = None
 
     def reset_device(self, world, mask=None, rng_offset=0):
@@ -224,7 +224,7 @@ class Scenario(BaseScenario):
             self.params(world, rng_offset=rng_offset), world.num_envs, len(world.agents), _native.ptr(mask),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
-            _native.current_stream()))
+            _native.current_stream(world.device)))
         self._cache = None
 
     # ---- per-agent callbacks (reference signature) -----------------------------

@@ -123,7 +123,7 @@ class LandmarkScenario(BaseScenario):
             world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
             world.step_count.data_ptr(),
             out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
-            _native.ptr(out.get("done")), _native.current_stream()))
+            _native.ptr(out.get("done")), _native.current_stream(world.device)))
         self._cache = out
 
     def bind_step(self, world, act, out, auto_reset=False):
@@ -141,7 +141,7 @@ class LandmarkScenario(BaseScenario):
                 world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
                 world.step_count.data_ptr(),
                 out["obs"].data_ptr(), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
-                _native.ptr(out.get("done")), _native.current_stream())
+                _native.ptr(out.get("done")), _native.current_stream(world.device))
         fn = lib.fg_step_scenario
         keep = (act, out)
 

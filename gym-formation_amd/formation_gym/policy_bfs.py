@@ -1,17 +1,24 @@
 """Built-in demo controller of the reference (formation_gym/__init__.py:19-47
 `ezpolicy`, :49-99 `get_action_BFS`), batched.
 
-The reference walks a Python queue of per-agent observation lists.  Here the
-hierarchy is evaluated level by level with tensor ops over all B environments
-and all groups of a level at once, on whatever device the observations live
-on (the GPU for rollouts; CPU float64 in the parity tests).  Both functions
-also accept the reference's calling convention (one observation vector / a
-list of N vectors) and then return NumPy like the reference does.
+`get_action_BFS(ezpolicy, obs, per)` on a device tensor [B, N, 6N] - what a
+rollout loop calls every step (test.py:23) - is ONE HIP launch
+(`fg_policy_bfs`, csrc/fg_policy_kernels.hpp): the whole hierarchy of an env is
+evaluated by one group of lanes from observation row 0.  There is no CPU
+fallback for it: a missing library raises.
+
+The reference's signature also admits an arbitrary `policy` callable and its
+own calling convention (a list of N NumPy vectors, one env).  Those are host
+orchestration around the caller's function: the hierarchy is then evaluated
+level by level with tensor ops over all groups of a level at once, on whatever
+device the observations live on, and NumPy goes out where NumPy came in.
 """
 import math
 
 import numpy as np
 import torch
+
+from . import _native
 
 
 def _ez_batch(vel_unused, others, ideal, ivel):
@@ -60,6 +67,8 @@ def get_action_BFS(policy, obs, num_agents_per_layer):
     `policy` must be batched when a tensor is given (`ezpolicy` is)."""
     per = int(num_agents_per_layer)
     ref_style = not torch.is_tensor(obs)
+    if not ref_style and policy is ezpolicy and obs.is_cuda:
+        return bfs_actions(obs, per)
     o = torch.as_tensor(np.asarray(obs, dtype=np.float64))[None] if ref_style else obs
     B, N, D = o.shape
     layers = math.log(N) / math.log(per)
@@ -97,3 +106,24 @@ def get_action_BFS(policy, obs, num_agents_per_layer):
         a = act[0].numpy()
         return [a[i] for i in range(N)]
     return act
+
+
+def bfs_actions(obs, num_agents_per_layer, out=None):
+    """`get_action_BFS(ezpolicy, obs, per)` for a device tensor obs [B, N, 6N] (float32; the env's own observation
+    buffer, or any view of it whose envs are a constant stride apart): one `fg_policy_bfs` launch on the
+    tensor's device and torch's current stream there.  Returns raw actions [B, N, 2] (`out` if given)."""
+    if not (torch.is_tensor(obs) and obs.is_cuda and obs.dim() == 3 and obs.dtype == torch.float32):
+        raise ValueError("bfs_actions needs a float32 CUDA tensor [B, N, 6N]")
+    B, N, D = obs.shape
+    if D != 6 * N:
+        raise ValueError("observation rows of %d floats do not belong to %d agents" % (D, N))
+    if B > 0 and (obs.stride(2) != 1 or obs.stride(1) != D):
+        obs = obs.contiguous()
+    stride = obs.stride(0) if B > 1 else D * N
+    if out is None:
+        out = torch.empty((B, N, 2), dtype=torch.float32, device=obs.device)
+    elif tuple(out.shape) != (B, N, 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != obs.device:
+        raise ValueError("out must be a contiguous float32 tensor [B, N, 2] on the observations' device")
+    _native.check(_native.load().fg_policy_bfs(B, N, int(num_agents_per_layer), obs.data_ptr(), int(stride),
+                                               out.data_ptr(), _native.current_stream(obs.device)))
+    return out

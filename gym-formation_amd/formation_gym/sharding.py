@@ -42,8 +42,11 @@ def make_env_shard(scenario_name, num_agents, global_envs, seed=1, rank=None, wo
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) if local_rank is None else int(local_rank)
     lo, hi = env_slice(global_envs, rank, world_size)
     ndev = max(1, torch.cuda.device_count())
-    env = formation_gym.make_env(scenario_name, False, num_agents, num_envs=hi - lo,
-                                 device=torch.device("cuda", local_rank % ndev), **scenario_kwargs)
+    device = torch.device("cuda", local_rank % ndev)
+    # one process per GPU: the rank's GPU becomes the process's current device, so that everything the caller
+    # allocates next to the env (action pools, rollout buffers, `torch.cuda.current_stream()`) lands on it too
+    torch.cuda.set_device(device)
+    env = formation_gym.make_env(scenario_name, False, num_agents, num_envs=hi - lo, device=device, **scenario_kwargs)
     env.seed(int(seed) + 1000 * lo)              # env b of this rank: seed + 1000 (lo + b)
     return env, lo, hi
 

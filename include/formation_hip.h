@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 2
+#define FG_ABI_VERSION 3
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -226,6 +226,14 @@ int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, 
 #define FG_ACT_INDEX 2
 #define FG_ACT_ARGMAX 3
 int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream);
+
+/* The reference's built-in demo controller for formation_hd_env, all B envs in one launch:
+ * formation_gym.get_action_BFS(formation_gym.ezpolicy, obs_n, per_layer) (formation_gym/__init__.py:49-99
+ * driving :19-47; caller test.py:23).  N must be per_layer^L with 2 <= per_layer <= 8.
+ *   obs  float [B][N][6N] as fg_step_hd / fg_observe_hd write it (only row 0 of every env is read: relative
+ *        positions, ideal shape, ideal velocity); obs_env_stride = floats between consecutive envs, 0 = 6 N^2
+ *   act  float [B][N][2] raw actions, what fg_step_hd takes as `act`. */
+int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream);
 
 #ifdef __cplusplus
 }

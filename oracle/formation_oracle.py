@@ -288,6 +288,20 @@ def step_hd(state, act, P=None, dtype=np.float64, **world_options):
     return new_state, out
 
 
+def benchmark_data_hd(pos, landmarks, indiv, P):
+    """Scenario.benchmark_data (formation_hd_env.py:97-117) for every agent of every env.
+    pos [B,N,2], landmarks [B,L,2] (as they stand when the env calls it: re-centred on the agents by
+    `observation`, :40-44), indiv [B,N] = Scenario.reward.  collisions counts every agent within the reward's
+    contact distance INCLUDING the agent itself (:101-104 has no `a is agent` guard)."""
+    d = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
+    collisions = (d < P.collide_thresh).sum(2)
+    dl = np.sqrt(((pos[:, :, None, :] - landmarks[:, None, :, :]) ** 2).sum(-1)).min(1)      # per landmark: nearest agent
+    B, N = pos.shape[:2]
+    return dict(reward=indiv, collisions=collisions,
+                min_dists=np.repeat(dl.sum(1)[:, None], N, 1),
+                occupied_landmarks=np.repeat((dl < 0.1).sum(1)[:, None], N, 1))
+
+
 def observation_basic(pos, vel, landmarks, dtype=np.float64):
     """basic_formation_env.py:29-41: [v_i | p_i | l_k - p_i | p_j - p_i (j != i) |
     zeros 2(N-1)] -> [B,N,4+2L+4(N-1)]."""
@@ -374,10 +388,16 @@ def ezpolicy(obs):
     return act + (ivel if done else 0.3 * ivel)
 
 
-def get_action_bfs(policy, obs, per_layer):
-    """__init__.py:49-99 breadth-first hierarchical expansion of `policy`."""
+def get_action_bfs(policy, obs, per_layer, strict=True):
+    """__init__.py:49-99 breadth-first hierarchical expansion of `policy`.
+    strict: keep the reference's own shape test (:55-56), which compares a float log ratio with an integer and
+    therefore REJECTS 3^5 = 243, 5^3 = 125 and 6^3 = 216 agents (np.log(243)/np.log(3) = 4.999999999999999);
+    strict=False accepts every exact power (the build's kernel does) so that those sizes can be checked too."""
     layers = np.log(len(obs)) / np.log(per_layer)
-    assert float(layers).is_integer(), "Observation shape error!"
+    if strict:
+        assert float(layers).is_integer(), "Observation shape error!"
+    else:
+        assert per_layer ** int(round(layers)) == len(obs), "Observation shape error!"
     queue = [[np.asarray(o, dtype=np.float64) for o in obs]]
     acts = []
     while queue:
@@ -405,6 +425,49 @@ def get_action_bfs(policy, obs, per_layer):
                 nxt.append(np.concatenate((o[:2], oth, np.zeros(2 * (n_sub - 1)), shp, sub_vel)))
             queue.append(nxt)
     return acts
+
+
+def ezpolicy_margin(obs):
+    """Smallest gap of any comparison `ezpolicy` (__init__.py:35-42) makes on this observation: adjacent
+    distances of the argsort (:35), me-vs-closest-other per mark (:37-38), the 0.01 formation test (:42).
+    A fp32 evaluation may legitimately decide differently only where this is ~1e-6 or less."""
+    obs = np.asarray(obs, dtype=np.float64)
+    n = len(obs) // 6
+    ideal = obs[4 * n - 2:6 * n - 2].reshape(-1, 2)
+    ideal = ideal - ideal.mean(0)
+    cur = np.append(obs[2:2 * n], [0.0, 0.0]).reshape(-1, 2)
+    cur = cur - cur.mean(0)
+    d_me = np.sqrt(((cur[-1] - ideal) ** 2).sum(1))
+    gaps = [np.diff(np.sort(d_me)).min()] if n > 1 else []
+    for k in range(n):
+        d = np.sqrt(((cur - ideal[k]) ** 2).sum(1))
+        gaps.append(abs(d[-1] - d[:-1].min()))
+    gaps.append(abs(np.linalg.norm(ideal - cur) - 0.01))
+    return float(min(gaps))
+
+
+def bfs_margins(obs, per_layer):
+    """Per agent: the smallest `ezpolicy_margin` along the chain of decisions that produce its action in
+    `get_action_bfs` (the group problems of every level it belongs to)."""
+    margins = []
+
+    def policy(inp):
+        margins.append(ezpolicy_margin(inp))
+        return ezpolicy(inp)
+
+    get_action_bfs(policy, obs, per_layer, strict=False)
+    N = len(obs)
+    L = int(round(np.log(N) / np.log(per_layer)))
+    out = np.full(N, np.inf)
+    # `policy` is called level by level, sub-groups in index order (the queue is breadth-first)
+    pos = 0
+    for lev in range(L, 0, -1):
+        n_sub = per_layer ** (lev - 1)
+        for sg in range(N // n_sub):
+            out[sg * n_sub:(sg + 1) * n_sub] = np.minimum(out[sg * n_sub:(sg + 1) * n_sub], margins[pos])
+            pos += 1
+    assert pos == len(margins)
+    return out
 
 
 # --------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # PMC passes over profiles/diag.py workloads; prints mean per launch of each counter.
 export TMPDIR=/tmp
-R=$PWD
+export R=$PWD
 OUT=$R/gpurun_out/diag; mkdir -p $OUT
 PASSES=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
         "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum"

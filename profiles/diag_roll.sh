@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # PMC passes on the default rollout bench (short), each under its own timeout.
 export TMPDIR=/tmp
-R=$PWD; OUT=$R/gpurun_out/diagroll; rm -rf $OUT; mkdir -p $OUT
+export R=$PWD; OUT=$R/gpurun_out/diagroll; rm -rf $OUT; mkdir -p $OUT
 PASSES=("SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"
         "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum"
         "TCC_REQ_sum TCC_TAG_STALL_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_NORMAL_WRITEBACK_sum"

@@ -364,6 +364,40 @@ def policy_fixture(fg, N, T, seed):
     return res
 
 
+def benchmark_fixture(fg, N, T, seed, act_seed, crowd):
+    """make_env(..., benchmark=True): per step the reference's step outputs (unchanged by the flag:
+    environment.py:130-133 forwards only a 'fail' key, which benchmark_data never sets) and, per agent,
+    the dict `Scenario.benchmark_data` (formation_hd_env.py:97-117) returns through `env._get_info`."""
+    env = fg.make_env("formation_hd_env", True, N)
+    env.seed(seed)
+    env.reset()
+    for a in env.world.agents:                              # crowd the agents so that collisions occur
+        a.state.p_pos = a.state.p_pos * crowd
+    sc = _scenario_of(env)
+    p0, v0 = _state(env)
+    lm0 = np.array([l.state.p_pos for l in env.world.landmarks], dtype=np.float64)
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    rec = {k: [] for k in ("pos", "vel", "shared", "indiv", "info_keys", "b_reward", "b_collisions", "b_min_dists",
+                           "b_occupied", "lm")}
+    for t in range(T):
+        obs_n, rew_n, done_n, info_n = env.step([acts[t, i].astype(np.float64) for i in range(N)])
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["shared"].append(rew_n[0][0])
+        rec["indiv"].append([i["individual_reward"] for i in info_n])
+        rec["info_keys"].append(sorted(set(k for i in info_n for k in i.keys())) == ["individual_reward"])
+        infos = [env._get_info(a) for a in env.world.agents]
+        rec["b_reward"].append([i["reward"] for i in infos])
+        rec["b_collisions"].append([i["collisions"] for i in infos])
+        rec["b_min_dists"].append([i["min_dists"] for i in infos])
+        rec["b_occupied"].append([i["occupied_landmarks"] for i in infos])
+        rec["lm"].append(np.array([l.state.p_pos for l in env.world.landmarks], dtype=np.float64))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, lm0=lm0, acts=acts, ideal_shape=np.array(sc.ideal_shape),
+               ideal_vel=np.array(sc.ideal_vel), seed=np.array(seed))
+    return res
+
+
 def hausdorff_kat():
     """scipy's own published docstring example for directed_hausdorff
     (scipy 1.15.3 spatial/distance.py) - the only external KAT on this path."""
@@ -415,6 +449,8 @@ def main():
     save("policy_n3", lambda: policy_fixture(fg, 3, 30, seed=41))
     save("policy_n9", lambda: policy_fixture(fg, 9, 30, seed=42))
     save("policy_n27", lambda: policy_fixture(fg, 27, 12, seed=43))
+    save("policy_n81", lambda: policy_fixture(fg, 81, 4, seed=44))
+    save("benchmark_n9", lambda: benchmark_fixture(fg, 9, 10, seed=91, act_seed=92, crowd=0.12))
     save("hausdorff_kat", lambda: hausdorff_kat())
     # non-default action modes of _set_action (environment.py:187-216)
     save("act_onehot5_n3", lambda: rollout_action_mode(fg, "onehot5", 3, 8, seed=71, act_seed=81))

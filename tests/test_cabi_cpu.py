@@ -40,8 +40,8 @@ def test_abi_version_and_struct_layout(lib, tmp_path):
     """The ctypes mirrors must have the C layout: compile the header with gcc and compare
     sizeof / offsetof of every field."""
     import subprocess
-    assert lib.fg_abi_version() == _native.ABI_VERSION == 2
-    assert "#define FG_ABI_VERSION 2" in open(HEADER).read()
+    assert lib.fg_abi_version() == _native.ABI_VERSION == 3
+    assert "#define FG_ABI_VERSION 3" in open(HEADER).read()
     structs = {"FgParams": _native.FgParams, "FgScenario": _native.FgScenario, "FgWall": _native.FgWall}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "formation_hip.h"', 'int main(void){']
     for name, cls in structs.items():
@@ -120,6 +120,15 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_decode_actions(_native.FG_ACT_INDEX, -3, p, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ARGMAX, 12, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
+    # fg_policy_bfs: N must be per_layer^L, 2 <= per_layer <= 8
+    assert lib.fg_policy_bfs(0, 9, 3, None, 0, None, None) == _native.FG_OK
+    assert lib.fg_policy_bfs(4, 10, 3, p, 0, p, None) == _native.FG_ERR_UNSUPPORTED_N
+    assert b"per_layer" in lib.fg_last_error()
+    assert lib.fg_policy_bfs(4, 81, 9, p, 0, p, None) == _native.FG_ERR_UNSUPPORTED_N     # per_layer > 8
+    assert lib.fg_policy_bfs(4, 9, 3, None, 0, p, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_policy_bfs(4, 9, 3, p, 7, p, None) == _native.FG_ERR_BAD_ARG            # odd / short env stride
+    assert lib.fg_policy_bfs(4, 9, 3, p + 4, 0, p, None) == _native.FG_ERR_ALIGNMENT
+    assert lib.fg_policy_bfs(-1, 9, 3, p, 0, p, None) == _native.FG_ERR_BAD_ARG
     with pytest.raises(_native.FormationHipError):
         _native.check(lib.fg_step_hd(P, -1, 9, *ok_ptrs))
 

@@ -424,6 +424,13 @@ def test_remaining_scenarios_seeded_reset(golden):
         np.testing.assert_allclose(np.array(o), g["obs0"][0], rtol=0, atol=1e-6)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _run(cmd, env_extra=None, timeout=600):
     import os
     import subprocess
@@ -449,7 +456,7 @@ def test_bench_json_contract_single_and_two_ranks():
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
     assert d["state_finite"] and d["value"] > 0 and "workload" in d["config"]
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29571", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
+                "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
                 "--agents", "9", "--backend", "gloo", "--no-extra"])
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1
@@ -458,7 +465,7 @@ def test_bench_json_contract_single_and_two_ranks():
     # default backend with two ranks on ONE GPU: RCCL cannot come up (duplicate device), every rank agrees to
     # keep the timing barrier on gloo and the run still completes
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29573", "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
+                "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
                 "--agents", "9", "--no-extra"], timeout=600)
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1

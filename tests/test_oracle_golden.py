@@ -136,7 +136,7 @@ def test_hausdorff_known_answer(golden):
     assert d2 == float(g["d_vu"]) == 3.0
 
 
-@pytest.mark.parametrize("name,per", [("policy_n3", 3), ("policy_n9", 3), ("policy_n27", 3)])
+@pytest.mark.parametrize("name,per", [("policy_n3", 3), ("policy_n9", 3), ("policy_n27", 3), ("policy_n81", 3)])
 def test_bfs_policy_matches_reference(golden, name, per):
     g = golden(name)
     N = g["pos0"].shape[0]
@@ -151,6 +151,51 @@ def test_bfs_policy_matches_reference(golden, name, per):
     if N == 3:
         ez = np.array([O.ezpolicy(o) for o in g["obs0"]])
         np.testing.assert_allclose(ez, g["ez_act0"], rtol=0, atol=1e-12)
+    # decision margins (what the fp32 GPU test may excuse): one per agent, non-negative, and never larger than
+    # the margin of the top-level problem of the sub-group the agent belongs to
+    m = O.bfs_margins(list(obs), per)
+    assert m.shape == (N,) and (m >= 0).all() and np.isfinite(m).all()
+    tops = np.array([O.ezpolicy_margin(x) for x in _top_level_inputs(obs, per)])
+    assert (m <= np.repeat(tops, N // per) + 1e-15).all()
+
+
+def test_bfs_shape_test_keeps_the_reference_quirk():
+    """__init__.py:55-56 compares a float log ratio with an integer: 243 = 3^5 agents are rejected by the
+    reference itself [probed: np.log(243)/np.log(3) = 4.999999999999999]."""
+    obs = [np.zeros(6 * 243)] * 243
+    with pytest.raises(AssertionError):
+        O.get_action_bfs(O.ezpolicy, obs, 3)
+    with pytest.raises(AssertionError):
+        O.get_action_bfs(O.ezpolicy, [np.zeros(60)] * 10, 3, strict=False)
+
+
+def _top_level_inputs(obs, per):
+    """The `per` observation vectors the top level of get_action_BFS hands to the policy (__init__.py:62-77)."""
+    seen = []
+
+    def spy(inp):
+        seen.append(np.array(inp))
+        return O.ezpolicy(inp)
+
+    O.get_action_bfs(spy, list(obs), per)
+    return seen[:per]
+
+
+def test_benchmark_data_matches_reference(golden):
+    """Scenario.benchmark_data (formation_hd_env.py:97-117) as make_env(benchmark=True) evaluates it."""
+    g = golden("benchmark_n9")
+    assert g["info_keys"].all()                       # the flag changes nothing in step()'s return (environment.py:130-133)
+    P = O.HdParams()
+    for t in range(g["pos"].shape[0]):
+        r = O.reward_hd(g["pos"][t][None], g["vel"][t][None], g["ideal_shape"][None], g["ideal_vel"][None], P)
+        np.testing.assert_allclose(r["indiv"][0], g["indiv"][t], rtol=0, atol=1e-12)
+        bd = O.benchmark_data_hd(g["pos"][t][None], g["lm"][t][None], r["indiv"], P)
+        np.testing.assert_allclose(bd["reward"][0], g["b_reward"][t], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(bd["collisions"][0], g["b_collisions"][t])
+        np.testing.assert_allclose(bd["min_dists"][0], g["b_min_dists"][t], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(bd["occupied_landmarks"][0], g["b_occupied"][t])
+        # the landmarks the reference measures against were re-centred on the agents by observation() (:40-44)
+        np.testing.assert_allclose(g["lm"][t], g["ideal_shape"] + g["pos"][t].mean(0), rtol=0, atol=1e-12)
 
 
 @pytest.mark.parametrize("name", ["hd_n3", "hd_n9_crowd", "hd_n27_crowd"])
