@@ -21,6 +21,16 @@ in HBM), episode length 100 with device-side auto-reset.  Environments are
 independent, so N GPUs run N disjoint slices with no collective (weak scaling:
 B per GPU fixed); the only communication is the timing barrier.
 
+Timing.  A timed BLOCK is exactly --steps steps.  After the warm-up a series of
+R consecutive blocks is timed (the rollout simply continues; R sized so that at
+least --min-timed-ms are timed: a short `--steps 20` command is ONE 0.3 ms
+launch per block and would otherwise be a single noisy sample), the series
+bracketed by a barrier + torch.cuda.synchronize() on both sides, every block
+delimited by HIP events on the launch stream, MAX over ranks per block.  ONE
+clock feeds `value`, `ms_per_step` and `roofline.achieved`: the MEDIAN block on
+the GPU's own timeline (gaps between launches included); min / max / count and
+the host wall clock of the same series are reported beside it (`timing`).
+
 Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs.
 """
 import argparse
@@ -55,6 +65,15 @@ def measured_traffic(n_agents, envs, mode, steps_per_launch):
     return best
 
 
+def n1_reference(workload_key):
+    """env-steps/s of a GLOBAL-batch config measured on ONE GPU (profiles/r02_n1_global_configs.json, written from
+    this script's own N = 1 line): the denominator of `scaling_efficiency_vs_n1`."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_n1_global_configs.json")))[workload_key]
+    except Exception:
+        return None
+
+
 def _cpu_port_worker(args):
     """One env of the faithful per-env port, `steps` steps; returns elapsed seconds."""
     n_agents, steps, seed = args
@@ -72,6 +91,14 @@ def _cpu_port_worker(args):
     return time.perf_counter() - t0
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        return "unknown"
+
+
 def cpu_baseline(n_agents, budget_s=12.0):
     """The oracle's per-env port (same loop structure as the reference) on the host
     cores: one env per process, bounded sample.  Reported baseline only."""
@@ -85,23 +112,57 @@ def cpu_baseline(n_agents, budget_s=12.0):
     with ctx.Pool(cores) as pool:
         elapsed = pool.map(_cpu_port_worker, [(n_agents, steps, 1 + 1000 * r) for r in range(cores)])
     wall = max(elapsed)
-    model = "unknown"
-    try:
-        with open("/proc/cpuinfo") as f:
-            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
-    except OSError:
-        pass
     return {
         "value": round(cores * steps / wall, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": "%d envs x %d steps of formation_hd_env N=%d, one env per process "
                   "(oracle.PortEnv, numpy/scipy, fp64), wall = slowest worker %.1fs; "
                   "pool start-up excluded (%.1fs total)" % (cores, steps, n_agents, wall, time.perf_counter() - t0),
         "agent_steps_per_s": round(cores * steps * n_agents / wall, 1),
-        "cpu_model": model,
+        "cpu_model": _cpu_model(),
         # the reference's files never travel to the GPU box; this port was timed against the REAL
         # reference in the build container (8 vCPU Xeon 2.1 GHz, one env per process):
         "calibration": "port / reference env-steps/s on the same 8 cores: 325 / 321 at N=27, 1130 / 1298 at N=9",
     }
+
+
+def config1(dev):
+    """BASELINE.json configs[0] / SURVEY 8(d) C1: basic_formation_env, 3 agents, 1 env, U(-1,1) actions, 1 000 steps
+    with a reset every 50 - the plumbing case.  (a) the oracle's restatement on ONE host core, (b) the same loop
+    through this build's reference-style list API (`make_env` / `env.step(list of arrays)`, one launch and one
+    pinned copy each way per step)."""
+    import numpy as np
+    from oracle import formation_oracle as O
+    steps = 1000
+    acts = np.random.RandomState(1).uniform(-1, 1, (steps, 1, 3, 2))
+    st = O.reset_basic(1, 3)
+    t0 = time.perf_counter()
+    ep = 0
+    for t in range(steps):
+        st, out = O.step_basic(st, acts[t])
+        if out["done"].all():
+            ep += 1
+            st = O.reset_basic(1 + ep, 3)
+    cpu_s = time.perf_counter() - t0
+    import formation_gym
+    env = formation_gym.make_env("basic_formation_env", False, 3, device=dev)
+    env.seed(1)
+    env.reset()
+    a32 = acts.astype(np.float32)
+    for t in range(20):                                                  # bindings, pinned buffers, clocks
+        env.step([a32[t, 0, i].copy() for i in range(3)])
+    env.reset()
+    t0 = time.perf_counter()
+    for t in range(steps):
+        _, _, done_n, _ = env.step([a32[t, 0, i].copy() for i in range(3)])
+        if all(done_n):
+            env.reset()
+    gpu_s = time.perf_counter() - t0
+    return {"workload": "basic_formation_env, 3 agents x 1 env, 1000 steps, reset every 50 (BASELINE configs[0])",
+            "cpu_port": {"env_steps_per_s": round(steps / cpu_s, 1), "cores": 1, "kind": "port",
+                         "what": "oracle.step_basic (vectorised NumPy restatement, fp64) at B = 1"},
+            "gpu_list_api": {"env_steps_per_s": round(steps / gpu_s, 1), "us_per_call": round(gpu_s / steps * 1e6, 1),
+                             "what": "env.step(list of 3 arrays) -> lists: one fg_step_basic launch + one pinned copy "
+                                     "each way per call, host resets (MT19937) every 50 steps; latency-bound by design"}}
 
 
 def main():
@@ -114,18 +175,23 @@ def main():
     ap.add_argument("--mode", choices=["step", "rollout"], default="rollout",
                     help="step: one fg_step_hd launch per step; rollout: fg_rollout_hd, --chunk steps per launch")
     ap.add_argument("--chunk", type=int, default=20)
+    ap.add_argument("--min-timed-ms", type=float, default=50.0,
+                    help="repeat the timed block of --steps steps until this much GPU time has been timed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true", help="tuning aid: episodes never reset")
     ap.add_argument("--obs-every", type=int, default=1,
                     help="tuning aid (rollout mode): write an observation only every n-th step; the JSON line is "
                          "then NOT a valid benchmark result")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary rollout-mode measurement")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no other mode / shapes / config 1)")
     ap.add_argument("--no-small-buffer", action="store_true",
                     help="skip the extra 4-steps-per-launch (Infinity-Cache-sized buffer) measurement")
     ap.add_argument("--prewarm-ms", type=float, default=150.0,
                     help="untimed stepping before the W warm-up steps, so that short runs are not measured during the clock ramp")
     ap.add_argument("--no-other-configs", action="store_true",
-                    help="skip the short runs of the other BASELINE per-GPU shapes (9 x 4096, 81 x 2048, 243 x 8192)")
+                    help="skip the short runs of the other BASELINE shapes")
+    ap.add_argument("--global-div", type=int, default=1,
+                    help="test aid: run the GLOBAL-batch configs (BASELINE configs[3], [4]) with their batch sizes divided "
+                         "by this, whatever the headline shape is (the lines are marked)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
@@ -191,25 +257,52 @@ def main():
             dist.barrier(group=sync_group)
         torch.cuda.synchronize()
 
-    def measure(N, B, mode, steps, warmup, chunk_req, other_steps):
-        """Times `steps` env steps of N agents x B envs per GPU in `mode` (and, if other_steps > 0, the
-        other launch mode beside it).  Returns wall seconds and HIP-event milliseconds, MAX over ranks."""
+    def per_rank(value):
+        """The value of every rank, in rank order (host-side gather over the gloo group)."""
+        if world_size == 1:
+            return [float(value)]
+        bucket = [None] * world_size
+        dist.all_gather_object(bucket, float(value))
+        return bucket
+
+    def max_vec(xs):
+        """Element-wise MAX over ranks of a list of floats."""
+        if world_size == 1:
+            return list(xs)
+        t = torch.tensor(xs, dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sync_group)
+        return t.tolist()
+
+    def median(xs):
+        s = sorted(xs)
+        return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
+
+    def measure(N, B, mode, steps, warmup, chunk_req, other_steps=0, global_envs=None, policy=False):
+        """Times blocks of `steps` env steps of N agents x B envs on this GPU in `mode` (and, if other_steps > 0,
+        the other launch mode beside it).  global_envs: this rank owns its slice of a GLOBAL batch of that many envs
+        (default: B per GPU, weak scaling).  policy: closed loop with the built-in controller (rollout_policy)."""
         # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
         # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
-        env, lo, hi = sharding.make_env_shard("formation_hd_env", N, B * world_size, seed=1, rank=rank,
+        env, lo, hi = sharding.make_env_shard("formation_hd_env", N, global_envs or B * world_size, seed=1, rank=rank,
                                               world_size=world_size, local_rank=local_rank)
-        env.reset()
+        B = hi - lo
+        if B > 65536:
+            env.scenario.reset_device(env.world, rng_offset=999)   # host MT19937 streams for > 65536 envs take minutes
+        else:
+            env.reset()
         env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
         env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device
         env.world.step_count.zero_()
 
         # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
-        chunk = max(1, min(chunk_req, int(48e9 // (B * N * 6 * N * 4)) or 1))
+        chunk = max(1, min(chunk_req, int(48e9 // max(1, B * N * 6 * N * 4)) or 1))
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
-        act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
         out = env._out
-        launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=not a.no_auto_reset) for i in range(P)]
+        act_pool, launchers = None, []
+        if not policy:
+            act_pool = (torch.rand((P, B, N, 2), generator=gen, device=dev) * 2 - 1).contiguous()
+            launchers = [env.scenario.bind_step(env.world, act_pool[i], out, auto_reset=not a.no_auto_reset) for i in range(P)]
 
         def run_steps(n, start):
             for t in range(start, start + n):
@@ -226,33 +319,61 @@ def main():
                             obs_every=a.obs_every)
                 t += k
 
+        def run_policy_rollout(n, start):
+            t = start
+            while t < start + n:
+                k = min(chunk, start + n - t)
+                env.rollout_policy(k, 3, out={k2: v[:k] for k2, v in seq.items()})
+                t += k
+
+        def run_policy_steps(n, start):
+            obs = out["obs"]
+            for t in range(start, start + n):
+                obs = env.step(formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3))[0]
+
         def timed(fn, n, w):
             # untimed: bring the GPU to its running clocks first (a short --steps/--warmup pair would otherwise
             # be measured during the DVFS ramp), then the W warm-up steps the caller asked for
             t_end = time.perf_counter() + a.prewarm_ms * 1e-3
-            pre = 0
+            cursor = 0
             while time.perf_counter() < t_end:
-                fn(chunk, pre)
-                pre += chunk
-                if pre % (8 * chunk) == 0:
+                fn(chunk, cursor)
+                cursor += chunk
+                if cursor % (8 * chunk) == 0:
                     torch.cuda.synchronize()
-            fn(w, pre)
-            w += pre
-            barrier()
+            fn(w, cursor)
+            cursor += w
+            # calibration: ONE block, to size the series (not reported)
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
+            barrier()
             ev0.record()
-            fn(n, w)
+            fn(n, cursor)
             ev1.record()
-            while not ev1.query():                             # completion seen by polling the closing event: the clock
-                pass                                           # is read when the K steps are done, not when a blocked
-            wall = time.perf_counter() - t0                    # host thread has been woken up; start barrier -> local completion
+            torch.cuda.synchronize()
+            cursor += n
+            t1 = sharding.max_over_ranks(ev0.elapsed_time(ev1), red_dev, sync_group)             # same value on every rank
+            R = int(min(4000, max(1, -(-a.min_timed_ms // max(t1, 1e-3)))))
+            # the timed series: R consecutive blocks of exactly n steps, each delimited by HIP events on the launch
+            # stream, the series bracketed by barrier + device synchronize.  The stream never idles between blocks
+            # (the host queues ahead), which is how a rollout loop runs; a block that started on an idle GPU would
+            # add the launch latency of its first kernel to every sample.
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+            barrier()
+            t0 = time.perf_counter()
+            evs[0].record()
+            for r_ in range(R):
+                fn(n, cursor)
+                cursor += n
+                evs[r_ + 1].record()
+            while not evs[R].query():                          # completion seen by polling the closing event
+                pass
+            wall = time.perf_counter() - t0
             torch.cuda.synchronize()
             barrier()
-            dev_ms = ev0.elapsed_time(ev1)
-            wall = sharding.max_over_ranks(wall, red_dev, sync_group)          # slowest rank
-            dev_ms = sharding.max_over_ranks(dev_ms, red_dev, sync_group)
-            return wall, dev_ms
+            local_blocks = [evs[r_].elapsed_time(evs[r_ + 1]) for r_ in range(R)]
+            dev_blocks = max_vec(local_blocks)                 # per block: the slowest rank
+            wall_blocks = [sharding.max_over_ranks(wall, red_dev, sync_group) * 1e3 / R] * R
+            return dev_blocks, wall_blocks, local_blocks
 
         seq = None
         if mode == "rollout" or other_steps > 0:
@@ -260,17 +381,28 @@ def main():
             seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
                        indiv=torch.empty((chunk, B, N), **f),
                        done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
-        fns = {"step": run_steps, "rollout": run_rollout}
-        wall, dev_ms = timed(fns[mode], steps, warmup)
+            if policy:
+                seq["act"] = torch.empty((chunk, B, N, 2), **f)
+        if policy:
+            env.scenario.observe_batch(env.world, {"obs": out["obs"], "reward": out["reward"]})
+            fns = {"step": run_policy_steps, "rollout": run_policy_rollout}
+        else:
+            fns = {"step": run_steps, "rollout": run_rollout}
+        dev_blocks, wall_blocks, local_blocks = timed(fns[mode], steps, warmup)
         bytes_per_env_step = _native.step_hd_bytes(N)
-        r = {"wall": wall, "dev_ms": dev_ms, "chunk": chunk, "bytes_per_env_step": bytes_per_env_step, "extra": None}
+        med = median(dev_blocks)                                     # every block is already the MAX over ranks
+        r = {"ms": med, "blocks": dev_blocks, "wall_blocks": wall_blocks, "local_ms": median(local_blocks),
+             "chunk": chunk, "B": B,
+             "bytes_per_env_step": bytes_per_env_step, "extra": None,
+             "GBps": bytes_per_env_step * B * steps / (med * 1e-3) / 1e9}
         if other_steps > 0:
             other = "rollout" if mode == "step" else "step"
-            w2, d2 = timed(fns[other], other_steps, min(warmup, 40))
-            r["extra"] = {"mode": other, "steps": other_steps,
-                          "env_steps_per_s": round(world_size * B * other_steps / w2, 1),
-                          "ms_per_step": round(w2 * 1e3 / other_steps, 5),
-                          "achieved_GBps": round(bytes_per_env_step * B * other_steps / (d2 * 1e-3) / 1e9, 1)}
+            d2, w2, _ = timed(fns[other], other_steps, min(warmup, 40))
+            m2 = median(d2)
+            r["extra"] = {"mode": other, "steps": other_steps, "blocks": len(d2),
+                          "env_steps_per_s": round(world_size * B * other_steps / (m2 * 1e-3), 1),
+                          "ms_per_step": round(m2 / other_steps, 5),
+                          "achieved_GBps": round(bytes_per_env_step * B * other_steps / (m2 * 1e-3) / 1e9, 1)}
             if other == "rollout":
                 r["extra"]["chunk"] = chunk
         pos, _ = env.world.get_state()
@@ -279,10 +411,24 @@ def main():
         torch.cuda.empty_cache()
         return r
 
+    def shape_line(n2, b2, st2, m2, mode, global_envs=None):
+        g = m2["GBps"]
+        total_envs = global_envs if global_envs else m2["B"] * world_size
+        line = {"workload": "formation_hd_env, %d agents x %d envs per GPU" % (n2, m2["B"]), "mode": mode,
+                "steps": st2, "blocks": len(m2["blocks"]), "steps_per_launch": 1 if mode == "step" else m2["chunk"],
+                "env_steps_per_s": round(total_envs * st2 / (m2["ms"] * 1e-3), 1),
+                "agent_steps_per_s": round(total_envs * n2 * st2 / (m2["ms"] * 1e-3), 1),
+                "ms_per_step": round(m2["ms"] / st2, 5), "achieved_GBps": round(g, 1),
+                "frac_of_hbm_peak": round(g / HBM_PEAK_GBPS, 4), "other_mode": m2["extra"],
+                "state_finite": m2["finite"]}
+        return line
+
     N, B = a.agents, a.envs
+    headline = (N, B) == (27, 4096)
     m = measure(N, B, a.mode, a.steps, a.warmup, a.chunk, 0 if a.no_extra else min(a.steps, 400))
-    wall, dev_ms, chunk, extra, finite = m["wall"], m["dev_ms"], m["chunk"], m["extra"], m["finite"]
+    chunk, extra, finite = m["chunk"], m["extra"], m["finite"]
     bytes_per_env_step = m["bytes_per_env_step"]
+    ms_block = m["ms"]                                          # median block, HIP events, MAX over ranks
 
     # The same workload with a rollout buffer that (nearly) fits the 256 MiB Infinity Cache: 4 steps per launch, the
     # buffer overwritten launch after launch.  The store stream is then absorbed by the cache instead of streaming to
@@ -290,60 +436,108 @@ def main():
     # that reads the observations right after each launch sees this rate.
     small = None
     if world_size == 1 and not a.no_extra and not a.no_small_buffer and a.mode == "rollout" and a.chunk > 4 \
-            and a.obs_every == 1 and (N, B) == (27, 4096):
-        m4 = measure(N, B, "rollout", min(a.steps, 400), min(a.warmup, 40), 4, 0)
-        g4 = m4["bytes_per_env_step"] * B * min(a.steps, 400) / (m4["dev_ms"] * 1e-3) / 1e9
+            and a.obs_every == 1 and headline:
+        s4 = min(a.steps, 400)
+        m4 = measure(N, B, "rollout", s4, min(a.warmup, 40), 4)
         small = {"steps_per_launch": m4["chunk"], "buffer_MB": round(m4["chunk"] * B * N * 6 * N * 4 / 1e6, 1),
-                 "ms_per_step": round(m4["wall"] * 1e3 / min(a.steps, 400), 5),
-                 "env_steps_per_s": round(B * min(a.steps, 400) / m4["wall"], 1), "algorithmic_GBps": round(g4, 1),
+                 "ms_per_step": round(m4["ms"] / s4, 5),
+                 "env_steps_per_s": round(B * s4 / (m4["ms"] * 1e-3), 1), "algorithmic_GBps": round(m4["GBps"], 1),
                  "note": "observation buffer resident in the Infinity Cache and overwritten every launch: cache-absorbed "
                          "stores, not an HBM-streaming figure"}
 
-    # the other BASELINE.json per-GPU shapes, short runs in the same process (N = 1 only; reported beside the
-    # headline workload, never as `value`)
-    others = []
-    if world_size == 1 and not a.no_extra and not a.no_other_configs and (N, B) == (27, 4096):
-        for n2, b2, st2 in ((9, 4096, 400), (81, 2048, 200), (243, 8192, 24)):
-            m2 = measure(n2, b2, a.mode, st2, max(4, st2 // 10), a.chunk, st2)
-            g = m2["bytes_per_env_step"] * b2 * st2 / (m2["dev_ms"] * 1e-3) / 1e9
-            others.append({"workload": "formation_hd_env, %d agents x %d envs per GPU" % (n2, b2), "mode": a.mode,
-                           "steps": st2, "steps_per_launch": 1 if a.mode == "step" else m2["chunk"],
-                           "env_steps_per_s": round(b2 * st2 / m2["wall"], 1),
-                           "agent_steps_per_s": round(b2 * n2 * st2 / m2["wall"], 1),
-                           "ms_per_step": round(m2["wall"] * 1e3 / st2, 5), "achieved_GBps": round(g, 1),
-                           "frac_of_hbm_peak": round(g / HBM_PEAK_GBPS, 4), "other_mode": m2["extra"],
-                           "state_finite": m2["finite"]})
+    others, global_cfgs, closed_loop, c1 = [], [], None, None
+    if not a.no_extra and not a.no_other_configs and (headline or a.global_div > 1):
+        if world_size == 1 and headline:
+            # the other BASELINE.json per-GPU shapes, short runs in the same process (reported beside the headline
+            # workload, never as `value`)
+            for n2, b2, st2 in ((9, 4096, 400), (81, 2048, 200), (243, 8192, 24)):
+                m2 = measure(n2, b2, a.mode, st2, max(4, st2 // 10), a.chunk, st2)
+                others.append(shape_line(n2, b2, st2, m2, a.mode))
+            # closed loop with the built-in controller (get_action_BFS + ezpolicy, reference test.py:23) in the loop
+            mp_ = measure(N, B, a.mode, min(a.steps, 200), 20, a.chunk, min(a.steps, 200), policy=True)
+            closed_loop = shape_line(N, B, min(a.steps, 200), mp_, a.mode)
+            closed_loop["workload"] += ", actions from the built-in BFS controller"
+            closed_loop["note"] = ("rollout: fg_rollout_hd_policy, the controller runs inside the rollout kernel; step: one "
+                                   "fg_policy_bfs + one fg_step_hd launch per step")
+        # BASELINE.json configs[3] and configs[4]: GLOBAL batches of 81 x 16384 and 243 x 65536 envs cut into
+        # world_size contiguous slices (strong scaling: the global batch is fixed, each rank owns 1/world_size)
+        for n2, g2, st2 in ((81, 16384 // a.global_div, 40), (243, 65536 // a.global_div, 8)):
+            per_gpu = g2 // world_size
+            if per_gpu * n2 * 6 * n2 * 4 > 150e9:                 # the observation buffer of ONE step must fit beside the rest
+                global_cfgs.append({"workload": "formation_hd_env, %d agents x %d envs GLOBAL" % (n2, g2),
+                                    "skipped": "a slice of %d envs per GPU needs %.0f GB of observations per step"
+                                               % (per_gpu, per_gpu * n2 * 6 * n2 * 4 / 1e9)})
+                continue
+            m2 = measure(n2, per_gpu, a.mode, st2, max(2, st2 // 10), a.chunk, 0, global_envs=g2)
+            line = shape_line(n2, per_gpu, st2, m2, a.mode, global_envs=g2)
+            line["workload"] = "formation_hd_env, %d agents x %d envs GLOBAL over %d GPU(s) (BASELINE configs[%d])" % (
+                n2, g2, world_size, 3 if n2 == 81 else 4)
+            line["scaling"] = "strong"
+            if a.global_div > 1:
+                line["test_scale_div"] = a.global_div
+            line["envs_per_gpu"] = m2["B"]
+            ranks_ms = per_rank(m2["local_ms"])                   # each rank's own median block
+            line["per_rank_ms_per_step"] = [round(x / st2, 5) for x in ranks_ms]
+            line["slowest_rank"] = int(max(range(world_size), key=lambda r_: ranks_ms[r_]))
+            key = "%dx%d" % (n2, g2)
+            ref = n1_reference(key)
+            line["n1_env_steps_per_s"] = ref
+            line["scaling_efficiency_vs_n1"] = round(line["env_steps_per_s"] / (world_size * ref), 4) if ref else None
+            global_cfgs.append(line)
+        if world_size == 1 and headline:
+            c1 = config1(dev)
 
     if rank == 0:
-        launches = a.steps if a.mode == "step" else None
-        achieved = bytes_per_env_step * B * a.steps / (dev_ms * 1e-3) / 1e9      # GB/s per GPU
+        blocks, walls = m["blocks"], m["wall_blocks"]
+        value = world_size * B * a.steps / (ms_block * 1e-3)
+        achieved = m["GBps"]                                      # GB/s per GPU, same clock as `value`
         cfg = _native.kernel_config(N)
+        spl = 1 if a.mode == "step" else chunk
+        alg_launch = bytes_per_env_step * B * spl
+        traffic, traffic_src = measured_traffic(N, B, a.mode, spl)
         res = {
-            "metric": "env-steps/sec", "value": round(world_size * B * a.steps / wall, 1), "unit": "env-steps/s",
-            "agent_steps_per_s": round(world_size * B * N * a.steps / wall, 1),
+            "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
+            "agent_steps_per_s": round(value * N, 1),
             "n_gpus": world_size, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(wall * 1e3 / a.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_block / a.steps, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "formation_hd_env, %d agents x %d envs per GPU, random policy, "
                                    "episode 100 with device auto-reset" % (N, B),
                        "baseline_config": "BASELINE.json configs[2] (27 agents x 4096 envs, the shape the north-star target "
                                           "is quoted on); configs[1] and the per-GPU shapes of configs[3], configs[4] are "
-                                          "under other_configs at N = 1" if (N, B) == (27, 4096) else "custom shape",
+                                          "under other_configs at N = 1, their GLOBAL batches under global_configs"
+                                          if headline else "custom shape",
                        "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
                        "timing_barrier": sync_backend,
-                       "steps_per_launch": 1 if a.mode == "step" else chunk,
+                       "steps_per_launch": spl,
                        "kernel": ("fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"]))
                        if a.mode == "step" else "fg::rollout_kernel<%d> (producer/writer pipelined)" % N},
+            "timing": {"clock": "HIP events on the launch stream delimiting consecutive blocks of --steps steps (the series "
+                                "bracketed by barrier + device synchronize, MAX over ranks per block); value, ms_per_step "
+                                "and roofline.achieved all come from the MEDIAN block",
+                       "blocks": len(blocks), "timed_ms_total": round(sum(blocks), 3),
+                       "block_ms_median": round(ms_block, 5), "block_ms_min": round(min(blocks), 5),
+                       "block_ms_max": round(max(blocks), 5),
+                       "wall_block_ms_median": round(median(walls), 5),
+                       "wall_env_steps_per_s_median": round(world_size * B * a.steps / (median(walls) * 1e-3), 1),
+                       "note": "wall = host clock over the whole series / blocks (first launch latency and the completion "
+                                "poll included once)"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": measured_traffic(N, B, a.mode, 1 if a.mode == "step" else chunk)[0],
-                         "traffic_source": measured_traffic(N, B, a.mode, 1 if a.mode == "step" else chunk)[1],
-                         "algorithmic_bytes_per_launch": bytes_per_env_step * B * (1 if a.mode == "step" else chunk),
-                         "avg_launch_us": round(dev_ms * 1e3 / a.steps * (1 if a.mode == "step" else chunk), 3),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": alg_launch,
+                         "avg_launch_us": round(ms_block * 1e3 / a.steps * spl, 3),
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
             "state_finite": finite,
         }
+        if traffic:
+            # the SURVEY 8(d) formula counts the pos/vel round trip of every step; a K-step launch keeps the state in
+            # registers, so the PMC counters see fewer bytes (committed profile: ratio below); both are reported
+            ratio = traffic / alg_launch
+            res["roofline"]["counter_to_algorithmic_bytes"] = round(ratio, 4)
+            res["roofline"]["achieved_counter_bytes"] = round(achieved * ratio, 1)
+            res["roofline"]["frac_counter_bytes"] = round(achieved * ratio / HBM_PEAK_GBPS, 4)
         if a.obs_every != 1:
             res["INVALID"] = "observations written only every %d-th step (tuning run)" % a.obs_every
         if extra:
@@ -352,6 +546,12 @@ def main():
             res["rollout_cache_resident_buffer"] = small
         if others:
             res["other_configs"] = others
+        if closed_loop:
+            res["closed_loop_policy"] = closed_loop
+        if global_cfgs:
+            res["global_configs"] = global_cfgs
+        if c1:
+            res["config1"] = c1
         if world_size == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(N)
         print(json.dumps(res), flush=True)

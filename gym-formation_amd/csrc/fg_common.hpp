@@ -65,6 +65,10 @@ struct Args {
     float* indiv;              // [K][B][N] or NULL
     uint8_t* done;             // [K][B][N] or NULL
     int32_t* near_lm; int32_t* near_ag; int32_t* hd_idx;
+    // closed-loop rollouts (fg_rollout_hd_policy): the actions come from the demo controller (fg_policy_kernels.hpp)
+    // evaluated on the workgroup's own state instead of from `act`
+    FgPolicyLevels pl;
+    float* act_out;            // [K][B][N][2] the actions taken
 };
 
 // ---------------------------------------------------------------------------

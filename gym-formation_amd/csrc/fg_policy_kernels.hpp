@@ -192,6 +192,34 @@ __global__ __launch_bounds__(256) void policy_bfs_kernel(const int B, const int 
         for (int a = lane; a < N; a += lpe) reinterpret_cast<float2*>(act)[(size_t)b * N + a] = res[a];
 }
 
+// The same controller straight from the simulator state (no observation needed): R[a] = p_a - p_0 is the very
+// subtraction the observation writers perform, so the actions equal `policy_bfs_kernel` on the written rows bit for bit.
+template <int PER>
+__global__ __launch_bounds__(256) void policy_state_kernel(const int B, const int N, const int lpe, const FgPolicyLevels pl,
+                                                           const float* __restrict__ px, const float* __restrict__ py,
+                                                           const float* __restrict__ shape, const float* __restrict__ ivel,
+                                                           float* __restrict__ act) {
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    const int tid = threadIdx.x;
+    const int E = 256 / lpe;
+    const int e = tid / lpe, lane = tid - e * lpe;
+    const int b = blockIdx.x * E + e;
+    const bool ok = b < B;
+    float2* const tab = smem + e * policy_block_units(N);
+    float2 iv = make_float2(0.f, 0.f);
+    const size_t s0 = (size_t)(ok ? b : 0) * N;
+    const float x0 = ok ? px[s0] : 0.f, y0 = ok ? py[s0] : 0.f;
+    for (int a = lane; a < N; a += lpe) {
+        tab[a] = ok ? make_float2(px[s0 + a] - x0, py[s0 + a] - y0) : make_float2(0.f, 0.f);
+        tab[N + a] = ok ? reinterpret_cast<const float2*>(shape)[s0 + a] : make_float2(0.f, 0.f);
+    }
+    if (ok) iv = reinterpret_cast<const float2*>(ivel)[b];
+    __syncthreads();
+    const float2* res = bfs_policy_env<PER>(tab, N, pl, iv, lane, lpe, BlockSync());
+    if (ok)
+        for (int a = lane; a < N; a += lpe) reinterpret_cast<float2*>(act)[(size_t)b * N + a] = res[a];
+}
+
 }  // namespace fg
 
 #endif  // FG_POLICY_KERNELS_HPP_

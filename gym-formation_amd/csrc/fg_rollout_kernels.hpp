@@ -6,6 +6,7 @@
 #include "fg_common.hpp"
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
+#include "fg_policy_kernels.hpp"
 
 namespace fg {
 
@@ -24,9 +25,11 @@ namespace fg {
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
 
-template <int NC, int G, int TP, int TW, int E, int WR>
+template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY = false>
 __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
+    // POLICY: closed loop - the action of step k is the demo controller (3-ary hierarchy) on the state step k-1
+    //         left, evaluated by the env's own lane group; a.act is not read, a.act_out records the actions
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
     constexpr int NPS = NP <= 16 ? NP : 0;              // small N: partners fetched up front (fg_pair_loops.hpp)
@@ -74,24 +77,41 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     // use to cover an HBM round trip inside one step).  Two registers alternate roles over a loop
     // unrolled by two, so that no copy (and with it the load's wait) lands inside the issuing step.
     float2 u_even = make_float2(0.f, 0.f), u_odd = u_even;
-    if (valid) u_even = reinterpret_cast<const float2*>(a.act)[sidx];
+    if (!POLICY && valid) u_even = reinterpret_cast<const float2*>(a.act)[sidx];
     const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
     const float2* act_next = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0) + (a.K > 1 ? act_stride : 0);
+    // closed loop: controller tables of this env behind the env blocks and the writers' tiles
+    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) +
+                            (WR > 0 ? 2 * NWW * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() : 0) + e * policy_block_units(N);
 
     // one producer step: World.step + reward of step k into table buffer (k & 1);
     // u_cur = action of step k (loaded during step k-1), u_nxt receives the action of step k+1
     auto produce = [&](int k, const float2& u_cur, float2& u_nxt) {
         float2* const A = TB0 + (k & 1) * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        float2 u_act = u_cur;
+        if constexpr (POLICY) {
+            // get_action_BFS(ezpolicy, obs, 3) on the observation the previous step (or the reset) returned:
+            // its row 0 holds p_j - p_0, exactly this subtraction; QX / QY hold the current positions
+            if (valid) { pol_tab[i] = make_float2(p.x - QX[0], p.y - QY[0]); pol_tab[N + i] = s; }
+            WaveSync()();
+            const float2* res = bfs_policy_env<3>(pol_tab, N, a.pl, iv, i, G, WaveSync());
+            if (valid) {
+                u_act = res[i];
+                if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u_act;
+            }
+        }
         if (valid) {
             // always issued (clamped to the last step): with a known number of younger loads the
             // wait for u_cur can leave this prefetch in flight
-            u_nxt = *act_next;
-            act_next += (k + 2 < a.K) ? act_stride : 0;
+            if constexpr (!POLICY) {
+                u_nxt = *act_next;
+                act_next += (k + 2 < a.K) ? act_stride : 0;
+            }
             float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                  a.p.dist_min, cutoff2);
-            f.x += a.p.mass * (a.p.sensitivity * u_cur.x);
-            f.y += a.p.mass * (a.p.sensitivity * u_cur.y);
+            f.x += a.p.mass * (a.p.sensitivity * u_act.x);
+            f.y += a.p.mass * (a.p.sensitivity * u_act.y);
             v.x = v.x * one_minus_damp + (f.x / a.p.mass) * dt;
             v.y = v.y * one_minus_damp + (f.y / a.p.mass) * dt;
             p.x += v.x * dt;
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
 // that every reduction stays inside the wave and producers still need no barrier of their own.
 // The partner loops load each partner pair once and update all A agents of the lane.
 // ---------------------------------------------------------------------------
-template <int NC, int A, int E, int TW>
+template <int NC, int A, int E, int TW, bool POLICY = false>
 __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a) {
     static_assert(A * 64 >= NC && (A - 1) * 64 < NC && TW % 64 == 0, "bad wide rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64, TP = E * 64;
@@ -273,9 +293,20 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         if (a.step && env_ok && lane == 0) a.step[b] = t_step;
     };
 
+    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + e * policy_block_units(N);
     auto produce = [&](int k, int buf) {
         float2* const T = TB0 + buf * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float2* pol_res = nullptr;
+        if constexpr (POLICY) {                         // closed loop: see rollout_kernel
+#pragma unroll
+            for (int q = 0; q < A; ++q) {
+                const int i = lane + 64 * q;
+                if (valid[q]) { pol_tab[i] = make_float2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
+            }
+            WaveSync()();
+            pol_res = bfs_policy_env<3>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
+        }
         // ---- World.step: all A agents of the lane against each partner pair ----
         float fx[A], fy[A];
 #pragma unroll
@@ -314,7 +345,13 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             part[q][0] = part[q][1] = part[q][2] = part[q][3] = 0.f;
             if (valid[q]) {
                 const int i = lane + 64 * q;
-                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                float2 u;
+                if constexpr (POLICY) {
+                    u = pol_res[i];
+                    if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u;
+                } else {
+                    u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                }
                 const float ffx = fx[q] + a.p.mass * (a.p.sensitivity * u.x);
                 const float ffy = fy[q] + a.p.mass * (a.p.sensitivity * u.y);
                 v[q].x = v[q].x * one_minus_damp + (ffx / a.p.mass) * dt;

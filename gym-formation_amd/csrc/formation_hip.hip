@@ -149,7 +149,7 @@ static int launch_step(Args a, hipStream_t st) {
 }
 
 // 64 < N <= 256: producer / writer pipelined kernel (rollout: over steps; single step: over env batches)
-template <int NC, int A, int E, int TW>
+template <int NC, int A, int E, int TW, bool POLICY>
 static int launch_wide_v(Args a, hipStream_t st) {
     if (a.K == 1) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
@@ -162,47 +162,51 @@ static int launch_wide_v(Args a, hipStream_t st) {
         a.groups = 1;
     }
     const int grid = (a.B + E * a.groups - 1) / (E * a.groups);
-    const int lds = E * roll_block_floats(NC) * (int)sizeof(float);
+    const int lds = E * roll_block_floats(NC) * (int)sizeof(float) +
+                    (POLICY ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, POLICY>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, POLICY>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+template <bool POLICY = false>
 static int launch_wide(const Args& a, hipStream_t st) {
-    return a.N == 81 ? launch_wide_v<81, 2, 4, 256>(a, st) : launch_wide_v<243, 4, 4, 256>(a, st);
+    return a.N == 81 ? launch_wide_v<81, 2, 4, 256, POLICY>(a, st) : launch_wide_v<243, 4, 4, 256, POLICY>(a, st);
 }
 
 // N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
-template <int NC, int G, int TP, int TW, int E, int WR>
+template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY>
 static int launch_roll_v(const Args& a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
     if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
+    if (POLICY) lds += E * policy_block_units(NC) * (int)sizeof(float2);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, POLICY>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR>), dim3(grid), dim3(TP + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR, POLICY>), dim3(grid), dim3(TP + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+template <bool POLICY = false>
 static int launch_roll(const Args& a, hipStream_t st) {
     // Defaults from the MI355X sweeps (profiles/README.md).  27 agents: 16 envs per workgroup = 8 producer + 4
     // writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.  9 agents: a batch of <= 4096 envs is
     // bound by the producers' dependent chain and wants many small workgroups with the row writer; larger
     // batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
-    if (a.N == 27) return launch_roll_v<27, 32, 512, 256, 16, 10>(a, st);
+    if (a.N == 27) return launch_roll_v<27, 32, 512, 256, 16, 10, POLICY>(a, st);
     if (a.N == 9) {
-        if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10>(a, st);
-        if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10>(a, st);
-        return launch_roll_v<9, 16, 64, 128, 4, 0>(a, st);
+        if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10, POLICY>(a, st);
+        if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10, POLICY>(a, st);
+        return launch_roll_v<9, 16, 64, 128, 4, 0, POLICY>(a, st);
     }
-    return launch_roll_v<3, 4, 64, 64, 16, 0>(a, st);
+    return launch_roll_v<3, 4, 64, 64, 16, 0, POLICY>(a, st);
 }
 
 // N = per^L with 2 <= per <= 8: fills the host-rounded constants of the hierarchy
@@ -344,6 +348,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
     // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
+    if (K == 1 && N == 243 && !world_options_set(a.p)) return launch_wide(a, (hipStream_t)stream);   // as fg_step_hd
     if (K >= 2 && !world_options_set(a.p)) {
         if (N == 81 || N == 243) return launch_wide(a, (hipStream_t)stream);
         if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);
@@ -460,6 +465,89 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
     sc.kind = FG_SCN_BASIC; sc.num_landmarks = L; sc.penalty = 1.0f;
     return launch_scenario(params, &sc, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
                            nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
+}
+
+// the controller from the simulator state: one launch, shared by fg_policy_bfs_state and the chained closed loop
+static int launch_policy_state(int B, int N, const FgPolicyLevels& pl, const float* px, const float* py,
+                               const float* shape, const float* ivel, float* act, hipStream_t st) {
+    const int lpe = N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 256;      // lanes per env
+    const int E = 256 / lpe;
+    const int grid = (B + E - 1) / E;
+    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 48 KiB
+#define FG_POLICY(PER) case PER: hipLaunchKernelGGL((policy_state_kernel<PER>), dim3(grid), dim3(256), lds, st, B, N, lpe, pl, \
+                                                   px, py, shape, ivel, act); break;
+    switch (pl.per) { FG_POLICY(2) FG_POLICY(3) FG_POLICY(4) FG_POLICY(5) FG_POLICY(6) FG_POLICY(7) FG_POLICY(8) }
+#undef FG_POLICY
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "policy launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_policy_bfs_state(int B, int N, int per_layer, const float* pos_x, const float* pos_y,
+                        const float* ideal_shape, const float* ideal_vel, float* act, void* stream) {
+    const DeviceGuard device_guard(stream);
+    if (B == 0) return FG_OK;
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    FgPolicyLevels pl;
+    if (!policy_levels_for(N, per_layer, &pl))
+        return fail(FG_ERR_UNSUPPORTED_N, "fg_policy_bfs_state: N must be per_layer^L with 2 <= per_layer <= 8%s");
+    if (!pos_x || !pos_y || !ideal_shape || !ideal_vel || !act)
+        return fail(FG_ERR_BAD_ARG, "fg_policy_bfs_state: a required pointer is NULL%s");
+    if (((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u) || ((uintptr_t)act & 7u))
+        return fail(FG_ERR_ALIGNMENT, "ideal_shape, ideal_vel and act must be 8-byte aligned%s");
+    return launch_policy_state(B, N, pl, pos_x, pos_y, ideal_shape, ideal_vel, act, (hipStream_t)stream);
+}
+
+int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_layer,
+                         float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                         float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
+                         float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                         int obs_every, void* stream) {
+    const DeviceGuard device_guard(stream);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B == 0 || K == 0) return FG_OK;
+    if (B < 0 || K < 0) return fail(FG_ERR_BAD_ARG, "B and K must be >= 0%s");
+    if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    FgPolicyLevels pl;
+    if (!policy_levels_for(N, per_layer, &pl))
+        return fail(FG_ERR_UNSUPPORTED_N, "fg_rollout_hd_policy: N must be per_layer^L with 2 <= per_layer <= 8%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !act_seq || !ideal_shape || !ideal_vel || !step || !reward_seq)
+        return fail(FG_ERR_BAD_ARG, "fg_rollout_hd_policy: a required pointer is NULL%s");
+    if (((uintptr_t)obs_seq & 15u) || ((uintptr_t)act_seq & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "obs_seq must be 16-byte, act_seq/ideal_shape/ideal_vel 8-byte aligned%s");
+    Args a; memset(&a, 0, sizeof(a));
+    a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+    a.do_phys = 1; a.do_post = 1;
+    a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y;
+    a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
+    a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
+    a.pl = pl; a.act_out = act_seq;
+    hipStream_t st = (hipStream_t)stream;
+    // the specialised agent counts are powers of 3: the controller runs inside the pipelined kernels
+    if (per_layer == 3 && !world_options_set(a.p)) {
+        if (N == 81 || N == 243) return launch_wide<true>(a, st);
+        if (N == 27 || N == 9 || N == 3) return launch_roll<true>(a, st);
+    }
+    // everything else: K times (controller launch, single-step launch) chained on the stream - the same device
+    // function on the same state, so the results equal the in-kernel loop's and fg_policy_bfs on the written rows
+    const size_t bn = (size_t)B * N;
+    for (int k = 0; k < K; ++k) {
+        float* act_k = act_seq + (size_t)k * bn * 2;
+        rc = launch_policy_state(B, N, pl, pos_x, pos_y, ideal_shape, ideal_vel, act_k, st);
+        if (rc) return rc;
+        Args s1 = a;
+        s1.K = 1; s1.obs_every = 1; s1.act = act_k; s1.act_out = nullptr;
+        s1.p.rng_offset = a.p.rng_offset + (uint64_t)k;
+        s1.rew = reward_seq + (size_t)k * bn;
+        s1.indiv = indiv_seq ? indiv_seq + (size_t)k * bn : nullptr;
+        s1.done = done_seq ? done_seq + (size_t)k * bn : nullptr;
+        s1.obs = (obs_seq && (k + 1) % a.obs_every == 0) ? obs_seq + (size_t)(k / a.obs_every) * bn * 6 * N : nullptr;
+        rc = launch_step(s1, st);
+        if (rc) return rc;
+    }
+    return FG_OK;
 }
 
 int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream) {

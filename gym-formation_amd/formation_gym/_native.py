@@ -99,6 +99,8 @@ SIGNATURES = {
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
     "fg_policy_bfs": (_I, [_I, _I, _I, _P, ctypes.c_int64, _P, _P]),
+    "fg_policy_bfs_state": (_I, [_I, _I, _I] + [_P] * 6),
+    "fg_rollout_hd_policy": (_I, [_PP, _I, _I, _I, _I] + [_P] * 12 + [_I, _P]),
 }
 
 _lib = None

@@ -214,6 +214,41 @@ class MultiAgentEnv(object):
         rew = out["reward"] if self.shared_reward else out["indiv"]
         return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), {"individual_reward": out["indiv"]}
 
+    def rollout_policy(self, K, num_agents_per_layer=3, out=None, obs_every=1):
+        """The reference's demo loop (test.py:17-27) for K steps in one call:
+            act_n = get_action_BFS(ezpolicy, obs_n, num_agents_per_layer); obs_n, ... = env.step(act_n)
+        starting from the current state (`fg_rollout_hd_policy`; ONE launch at 3, 9, 27, 81 or 243 agents with
+        3 agents per layer).  Results equal K x (`get_action_BFS` on the last observation, `step`) bit for bit and
+        come back like `rollout`'s, with the actions taken under info['actions'] [K, B, N, 2]."""
+        roll = getattr(self.scenario, "rollout_policy_batch", None)
+        if roll is None:
+            raise NotImplementedError("%s has no built-in controller" % type(self.scenario).__name__)
+        if self._action_mode():
+            raise NotImplementedError("the built-in controller emits raw continuous actions")
+        if self.post_step_callback is not None:
+            raise NotImplementedError("post_step_callback runs on the host after every step; call step()")
+        K, obs_every = int(K), int(obs_every)
+        if K < 1 or obs_every < 1:
+            raise ValueError("need K >= 1 steps and obs_every >= 1")
+        B, N = self.num_envs, self.num_agents
+        D = self._out["obs"].shape[-1]
+        f = dict(dtype=torch.float32, device=self._act.device)
+        want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N), act=(K, B, N, 2))
+        if out is None:
+            out = {k: (torch.zeros(shp, dtype=torch.uint8, device=self._act.device) if k == "done"
+                       else torch.empty(shp, **f)) for k, shp in want.items()}
+        for k, shp in want.items():
+            if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
+                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
+        roll(self.world, K, num_agents_per_layer, out, obs_every=obs_every, auto_reset=self.auto_reset,
+             rng_offset=self._rng_offset + 1)
+        self._rng_offset += K
+        self.current_step += K
+        self.world.world_step += K
+        rew = out["reward"] if self.shared_reward else out["indiv"]
+        return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), \
+            {"individual_reward": out["indiv"], "actions": out["act"]}
+
     def _bound_step(self, act):
         """Per-step host work kept to one ctypes call: the scenario resolves every pointer and the
         FgParams struct once (`bind_step`), keyed by everything the binding depends on - action

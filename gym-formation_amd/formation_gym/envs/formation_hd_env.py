@@ -168,6 +168,31 @@ class Scenario(BaseScenario):
             _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device)))
         self._cache = None
 
+    def rollout_policy_batch(self, world, K, per_layer, out, obs_every=1, auto_reset=False, rng_offset=0):
+        """K closed-loop steps with the built-in controller (`fg_rollout_hd_policy`): out["act"] [K,B,N,2]
+        receives the actions taken, the other tensors are those of `rollout_batch`."""
+        lib = _native.load()
+        _native.check(lib.fg_rollout_hd_policy(
+            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents), int(K), int(per_layer),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            out["act"].data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+            world.step_count.data_ptr(),
+            _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+            _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device)))
+        self._cache = None
+
+    def policy_actions(self, world, per_layer, out=None):
+        """get_action_BFS(ezpolicy, obs, per_layer) for the CURRENT state of every env, straight from the
+        simulator state (`fg_policy_bfs_state`): raw actions [B, N, 2]."""
+        B, N = world.num_envs, len(world.agents)
+        if out is None:
+            out = torch.empty((B, N, 2), dtype=torch.float32, device=world.device)
+        _native.check(_native.load().fg_policy_bfs_state(
+            B, N, int(per_layer), world.pos_x.data_ptr(), world.pos_y.data_ptr(),
+            self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), out.data_ptr(),
+            _native.current_stream(world.device)))
+        return out
+
     def bind_rollout(self, world, act_seq, out, obs_every=1, auto_reset=False):
         """`rollout_batch` with every pointer and the FgParams struct resolved once: returns
         `launch(rng_offset)`, one ctypes call per K-step launch (a 9 x 4096 launch lasts ~35 us on the GPU,

@@ -235,6 +235,23 @@ int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void*
  *   act  float [B][N][2] raw actions, what fg_step_hd takes as `act`. */
 int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream);
 
+/* The same controller evaluated straight from the simulator state (no observation buffer needed); bit-identical
+ * to fg_policy_bfs on the observation fg_observe_hd / fg_step_hd writes for that state. */
+int fg_policy_bfs_state(int B, int N, int per_layer, const float* pos_x, const float* pos_y,
+                        const float* ideal_shape, const float* ideal_vel, float* act, void* stream);
+
+/* Closed-loop rollout with the built-in controller: the loop of test.py:17-27
+ *     act_n = get_action_BFS(ezpolicy, obs_n, per_layer); obs_n, ... = env.step(act_n)
+ * for K steps and all B envs.  Like fg_rollout_hd, except that act_seq [K][B][N][2] is an OUTPUT (the actions
+ * taken, required).  For N in {3, 9, 27, 81, 243} with per_layer = 3 the controller runs inside the pipelined
+ * rollout kernels (ONE launch); otherwise K x (controller launch + step launch) are chained on `stream`.
+ * Results equal K x (fg_policy_bfs on the last observation, fg_step_hd) bit for bit. */
+int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_layer,
+                         float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                         float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
+                         float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                         int obs_every, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -444,36 +444,55 @@ def _run(cmd, env_extra=None, timeout=600):
 
 def test_bench_json_contract_single_and_two_ranks():
     """bench.py prints ONE JSON line with the contract keys; the 2-rank path (barrier, MAX over
-    ranks, sharded seeds) is exercised with two gloo ranks sharing this GPU."""
+    ranks, sharded seeds, GLOBAL-batch configs) is exercised with two gloo ranks sharing this GPU."""
     import json
     line = [l for l in _run(["bench.py", "--steps", "30", "--warmup", "5", "--envs", "512", "--agents", "9",
                              "--no-cpu-baseline"]).splitlines() if l.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "timing"):
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
     assert d["state_finite"] and d["value"] > 0 and "workload" in d["config"]
+    # ONE clock: value, ms_per_step and roofline.achieved all come from the median HIP-event block, and a short
+    # --steps block is repeated until >= 50 ms have been timed
+    t = d["timing"]
+    assert t["blocks"] >= 3 and t["timed_ms_total"] >= 35.0 and t["block_ms_min"] <= t["block_ms_median"] <= t["block_ms_max"]
+    assert abs(d["ms_per_step"] * 30 - t["block_ms_median"]) < 1e-3 * t["block_ms_median"] + 1e-5
+    assert abs(d["value"] - 512 * 30 / (t["block_ms_median"] * 1e-3)) < 1e-3 * d["value"]
+    alg = d["roofline"]["algorithmic_bytes_per_launch"] / d["config"]["steps_per_launch"] * 30
+    assert abs(d["roofline"]["achieved"] - alg / (t["block_ms_median"] * 1e-3) / 1e9) < 1e-3 * d["roofline"]["achieved"] + 0.1
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
-                "--agents", "9", "--backend", "gloo", "--no-extra"])
+                "--agents", "9", "--backend", "gloo", "--no-cpu-baseline", "--global-div", "64", "--min-timed-ms", "5"])
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1
     d2 = json.loads(line[0])
     assert d2["n_gpus"] == 2 and d2["config"]["global_envs"] == 512 and d2["scaling"] == "weak"
+    # BASELINE configs[3] and [4] as slices of their GLOBAL batches (here divided by 64): both ranks' times, the
+    # slowest rank, global env counts
+    gc = d2["global_configs"]
+    assert [g["workload"].split(" GLOBAL")[0] for g in gc] == ["formation_hd_env, 81 agents x 256 envs",
+                                                               "formation_hd_env, 243 agents x 1024 envs"]
+    for g, n_ag, n_env in zip(gc, (81, 243), (256, 1024)):
+        assert g["scaling"] == "strong" and g["envs_per_gpu"] == n_env // 2 and len(g["per_rank_ms_per_step"]) == 2
+        assert g["slowest_rank"] in (0, 1) and g["state_finite"] and g["test_scale_div"] == 64
+        assert abs(g["env_steps_per_s"] - n_env / (g["ms_per_step"] * 1e-3)) < 2e-3 * g["env_steps_per_s"]
+        assert abs(g["agent_steps_per_s"] - n_ag * g["env_steps_per_s"]) < 1e-3 * g["agent_steps_per_s"]
+        assert "scaling_efficiency_vs_n1" in g
     # default backend with two ranks on ONE GPU: RCCL cannot come up (duplicate device), every rank agrees to
     # keep the timing barrier on gloo and the run still completes
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
-                "--agents", "9", "--no-extra"], timeout=600)
+                "--agents", "9", "--no-extra", "--min-timed-ms", "5"], timeout=600)
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1
     d3 = json.loads(line[0])
     assert d3["n_gpus"] == 2 and d3["config"]["timing_barrier"] in ("gloo", "rccl")
     # without a launcher, `--gpus 2` starts its own ranks
     out = _run(["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256", "--agents", "9",
-                "--backend", "gloo", "--no-extra"])
+                "--backend", "gloo", "--no-extra", "--min-timed-ms", "5"])
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 2
 
