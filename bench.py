@@ -189,6 +189,9 @@ def main():
                     help="untimed stepping before the W warm-up steps, so that short runs are not measured during the clock ramp")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of the other BASELINE shapes")
+    ap.add_argument("--obs-pitch", type=int, default=0,
+                    help="rollout mode: floats between consecutive envs' observation blocks in the rollout buffer "
+                         "(0 = contiguous 6 N^2; -1 = 6 N^2 rounded up to 32 floats = whole 128-byte lines per env)")
     ap.add_argument("--global-div", type=int, default=1,
                     help="test aid: run the GLOBAL-batch configs (BASELINE configs[3], [4]) with their batch sizes divided "
                          "by this, whatever the headline shape is (the lines are marked)")
@@ -343,15 +346,16 @@ def main():
                     torch.cuda.synchronize()
             fn(w, cursor)
             cursor += w
-            # calibration: ONE block, to size the series (not reported)
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # calibration (not reported): 4 consecutive blocks, the first one (which starts on an idle GPU) left out
+            cal = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             barrier()
-            ev0.record()
-            fn(n, cursor)
-            ev1.record()
+            cal[0].record()
+            for c_ in range(4):
+                fn(n, cursor)
+                cursor += n
+                cal[c_ + 1].record()
             torch.cuda.synchronize()
-            cursor += n
-            t1 = sharding.max_over_ranks(ev0.elapsed_time(ev1), red_dev, sync_group)             # same value on every rank
+            t1 = sharding.max_over_ranks(cal[1].elapsed_time(cal[4]) / 3.0, red_dev, sync_group)  # same value on every rank
             R = int(min(4000, max(1, -(-a.min_timed_ms // max(t1, 1e-3)))))
             # the timed series: R consecutive blocks of exactly n steps, each delimited by HIP events on the launch
             # stream, the series bracketed by barrier + device synchronize.  The stream never idles between blocks
@@ -378,7 +382,9 @@ def main():
         seq = None
         if mode == "rollout" or other_steps > 0:
             f = dict(dtype=torch.float32, device=dev)
-            seq = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
+            pitch = a.obs_pitch if a.obs_pitch > 0 else (-(-6 * N * N // 32) * 32 if a.obs_pitch < 0 else 6 * N * N)
+            obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)
+            seq = dict(obs=obs_buf, reward=torch.empty((chunk, B, N), **f),
                        indiv=torch.empty((chunk, B, N), **f),
                        done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
             if policy:

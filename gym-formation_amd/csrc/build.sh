@@ -16,3 +16,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
     -I"$ROOT/include" ${FG_EXTRA_FLAGS:-} \
     -o "$OUT/libformation_hip.so" "$HERE/formation_hip.hip"
 echo "built $OUT/libformation_hip.so"
+# Parity-mode build of the SAME step-kernel source in fp64 (tests only, never loaded by the product): see
+# formation_hip_f64.hip.  No -fapprox-func: full-precision exp / log / sqrt.
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=on -DFG_F64=1 -fPIC -shared \
+    -I"$ROOT/include" -o "$OUT/libformation_hip_f64.so" "$HERE/formation_hip_f64.hip"
+echo "built $OUT/libformation_hip_f64.so"

@@ -22,6 +22,61 @@ namespace fg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// The arithmetic type of the fused step kernel (fg_step_kernel.hpp, fg_pair_loops.hpp, the reductions below).
+// The product library is fp32 (north_star).  -DFG_F64=1 builds the SAME kernel source in fp64 with run-time N only
+// (formation_hip_f64.hip -> libformation_hip_f64.so, tests only): the "parity mode" of SURVEY 7.3 H1, in which the
+// kernel's algorithm free-runs against the reference's fp64 trajectories over whole fixtures.
+#ifndef FG_F64
+#define FG_F64 0
+#endif
+#if FG_F64
+typedef double real;
+typedef double2 real2;
+#define make_real2 make_double2
+#else
+typedef float real;
+typedef float2 real2;
+#define make_real2 make_float2
+#endif
+typedef real realx2 __attribute__((ext_vector_type(2)));
+typedef real realx4 __attribute__((ext_vector_type(4)));
+
+// fp32: hardware transcendentals (v_sqrt / v_exp / v_log / v_rcp, ~1 ulp); fp64: the math library
+FG_DEV float rmin(float a, float b) { return fminf(a, b); }
+FG_DEV float rmax(float a, float b) { return fmaxf(a, b); }
+FG_DEV float rabs(float a) { return fabsf(a); }
+FG_DEV float rsqrt_(float a) { return sqrtf(a); }
+FG_DEV float rfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+FG_DEV float hw_sqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+FG_DEV float hw_rcp(float a) { return __builtin_amdgcn_rcpf(a); }
+FG_DEV float hw_log(float a) { return __logf(a); }
+FG_DEV float hw_exp(float a) { return __expf(a); }
+FG_DEV double rmin(double a, double b) { return fmin(a, b); }
+FG_DEV double rmax(double a, double b) { return fmax(a, b); }
+FG_DEV double rabs(double a) { return fabs(a); }
+FG_DEV double rsqrt_(double a) { return sqrt(a); }
+FG_DEV double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+FG_DEV double hw_sqrt(double a) { return sqrt(a); }
+FG_DEV double hw_rcp(double a) { return 1.0 / a; }
+FG_DEV double hw_log(double a) { return log(a); }
+FG_DEV double hw_exp(double a) { return exp(a); }
+
+// World / scenario constants as the kernels read them: the C ABI's FgParams (fp32 fields), or the same names in fp64
+// for the parity build (0.1f is not the reference's 0.1)
+#if FG_F64
+struct KParams {
+    double dt, damping, contact_force, contact_margin, sensitivity, mass, dist_min, collide_thresh;
+    int32_t world_length, auto_reset;
+    uint64_t seed, rng_offset;
+    double accel, max_speed, u_noise;
+    int32_t num_walls;
+    FgWall walls[FG_MAX_WALLS];
+    int32_t obs_env_pitch, reserved0;
+};
+#else
+typedef FgParams KParams;
+#endif
+
 // LDS block of one environment, in floats:
 //   float2 tables  A[3N] = post pos[N] | zeros[N-1] | ideal_shape[N] | ideal_vel[1],  V[N],  NV[N] = -V
 //                  (what the observation writers read: unit u >= N of any row is A[u])
@@ -30,13 +85,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //                  (ds_read_b64) by the packed-math pair loops
 __host__ __device__ constexpr int npad(int n) { return (n + 3) & ~3; }
 __host__ __device__ constexpr int env_block_floats(int n) { return 10 * n + 6 * npad(n); }
-FG_DEV float2* env_tables(float2* smem, int ee, int n) {
-    return reinterpret_cast<float2*>(reinterpret_cast<float*>(smem) + ee * env_block_floats(n));
+FG_DEV real2* env_tables(real2* smem, int ee, int n) {
+    return reinterpret_cast<real2*>(reinterpret_cast<real*>(smem) + ee * env_block_floats(n));
 }
-FG_DEV const float2* env_tables(const float2* smem, int ee, int n) {
-    return reinterpret_cast<const float2*>(reinterpret_cast<const float*>(smem) + ee * env_block_floats(n));
+FG_DEV const real2* env_tables(const real2* smem, int ee, int n) {
+    return reinterpret_cast<const real2*>(reinterpret_cast<const real*>(smem) + ee * env_block_floats(n));
 }
-constexpr float FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances stay finite (2e36)
+constexpr real FAR_AWAY = 1.0e18f;   // sentinel coordinate: squared distances stay finite (2e36)
 
 // Constants of the demo controller's hierarchy (fg_policy_kernels.hpp), rounded ONCE on the host so that kernels
 // with a compile-time and with a run-time agent count multiply by the very same values (-fapprox-func turns a
@@ -49,26 +104,27 @@ struct FgPolicyLevels {
 };
 
 struct Args {
-    FgParams p;
+    KParams p;
     int B, N, K, obs_every;
-    float inv_n;               // 1 / N, correctly rounded on the host: run-time-N kernels must use the very value that
+    real inv_n;               // 1 / N, correctly rounded on the host: run-time-N kernels must use the very value that
                                // compile-time-N kernels constant-fold (-fapprox-func turns a device-side division into v_rcp_f32)
     int do_phys, do_post;
     int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
-    float* px; float* py; float* vx; float* vy;
-    const float* act;          // [K][B][N][2]
-    float* shape;              // [B][N][2]
-    float* ivel;               // [B][2]
+    real* px; real* py; real* vx; real* vy;
+    const real* act;          // [K][B][N][2]
+    real* shape;              // [B][N][2]
+    real* ivel;               // [B][2]
     int32_t* step;             // [B]
-    float* obs;                // [slots][B][N][6N]
-    float* rew;                // [K][B][N]
-    float* indiv;              // [K][B][N] or NULL
+    real* obs;                // [slots][B] env blocks of [N][6N], obs_pitch float2 units apart
+    long long obs_pitch;       // float2 units between consecutive env blocks: 3 N^2 (contiguous) or a padded pitch
+    real* rew;                // [K][B][N]
+    real* indiv;              // [K][B][N] or NULL
     uint8_t* done;             // [K][B][N] or NULL
     int32_t* near_lm; int32_t* near_ag; int32_t* hd_idx;
     // closed-loop rollouts (fg_rollout_hd_policy): the actions come from the demo controller (fg_policy_kernels.hpp)
     // evaluated on the workgroup's own state instead of from `act`
     FgPolicyLevels pl;
-    float* act_out;            // [K][B][N][2] the actions taken
+    real* act_out;            // [K][B][N][2] the actions taken
 };
 
 // ---------------------------------------------------------------------------
@@ -76,10 +132,10 @@ struct Args {
 // ---------------------------------------------------------------------------
 enum { R_SUM = 0, R_MAX = 1, R_MIN = 2 };
 
-template <int OP> FG_DEV float combine(float a, float b) {
+template <int OP> FG_DEV real combine(real a, real b) {
     if (OP == R_SUM) return a + b;
-    if (OP == R_MAX) return fmaxf(a, b);
-    return fminf(a, b);
+    if (OP == R_MAX) return rmax(a, b);
+    return rmin(a, b);
 }
 
 // Cross-lane partner fetch for a butterfly reduction step, without going through the LDS
@@ -87,28 +143,32 @@ template <int OP> FG_DEV float combine(float a, float b) {
 // mirrors inside a 16-lane row, v_permlane16/32_swap across rows (gfx950).  STEP 4 and 8 use
 // mirrors instead of xor: any pairing of disjoint halves that already hold their own totals
 // gives the same reduction.
-template <int STEP, int OP> FG_DEV float bfly(float v) {
+template <int STEP, int OP> FG_DEV real bfly(real v) {
+#if FG_F64
+    return combine<OP>(v, __shfl_xor(v, STEP));        // 64-bit values: through ds_bpermute (parity build, not tuned)
+#else
     const int iv = __builtin_bit_cast(int, v);
     if constexpr (STEP >= 16) {
         // v_permlane{16,32}_swap(v, v) returns the two row / half sets side by side:
         // {rows 0,0,2,2 | rows 1,1,3,3} resp. {low,low | high,high}; combining them IS the step
         const auto sw = (STEP == 16) ? __builtin_amdgcn_permlane16_swap(iv, iv, false, false)
                                      : __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
-        return combine<OP>(__builtin_bit_cast(float, (int)sw[0]), __builtin_bit_cast(float, (int)sw[1]));
+        return combine<OP>(__builtin_bit_cast(real, (int)sw[0]), __builtin_bit_cast(real, (int)sw[1]));
     } else {
         constexpr int CTRL = (STEP == 1) ? 0xB1      // quad_perm [1,0,3,2]
                            : (STEP == 2) ? 0x4E      // quad_perm [2,3,0,1]
                            : (STEP == 4) ? 0x141     // row_half_mirror
                                          : 0x140;    // row_mirror
         const int r = __builtin_amdgcn_update_dpp(iv, iv, CTRL, 0xF, 0xF, false);
-        return combine<OP>(v, __builtin_bit_cast(float, r));
+        return combine<OP>(v, __builtin_bit_cast(real, r));
     }
+#endif
 }
 
 // G <= 64: the env occupies an aligned group of G lanes of one wave -> in-register butterfly.
 // G  > 64: the env is the whole workgroup (E == 1) -> wave butterfly + LDS partials.
 template <int G, int T, int NV, int OP0, int OP1, int OP2, int OP3>
-FG_DEV void env_reduce(float (&v)[NV], float* scratch) {
+FG_DEV void env_reduce(real (&v)[NV], real* scratch) {
     constexpr int W = (G <= 64) ? G : 64;
 #define FG_STEP(S)                                                                   \
     if constexpr (W > S) {                                                           \
@@ -165,54 +225,54 @@ FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
 // World options no reference scenario enables: walls, motor noise, speed clamp
 // ---------------------------------------------------------------------------
 // core.py:325-362 get_wall_collision_force, summed over the walls (hard walls, no ghosts)
-FG_DEV void wall_forces(const FgParams& P, float2 p, float size, float& fx, float& fy) {
+FG_DEV void wall_forces(const KParams& P, real2 p, real size, real& fx, real& fy) {
 #pragma unroll
     for (int w = 0; w < FG_MAX_WALLS; ++w) {                                   // static indices: no scratch copy
         if (w >= P.num_walls) break;
         const FgWall wl = P.walls[w];
-        const float prll = wl.vertical ? p.y : p.x;
-        const float perp = wl.vertical ? p.x : p.y;
+        const real prll = wl.vertical ? p.y : p.x;
+        const real perp = wl.vertical ? p.x : p.y;
         if (prll < wl.end0 - size || prll > wl.end1 + size) continue;      // beyond the endpoints
-        float ct = 1.0f, st = 0.0f;
+        real ct = 1.0f, st = 0.0f;
         if (prll < wl.end0 || prll > wl.end1) {                            // rounding the corner
-            const float past = (prll < wl.end0) ? prll - wl.end0 : prll - wl.end1;
+            const real past = (prll < wl.end0) ? prll - wl.end0 : prll - wl.end1;
             st = past / size;                                              // sin(theta)
-            ct = __builtin_amdgcn_sqrtf(fmaxf(1.0f - st * st, 0.0f));
+            ct = hw_sqrt(rmax(1.0f - st * st, real(0)));
         }
-        const float dmin = ct * size + 0.5f * wl.width;
-        const float delta = perp - wl.axis_pos;
-        const float dist = fabsf(delta);
-        const float x = (dmin - dist) / P.contact_margin;
-        const float pen = P.contact_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
-        const float mag = P.contact_force * delta * __builtin_amdgcn_rcpf(dist) * pen;   // dist == 0 -> NaN, as the reference
-        const float f_perp = ct * mag, f_prll = st * fabsf(mag);
+        const real dmin = ct * size + 0.5f * wl.width;
+        const real delta = perp - wl.axis_pos;
+        const real dist = rabs(delta);
+        const real x = (dmin - dist) / P.contact_margin;
+        const real pen = P.contact_margin * (rmax(x, real(0)) + hw_log(1.0f + hw_exp(-rabs(x))));
+        const real mag = P.contact_force * delta * hw_rcp(dist) * pen;   // dist == 0 -> NaN, as the reference
+        const real f_perp = ct * mag, f_prll = st * rabs(mag);
         if (wl.vertical) { fx += f_perp; fy += f_prll; } else { fy += f_perp; fx += f_prll; }
     }
 }
 
-FG_DEV float2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset) {
+FG_DEV real2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset) {
     uint32_t c[4] = {b, i ^ 0x80000000u, (uint32_t)offset, (uint32_t)(offset >> 32)};
     philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    const float r = sqrtf(-2.0f * __logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));   // Box-Muller
+    const float r = sqrtf(-2.0f * __logf(((float)(c[0] >> 8) + 1.0f) * (1.0f / 16777216.0f)));   // Box-Muller (fp32 draw)
     const float a = 6.2831853f * ((float)(c[1] >> 8) * (1.0f / 16777216.0f));
-    return make_float2(r * __cosf(a), r * __sinf(a));
+    return make_real2(r * __cosf(a), r * __sinf(a));
 }
 
 // action force incl. accel (core.py:236, environment.py:219-220) and motor noise (core.py:232-233)
-FG_DEV float2 action_force(const FgParams& P, float2 u, uint32_t b, uint32_t i, uint64_t offset) {
-    const float gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
-    float2 f = make_float2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
+FG_DEV real2 action_force(const KParams& P, real2 u, uint32_t b, uint32_t i, uint64_t offset) {
+    const real gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
+    real2 f = make_real2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
     if (P.u_noise > 0.0f) {
-        const float2 n = motor_noise(P.seed, b, i, offset);
+        const real2 n = motor_noise(P.seed, b, i, offset);
         f.x += P.u_noise * n.x;
         f.y += P.u_noise * n.y;
     }
     return f;
 }
 
-FG_DEV float2 clamp_speed(const FgParams& P, float2 v) {                    // core.py:271-276
+FG_DEV real2 clamp_speed(const KParams& P, real2 v) {                    // core.py:271-276
     if (P.max_speed > 0.0f) {
-        const float speed = sqrtf(v.x * v.x + v.y * v.y);
+        const real speed = rsqrt_(v.x * v.x + v.y * v.y);
         if (speed > P.max_speed) { v.x = v.x / speed * P.max_speed; v.y = v.y / speed * P.max_speed; }
     }
     return v;

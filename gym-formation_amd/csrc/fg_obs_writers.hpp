@@ -26,8 +26,10 @@ FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
 
 template <int NC, int NW, int E>
 FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
-                           float2* __restrict__ out_env0, int El, int parts) {
+                           float2* __restrict__ out_env0, size_t env_units, int El, int parts) {
     // tables0 / env_stride: A-table of env 0 and the distance (float2) to the next env's;
+    // out_env0 / env_units: observation block of env 0 and the distance (float2 units) to the next env's
+    //   (3 N^2 when the [B][N][6N] tensor is contiguous; larger with a padded env pitch or strided env ownership)
     // w: index of this wave among the NW waves that share the job
     // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
     constexpr int N = NC;
@@ -39,7 +41,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
     constexpr unsigned ROWU = 3u * N;                       // units per row
     for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
         const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
-        float2* __restrict__ out = out_env0 + (size_t)ee * (ROWU * N);
+        float2* __restrict__ out = out_env0 + (size_t)ee * env_units;
         if constexpr (N <= 64) {
             // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
             // whole block, then the static part (zeros | ideal_shape | ideal_vel, the same for every
@@ -130,12 +132,12 @@ template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 +
 // `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
 template <int NC, int NW, int E, int RT>
 FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
-                            float2* __restrict__ out_env0, size_t unit0, int El) {
+                            float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El) {
     constexpr int N = NC;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
     static_assert(N <= 32 && N % RT == 0, "tiled writer: N <= 32, RT divides N");
-    constexpr unsigned ROWU = 3u * N, NENV = ROWU * N, TU = ROWU * RT;
+    constexpr unsigned ROWU = 3u * N, TU = ROWU * RT;
     constexpr int TILES_ENV = N / RT;                                  // tiles per env
     constexpr int MY_TILES = (TILES_ENV + WPE - 1) / WPE;              // of which this wave takes every WPE-th
     const int lane = threadIdx.x & 63;
@@ -169,7 +171,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             Pu = lds_if(act && u >= 1, AA, u);
             sv = lds_if(ssub < RS, AA, N + sidx);
         }
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * env_units + (size_t)r0 * ROWU) & 1);
         float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;     // no restrict: the two tiles alternate
 #pragma unroll
         for (int rb = 0; rb < RT; rb += RW) {
@@ -190,9 +192,9 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     auto stream = [&](int t) {
         int ee, r0; locate(t, ee, r0);
         if (r0 >= N) return;
-        const unsigned par = (unsigned)((unit0 + (size_t)ee * NENV + (size_t)r0 * ROWU) & 1);
+        const unsigned par = (unsigned)((unit0 + (size_t)ee * env_units + (size_t)r0 * ROWU) & 1);
         const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
-        float2* __restrict__ out = out_env0 + (size_t)ee * NENV + (size_t)r0 * ROWU;
+        float2* __restrict__ out = out_env0 + (size_t)ee * env_units + (size_t)r0 * ROWU;
         if (par && lane == 0) out[0] = img[0];
         constexpr unsigned NPMAX = TU >> 1;
         const unsigned npair = (TU - par) >> 1;

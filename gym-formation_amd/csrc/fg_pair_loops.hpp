@@ -15,26 +15,26 @@ namespace fg {
 // NPC every partner is fetched from LDS up front (one round trip instead of one per iteration:
 // at small N the producer chain is latency-bound); the arithmetic and its order are the same.
 template <int NPC = 0>
-FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __restrict__ QY, int NP,
-                                   int i, float2 p, float cf, float kmargin, float dmin, float cutoff2) {
-    float fx = 0.0f, fy = 0.0f;
-    const f32x2 px = {p.x, p.x}, py = {p.y, p.y};
-    const float inv_k = 1.0f / kmargin;
-    auto add = [&](float dx, float dy, float d2) {
+FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __restrict__ QY, int NP,
+                                   int i, real2 p, real cf, real kmargin, real dmin, real cutoff2) {
+    real fx = 0.0f, fy = 0.0f;
+    const realx2 px = {p.x, p.x}, py = {p.y, p.y};
+    const real inv_k = 1.0f / kmargin;
+    auto add = [&](real dx, real dy, real d2) {
         // Hardware transcendentals (v_sqrt/v_exp/v_log/v_rcp, ~1 ulp): the contact branch is
         // taken by about half of all wave iterations at uniform-random density, so its length
         // sets the physics time.  Relative force error ~3e-7 (|f| <= 6) -> < 2e-8 on positions.
         // d2 == 0 for two distinct agents is kept: 0 * inf -> NaN as in core.py:312.
-        const float d = __builtin_amdgcn_sqrtf(d2);
-        const float x = (dmin - d) * inv_k;
-        const float pen = kmargin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
-        const float c = cf * pen * __builtin_amdgcn_rcpf(d);
+        const real d = hw_sqrt(d2);
+        const real x = (dmin - d) * inv_k;
+        const real pen = kmargin * (rmax(x, real(0)) + hw_log(1.0f + hw_exp(-rabs(x))));
+        const real c = cf * pen * hw_rcp(d);
         fx += dx * c;
         fy += dy * c;
     };
-    auto pair = [&](int j, f32x2 qx, f32x2 qy) {
-        const f32x2 dx = px - qx, dy = py - qy;
-        const f32x2 d2 = dx * dx + dy * dy;
+    auto pair = [&](int j, realx2 qx, realx2 qy) {
+        const realx2 dx = px - qx, dy = py - qy;
+        const realx2 d2 = dx * dx + dy * dy;
         // beyond the cutoff the softplus penetration is below fp32 resolution of the force: skipped
         const bool n0 = (d2.x < cutoff2) && (j != i);
         const bool n1 = (d2.y < cutoff2) && (j + 1 != i);
@@ -44,66 +44,66 @@ FG_DEV float2 contact_force_packed(const float* __restrict__ QX, const float* __
         }
     };
     if constexpr (NPC > 0 && NPC <= 16) {
-        f32x2 qx[NPC / 2], qy[NPC / 2];
+        realx2 qx[NPC / 2], qy[NPC / 2];
 #pragma unroll
         for (int h = 0; h < NPC / 2; ++h) {
-            qx[h] = *reinterpret_cast<const f32x2*>(QX + 2 * h);
-            qy[h] = *reinterpret_cast<const f32x2*>(QY + 2 * h);
+            qx[h] = *reinterpret_cast<const realx2*>(QX + 2 * h);
+            qy[h] = *reinterpret_cast<const realx2*>(QY + 2 * h);
         }
 #pragma unroll
         for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h]);
     } else {
 #pragma unroll 2
         for (int j = 0; j < NP; j += 2)
-            pair(j, *reinterpret_cast<const f32x2*>(QX + j), *reinterpret_cast<const f32x2*>(QY + j));
+            pair(j, *reinterpret_cast<const realx2*>(QX + j), *reinterpret_cast<const realx2*>(QY + j));
     }
-    return make_float2(fx, fy);
+    return make_real2(fx, fy);
 }
 
 // Scenario.reward inner pass for agent i / ideal point i (formation_hd_env.py:61-75):
 //   rowmin = min_j |p~_i - s_j|^2,  colmin = min_j |p~_j - s_i|^2,  cnt = #{j != i : |p_j - p_i| < thr}
 template <bool IDX, int NPC = 0>
-FG_DEV void reward_pass_packed(const float* __restrict__ PX, const float* __restrict__ PY,
-                               const float* __restrict__ SX, const float* __restrict__ SY, int NP,
-                               float2 p, float ptx, float pty, float tx, float ty, float thr2,
-                               float& rowmin, float& colmin, int& cnt, int& arg_lm, int& arg_ag) {
-    const f32x2 px = {p.x, p.x}, py = {p.y, p.y};
-    const f32x2 ptx2 = {ptx, ptx}, pty2 = {pty, pty}, tx2 = {tx, tx}, ty2 = {ty, ty};
+FG_DEV void reward_pass_packed(const real* __restrict__ PX, const real* __restrict__ PY,
+                               const real* __restrict__ SX, const real* __restrict__ SY, int NP,
+                               real2 p, real ptx, real pty, real tx, real ty, real thr2,
+                               real& rowmin, real& colmin, int& cnt, int& arg_lm, int& arg_ag) {
+    const realx2 px = {p.x, p.x}, py = {p.y, p.y};
+    const realx2 ptx2 = {ptx, ptx}, pty2 = {pty, pty}, tx2 = {tx, tx}, ty2 = {ty, ty};
     int c = -1;                                    // the self pair (distance 0) is counted below
-    auto pair = [&](int j, f32x2 qx, f32x2 qy, f32x2 sx, f32x2 sy) {
-        const f32x2 cx = qx - px, cy = qy - py;
-        const f32x2 dc = cx * cx + cy * cy;
+    auto pair = [&](int j, realx2 qx, realx2 qy, realx2 sx, realx2 sy) {
+        const realx2 cx = qx - px, cy = qy - py;
+        const realx2 dc = cx * cx + cy * cy;
         c += (dc.x < thr2 ? 1 : 0) + (dc.y < thr2 ? 1 : 0);
-        const f32x2 rx = ptx2 - sx, ry = pty2 - sy;
-        const f32x2 dr = rx * rx + ry * ry;
-        const f32x2 ux = qx - tx2, uy = qy - ty2;
-        const f32x2 dq = ux * ux + uy * uy;
+        const realx2 rx = ptx2 - sx, ry = pty2 - sy;
+        const realx2 dr = rx * rx + ry * ry;
+        const realx2 ux = qx - tx2, uy = qy - ty2;
+        const realx2 dq = ux * ux + uy * uy;
         if (IDX) {
             if (dr.x < rowmin) { rowmin = dr.x; arg_lm = j; }
             if (dr.y < rowmin) { rowmin = dr.y; arg_lm = j + 1; }
             if (dq.x < colmin) { colmin = dq.x; arg_ag = j; }
             if (dq.y < colmin) { colmin = dq.y; arg_ag = j + 1; }
         } else {
-            rowmin = fminf(fminf(rowmin, dr.x), dr.y);
-            colmin = fminf(fminf(colmin, dq.x), dq.y);
+            rowmin = rmin(rmin(rowmin, dr.x), dr.y);
+            colmin = rmin(rmin(colmin, dq.x), dq.y);
         }
     };
     if constexpr (NPC > 0 && NPC <= 16) {
-        f32x2 qx[NPC / 2], qy[NPC / 2], sx[NPC / 2], sy[NPC / 2];
+        realx2 qx[NPC / 2], qy[NPC / 2], sx[NPC / 2], sy[NPC / 2];
 #pragma unroll
         for (int h = 0; h < NPC / 2; ++h) {
-            qx[h] = *reinterpret_cast<const f32x2*>(PX + 2 * h);
-            qy[h] = *reinterpret_cast<const f32x2*>(PY + 2 * h);
-            sx[h] = *reinterpret_cast<const f32x2*>(SX + 2 * h);
-            sy[h] = *reinterpret_cast<const f32x2*>(SY + 2 * h);
+            qx[h] = *reinterpret_cast<const realx2*>(PX + 2 * h);
+            qy[h] = *reinterpret_cast<const realx2*>(PY + 2 * h);
+            sx[h] = *reinterpret_cast<const realx2*>(SX + 2 * h);
+            sy[h] = *reinterpret_cast<const realx2*>(SY + 2 * h);
         }
 #pragma unroll
         for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h], sx[h], sy[h]);
     } else {
 #pragma unroll 2
         for (int j = 0; j < NP; j += 2)
-            pair(j, *reinterpret_cast<const f32x2*>(PX + j), *reinterpret_cast<const f32x2*>(PY + j),
-                 *reinterpret_cast<const f32x2*>(SX + j), *reinterpret_cast<const f32x2*>(SY + j));
+            pair(j, *reinterpret_cast<const realx2*>(PX + j), *reinterpret_cast<const realx2*>(PY + j),
+                 *reinterpret_cast<const realx2*>(SX + j), *reinterpret_cast<const realx2*>(SY + j));
     }
     cnt = c + (thr2 > 0.0f ? 0 : 1);               // thr == 0: not even the self pair was counted
 }

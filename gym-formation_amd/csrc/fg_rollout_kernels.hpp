@@ -41,6 +41,8 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
     const int i = tid % G;
     // env -> workgroup mapping: blocked (envs b0 .. b0+E-1), one contiguous span of observations per workgroup
     // (dealing envs round-robin over the workgroups was measured slower and is gone: profiles/README.md)
+    // (dealing envs round-robin over the workgroups - a compact chip-wide window of the store stream - was measured
+    // slower again in round 2, with and without a line-aligned env pitch: profiles/r02_pitch/)
     const int b0 = (int)blockIdx.x * E;
     const int b = b0 + e;
     const bool env_ok = producer && (b < a.B);
@@ -193,15 +195,16 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
             bool want_obs = a.obs != nullptr;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
-                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
+                const size_t env_units = (size_t)a.obs_pitch;
                 const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
                 if constexpr (WR == 0)
                     write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                               reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
+                                               reinterpret_cast<float2*>(a.obs) + unit0, env_units, El, 3);
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                         reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
-                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, El);
+                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
             }
         }
         __syncthreads();
@@ -491,10 +494,10 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             bool want_obs = a.obs != nullptr && El > 0;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
-                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)(3 * NC * NC);
+                const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
                 write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                           reinterpret_cast<float2*>(a.obs) + unit0, El, 3);
+                                           reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
             }
         }
         __syncthreads();

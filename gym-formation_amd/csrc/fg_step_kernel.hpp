@@ -20,9 +20,9 @@ namespace fg {
 // ---------------------------------------------------------------------------
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 __global__ __launch_bounds__(T)
-void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre_px, const float* __restrict__ pre_py,
-                 const float* __restrict__ pre_vx, const float* __restrict__ pre_vy, const float* __restrict__ pre_shape,
-                 const float* __restrict__ pre_ivel, const int32_t* __restrict__ pre_step, const Args a) {
+void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_px, const real* __restrict__ pre_py,
+                 const real* __restrict__ pre_vx, const real* __restrict__ pre_vy, const real* __restrict__ pre_shape,
+                 const real* __restrict__ pre_ivel, const int32_t* __restrict__ pre_step, const Args a) {
     // The leading scalar arguments repeat what phase 1 needs (batch size, agent count, state pointers): with
     // -amdgpu-kernarg-preload-count=16 the command processor hands them over in SGPRs at wave start, so the state
     // loads go out at once instead of behind a cold s_load of the argument block (one memory round trip off the
@@ -31,7 +31,7 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
     // compiled into a separate instantiation so that the common path keeps its registers.
     constexpr bool FLAT = (NC == 0);          // observation writer: register-cached rows (compile-time N) or flat decode
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    extern __shared__ __attribute__((aligned(16))) real2 smem[];
     const int N = NC ? NC : pre_N;
     const int tid = threadIdx.x;
     const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
@@ -44,40 +44,40 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
 
     const int NP = npad(N);
     constexpr int NPS = (NC > 0 && npad(NC > 0 ? NC : 1) <= 16) ? npad(NC > 0 ? NC : 1) : 0;   // small N: partners fetched up front
-    float2* const A = env_tables(smem, e < E ? e : 0, N);
-    float2* const V = A + 3 * N;
-    float2* const NV = A + 4 * N;             // -velocity, read by the row writer
-    float* const QX = reinterpret_cast<float*>(A + 5 * N);
-    float* const QY = QX + NP;
-    float* const PX = QY + NP;
-    float* const PY = PX + NP;
-    float* const SX = PY + NP;
-    float* const SY = SX + NP;
-    float* const scratch = reinterpret_cast<float*>(env_tables(smem, E, N));
-    volatile int* const reset_flag = reinterpret_cast<volatile int*>(scratch) + 64;   // 2 ints after the 16x4 reduction partials
+    real2* const A = env_tables(smem, e < E ? e : 0, N);
+    real2* const V = A + 3 * N;
+    real2* const NV = A + 4 * N;             // -velocity, read by the row writer
+    real* const QX = reinterpret_cast<real*>(A + 5 * N);
+    real* const QY = QX + NP;
+    real* const PX = QY + NP;
+    real* const PY = PX + NP;
+    real* const SX = PY + NP;
+    real* const SY = SX + NP;
+    real* const scratch = reinterpret_cast<real*>(env_tables(smem, E, N));
+    volatile int* const reset_flag = reinterpret_cast<volatile int*>(scratch + 64);   // 2 ints after the 16x4 reduction partials
 
-    const float one_minus_damp = 1.0f - a.p.damping;
-    const float dt = a.p.dt;
-    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;   // force beyond: < 1e2 k e^-18 ~ 1.5e-9
-    const float cutoff2 = cutoff * cutoff;
-    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
-    const float invN = NC ? 1.0f / (float)(NC ? NC : 1) : a.inv_n;      // compile-time N: folded to the same correctly rounded value
+    const real one_minus_damp = 1.0f - a.p.damping;
+    const real dt = a.p.dt;
+    const real cutoff = a.p.dist_min + (FG_F64 ? 40.0f : 18.0f) * a.p.contact_margin;   // force beyond: < 1e2 k e^-18 ~ 1.5e-9 (fp64 build: e^-40)
+    const real cutoff2 = cutoff * cutoff;
+    const real thr2 = (real)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const real invN = NC ? 1.0f / (real)(NC ? NC : 1) : a.inv_n;      // compile-time N: folded to the same correctly rounded value
 
     // ---- phase 1: state -> registers + LDS --------------------------------
-    float2 p = make_float2(0.f, 0.f), v = make_float2(0.f, 0.f), s = make_float2(0.f, 0.f);
+    real2 p = make_real2(0.f, 0.f), v = make_real2(0.f, 0.f), s = make_real2(0.f, 0.f);
     int t_step = 0;
     const size_t sidx = (size_t)b * N + i;
     if (valid) {
-        p = make_float2(pre_px[sidx], pre_py[sidx]);
-        v = make_float2(pre_vx[sidx], pre_vy[sidx]);
-        A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+        p = make_real2(pre_px[sidx], pre_py[sidx]);
+        v = make_real2(pre_vx[sidx], pre_vy[sidx]);
+        A[i] = p; V[i] = v; NV[i] = make_real2(-v.x, -v.y);
         QX[i] = p.x; QY[i] = p.y; PX[i] = p.x; PY[i] = p.y;
         if (a.do_post) {
-            s = reinterpret_cast<const float2*>(pre_shape)[sidx];
+            s = reinterpret_cast<const real2*>(pre_shape)[sidx];
             A[2 * N - 1 + i] = s;
             SX[i] = s.x; SY[i] = s.y;
-            if (i < N - 1) A[N + i] = make_float2(0.f, 0.f);
-            if (i == 0) A[3 * N - 1] = reinterpret_cast<const float2*>(pre_ivel)[b];
+            if (i < N - 1) A[N + i] = make_real2(0.f, 0.f);
+            if (i == 0) A[3 * N - 1] = reinterpret_cast<const real2*>(pre_ivel)[b];
         }
     } else if (env_ok && i < NP) {              // sentinel partners of the packed pair loops
         QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
@@ -93,11 +93,11 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
         // ---- phase 2: World.step ------------------------------------------
         if (a.do_phys) {
             if (valid) {
-                const float2 u = reinterpret_cast<const float2*>(a.act)[((size_t)k * pre_B + b) * N + i];
-                float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                const real2 u = reinterpret_cast<const real2*>(a.act)[((size_t)k * pre_B + b) * N + i];
+                real2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
-                    const float2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
+                    const real2 fa = action_force(a.p, u, (uint32_t)b, (uint32_t)i, a.p.rng_offset + k);
                     f.x += fa.x; f.y += fa.y;
                     if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
                 } else {
@@ -109,7 +109,7 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
                 if constexpr (OPTS) v = clamp_speed(a.p, v);
                 p.x += v.x * dt;
                 p.y += v.y * dt;
-                A[i] = p; V[i] = v; NV[i] = make_float2(-v.x, -v.y);
+                A[i] = p; V[i] = v; NV[i] = make_real2(-v.x, -v.y);
                 PX[i] = p.x; PY[i] = p.y;
             }
             t_step += 1;
@@ -125,25 +125,25 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
 
         if (a.do_post) {
             // ---- phase 3: reward -------------------------------------------
-            float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+            real sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
             env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, scratch);
-            const float mx = sums[0] * invN, my = sums[1] * invN;
-            const float mvx = sums[2] * invN, mvy = sums[3] * invN;
-            const float ptx = p.x - mx, pty = p.y - my;        // centred own position
-            const float tx = s.x + mx, ty = s.y + my;          // own ideal point, un-centred
-            float rowmin = INFINITY, colmin = INFINITY;
+            const real mx = sums[0] * invN, my = sums[1] * invN;
+            const real mvx = sums[2] * invN, mvy = sums[3] * invN;
+            const real ptx = p.x - mx, pty = p.y - my;        // centred own position
+            const real tx = s.x + mx, ty = s.y + my;          // own ideal point, un-centred
+            real rowmin = INFINITY, colmin = INFINITY;
             int cnt = 0, arg_lm = 0, arg_ag = 0;
             if (valid)
                 reward_pass_packed<IDX, NPS>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
                                         rowmin, colmin, cnt, arg_lm, arg_ag);
-            float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+            real red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (real)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
-            const float H = sqrtf(fmaxf(red[0], red[1]));
-            const float2 iv = A[3 * N - 1];
-            const float ex = iv.x - mvx, ey = iv.y - mvy;
-            const float velterm = sqrtf(ex * ex + ey * ey);
-            const float indiv = (-H - velterm) - (float)cnt;
-            const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            const real H = rsqrt_(rmax(red[0], red[1]));
+            const real2 iv = A[3 * N - 1];
+            const real ex = iv.x - mvx, ey = iv.y - mvy;
+            const real velterm = rsqrt_(ex * ex + ey * ey);
+            const real indiv = (-H - velterm) - (real)cnt;
+            const real shared = (real)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
             const bool is_done = t_step >= a.p.world_length;
             if (valid) {
                 const size_t o = ((size_t)k * pre_B + b) * N + i;
@@ -153,8 +153,8 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
             }
             if (IDX) {
                 // scipy's witnesses: first maximiser of the row/col minima
-                float w[2] = {(valid && rowmin == red[0]) ? (float)i : 1e9f,
-                              (valid && colmin == red[1]) ? (float)i : 1e9f};
+                real w[2] = {(valid && rowmin == red[0]) ? (real)i : 1e9f,
+                              (valid && colmin == red[1]) ? (real)i : 1e9f};
                 env_reduce<G, T, 2, R_MIN, R_MIN, R_MIN, R_MIN>(w, scratch);
                 if (valid) {
                     if (a.near_lm) a.near_lm[sidx] = arg_lm;
@@ -173,23 +173,23 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
                     uint32_t c[4] = {(uint32_t)b, (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
                                      (uint32_t)((a.p.rng_offset + k) >> 32)};
                     philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
-                    float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
-                    const float rx = raw[0], ry = raw[1];
+                    real raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                    const real rx = raw[0], ry = raw[1];
                     env_reduce<G, T, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, scratch);
                     if (mine && valid) {
-                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
-                        v = make_float2(0.f, 0.f);
-                        s = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
+                        p = make_real2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_real2(0.f, 0.f);
+                        s = make_real2(rfma(-raw[0], invN, rx), rfma(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
                         A[i] = p; V[i] = v; NV[i] = v; A[2 * N - 1 + i] = s;
                         PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
-                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
+                        reinterpret_cast<real2*>(a.shape)[sidx] = s;
                         if (i == 0) {
                             uint32_t c2[4] = {(uint32_t)b, 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
                                               (uint32_t)((a.p.rng_offset + k) >> 32)};
                             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
-                            const float2 niv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                            const real2 niv = make_real2(u_pm1(c2[0]), u_pm1(c2[1]));
                             A[3 * N - 1] = niv;
-                            reinterpret_cast<float2*>(a.ivel)[b] = niv;
+                            reinterpret_cast<real2*>(a.ivel)[b] = niv;
                         }
                     }
                     if (mine) t_step = 0;
@@ -201,50 +201,57 @@ void step_kernel(const int pre_B, const int pre_N, const float* __restrict__ pre
             if (want_obs && !FLAT) {
                 if constexpr (NC > 0)
                     write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
-                                                  reinterpret_cast<float2*>(a.obs) +
-                                                  ((size_t)slot * pre_B + b0) * (size_t)(3 * NC * NC), El, 3);
+                                                  reinterpret_cast<real2*>(a.obs) +
+                                                  ((size_t)slot * pre_B + b0) * (size_t)a.obs_pitch, (size_t)a.obs_pitch, El, 3);
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows
-                const size_t U0 = ((size_t)slot * pre_B + b0) * nenv;
-                const unsigned total = (unsigned)El * nenv;
-                const unsigned head = (unsigned)(U0 & 1);  // region start not 16-byte aligned
-                float2* const out2 = reinterpret_cast<float2*>(a.obs) + U0;
-                // unit (rp, u): rp = e*N + row is the row index inside the group, u the unit in
-                // the row.  Branch-free so that the LDS reads of several units overlap.
-                auto unit = [&](unsigned rp, unsigned u) -> float2 {
-                    const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
-                    const unsigned row = rp - ee * N;
-                    const float2* AA = env_tables(smem, (int)ee, N);
-                    const unsigned j = u - 1u;
-                    const bool is_delta = j < (unsigned)(N - 1);
-                    unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
-                    idx = (u == 0u) ? n3 + row : idx;
-                    float2 val = AA[idx];
-                    const float2 pi = AA[row];
-                    val.x -= is_delta ? pi.x : 0.0f;
-                    val.y -= is_delta ? pi.y : 0.0f;
-                    return val;
-                };
-                if (head && tid == 0) out2[0] = unit(0u, 0u);
-                const unsigned npair = (total - head) >> 1;
-                f32x4* const out4 = reinterpret_cast<f32x4*>(out2 + head);
-                const unsigned du = (2u * T) % n3, drow = (2u * T) / n3;
-                unsigned q = head + 2u * tid;
-                unsigned rp = q / n3;
-                unsigned u = q - rp * n3;
+                // contiguous [B][N][6N]: the El envs of the workgroup are ONE span; padded env pitch: one span per env
+                const bool contig = (size_t)a.obs_pitch == (size_t)nenv;
+                const int spans = contig ? 1 : El;
+                for (int sp = 0; sp < spans; ++sp) {
+                    const size_t U0 = ((size_t)slot * pre_B + b0 + sp) * (size_t)a.obs_pitch;
+                    const unsigned total = contig ? (unsigned)El * nenv : nenv;
+                    const unsigned rp_base = (unsigned)sp * (unsigned)N;
+                    const unsigned head = (unsigned)(U0 & 1);  // region start not 16-byte aligned
+                    real2* const out2 = reinterpret_cast<real2*>(a.obs) + U0;
+                    // unit (rp, u): rp = e*N + row is the row index inside the group, u the unit in
+                    // the row.  Branch-free so that the LDS reads of several units overlap.
+                    auto unit = [&](unsigned rp, unsigned u) -> real2 {
+                        rp += rp_base;
+                        const unsigned ee = (E == 1) ? 0u : rp / (unsigned)N;
+                        const unsigned row = rp - ee * N;
+                        const real2* AA = env_tables(smem, (int)ee, N);
+                        const unsigned j = u - 1u;
+                        const bool is_delta = j < (unsigned)(N - 1);
+                        unsigned idx = is_delta ? j + (j >= row ? 1u : 0u) : u;
+                        idx = (u == 0u) ? n3 + row : idx;
+                        real2 val = AA[idx];
+                        const real2 pi = AA[row];
+                        val.x -= is_delta ? pi.x : 0.0f;
+                        val.y -= is_delta ? pi.y : 0.0f;
+                        return val;
+                    };
+                    if (head && tid == 0) out2[0] = unit(0u, 0u);
+                    const unsigned npair = (total - head) >> 1;
+                    realx4* const out4 = reinterpret_cast<realx4*>(out2 + head);
+                    const unsigned du = (2u * T) % n3, drow = (2u * T) / n3;
+                    unsigned q = head + 2u * tid;
+                    unsigned rp = q / n3;
+                    unsigned u = q - rp * n3;
 #pragma unroll 2
-                for (unsigned q2 = tid; q2 < npair; q2 += T) {
-                    unsigned u1 = u + 1u, rp1 = rp;
-                    if (u1 == n3) { u1 = 0u; rp1 += 1u; }
-                    const float2 x0 = unit(rp, u), x1 = unit(rp1, u1);
-                    const f32x4 w = {x0.x, x0.y, x1.x, x1.y};
-                    out4[q2] = w;
-                    u += du; rp += drow;
-                    if (u >= n3) { u -= n3; rp += 1u; }
+                    for (unsigned q2 = tid; q2 < npair; q2 += T) {
+                        unsigned u1 = u + 1u, rp1 = rp;
+                        if (u1 == n3) { u1 = 0u; rp1 += 1u; }
+                        const real2 x0 = unit(rp, u), x1 = unit(rp1, u1);
+                        const realx4 w = {x0.x, x0.y, x1.x, x1.y};
+                        out4[q2] = w;
+                        u += du; rp += drow;
+                        if (u >= n3) { u -= n3; rp += 1u; }
+                    }
+                    if (((total - head) & 1u) && tid == T - 1)
+                        out2[total - 1] = unit((total - 1) / n3, (total - 1) % n3);
                 }
-                if (((total - head) & 1u) && tid == T - 1)
-                    out2[total - 1] = unit((total - 1) / n3, (total - 1) % n3);
             }
         }
 

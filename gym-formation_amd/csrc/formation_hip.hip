@@ -221,6 +221,16 @@ static bool policy_levels_for(int N, int per, FgPolicyLevels* pl) {
     return true;
 }
 
+// Args.obs_pitch (float2 units) from FgParams.obs_env_pitch (floats; 0 = contiguous)
+static int set_obs_pitch(Args* a) {
+    const long long nenv = 6LL * a->N * a->N;
+    const long long pitch = a->p.obs_env_pitch ? (long long)a->p.obs_env_pitch : nenv;
+    if (pitch < nenv || (pitch & 1))
+        return fail(FG_ERR_BAD_ARG, "params: obs_env_pitch must be 0 or an even number of floats >= 6 N^2%s");
+    a->obs_pitch = pitch / 2;
+    return FG_OK;
+}
+
 static int check_params(const FgParams* p) {
     if (!p) return fail(FG_ERR_BAD_ARG, "params is NULL%s");
     if (!(p->mass > 0.f) || !(p->contact_margin > 0.f) || !(p->dt > 0.f))
@@ -268,6 +278,7 @@ int fg_step_hd(const FgParams* params, int B, int N,
         return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, act/ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
     a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 1;
+    if ((rc = set_obs_pitch(&a)) != FG_OK) return rc;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
@@ -294,6 +305,7 @@ int fg_physics_step(const FgParams* params, int B, int N,
     if ((uintptr_t)act & 7u) return fail(FG_ERR_ALIGNMENT, "act must be 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
     a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 1; a.do_post = 0;
+    if ((rc = set_obs_pitch(&a)) != FG_OK) return rc;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act;
     return launch_step(a, (hipStream_t)stream);
 }
@@ -316,6 +328,7 @@ int fg_observe_hd(const FgParams* params, int B, int N,
         return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
     a.p = *params; a.p.auto_reset = 0; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = 1; a.obs_every = 1; a.do_phys = 0; a.do_post = 1;
+    if ((rc = set_obs_pitch(&a)) != FG_OK) return rc;
     a.px = const_cast<float*>(pos_x); a.py = const_cast<float*>(pos_y);
     a.vx = const_cast<float*>(vel_x); a.vy = const_cast<float*>(vel_y);
     a.shape = const_cast<float*>(ideal_shape); a.ivel = const_cast<float*>(ideal_vel);
@@ -342,6 +355,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
         return fail(FG_ERR_ALIGNMENT, "obs_seq must be 16-byte, act_seq/ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
     a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+    if ((rc = set_obs_pitch(&a)) != FG_OK) return rc;
     a.do_phys = 1; a.do_post = 1;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
@@ -519,6 +533,7 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
         return fail(FG_ERR_ALIGNMENT, "obs_seq must be 16-byte, act_seq/ideal_shape/ideal_vel 8-byte aligned%s");
     Args a; memset(&a, 0, sizeof(a));
     a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+    if ((rc = set_obs_pitch(&a)) != FG_OK) return rc;
     a.do_phys = 1; a.do_post = 1;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
@@ -543,7 +558,8 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
         s1.rew = reward_seq + (size_t)k * bn;
         s1.indiv = indiv_seq ? indiv_seq + (size_t)k * bn : nullptr;
         s1.done = done_seq ? done_seq + (size_t)k * bn : nullptr;
-        s1.obs = (obs_seq && (k + 1) % a.obs_every == 0) ? obs_seq + (size_t)(k / a.obs_every) * bn * 6 * N : nullptr;
+        s1.obs = (obs_seq && (k + 1) % a.obs_every == 0)
+                     ? obs_seq + (size_t)(k / a.obs_every) * (size_t)B * (size_t)a.obs_pitch * 2 : nullptr;
         rc = launch_step(s1, st);
         if (rc) return rc;
     }

@@ -14,7 +14,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_WALLS = 4
 
 FG_OK = 0
@@ -50,6 +50,8 @@ class FgParams(ctypes.Structure):
         ("u_noise", ctypes.c_float),
         ("num_walls", ctypes.c_int32),
         ("walls", FgWall * 4),
+        ("obs_env_pitch", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 

@@ -196,8 +196,8 @@ class MultiAgentEnv(object):
         if launch is None:
             want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N))
             for k, shp in want.items():
-                if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
-                    raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
+                if k not in out or tuple(out[k].shape) != shp or not (out[k].is_contiguous() or k == "obs"):
+                    raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))   # obs: or a padded env pitch
             if key is not None:
                 if len(self._roll_launchers) >= 8:
                     self._roll_launchers.clear()
@@ -238,8 +238,8 @@ class MultiAgentEnv(object):
             out = {k: (torch.zeros(shp, dtype=torch.uint8, device=self._act.device) if k == "done"
                        else torch.empty(shp, **f)) for k, shp in want.items()}
         for k, shp in want.items():
-            if k not in out or tuple(out[k].shape) != shp or not out[k].is_contiguous():
-                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))
+            if k not in out or tuple(out[k].shape) != shp or not (out[k].is_contiguous() or k == "obs"):
+                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))       # obs: or a padded env pitch
         roll(self.world, K, num_agents_per_layer, out, obs_every=obs_every, auto_reset=self.auto_reset,
              rng_offset=self._rng_offset + 1)
         self._rng_offset += K

@@ -103,15 +103,34 @@ class Scenario(BaseScenario):
     def obs_dim(self, world):
         return 6 * len(world.agents)
 
-    def params(self, world, auto_reset=False, rng_offset=0):
+    def params(self, world, auto_reset=False, rng_offset=0, obs=None):
         a0 = world.agents[0]
-        return world.native_params(collide_thresh=(a0.size + a0.size) / 2,   # :121
-                                   auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
+        p = world.native_params(collide_thresh=(a0.size + a0.size) / 2,   # :121
+                                auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
+        p.obs_env_pitch = self.obs_env_pitch(obs, len(world.agents))
+        return p
+
+    @staticmethod
+    def obs_env_pitch(obs, N):
+        """Floats between the [N, 6N] blocks of consecutive envs of an observation tensor [B, N, 6N] or
+        [K, B, N, 6N]: 0 for a contiguous tensor, else its (padded) env stride.  Rows must be dense and, with a step
+        axis, the step slots B env pitches apart - anything else cannot be described to the kernels."""
+        if obs is None or obs.numel() == 0 or obs.is_contiguous():
+            return 0
+        D = 6 * N
+        ok = obs.dim() in (3, 4) and obs.stride(-1) == 1 and obs.stride(-2) == D and obs.shape[-2:] == (N, D)
+        pitch = obs.stride(-3) if ok else 0
+        if ok and obs.dim() == 4 and obs.shape[0] > 1:
+            ok = obs.stride(0) == obs.shape[1] * pitch
+        if not ok or pitch < N * D or pitch % 2:
+            raise ValueError("observation tensor must be [.., B, N, 6N] with dense rows and a uniform even env pitch "
+                             ">= 6 N^2 floats; got shape %s strides %s" % (tuple(obs.shape), tuple(obs.stride())))
+        return int(pitch)
 
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
         lib = _native.load()
         _native.check(lib.fg_step_hd(
-            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents),
+            self.params(world, auto_reset, rng_offset, out.get("obs")), world.num_envs, len(world.agents),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             act.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
             world.step_count.data_ptr(),
@@ -124,7 +143,7 @@ class Scenario(BaseScenario):
         """Resolve every pointer once and return `launch(rng_offset)`: the per-call
         host work is one ctypes call (rollout loops, bench.py)."""
         lib = _native.load()
-        p = self.params(world, auto_reset, 0)
+        p = self.params(world, auto_reset, 0, out.get("obs"))
         args = (world.num_envs, len(world.agents),
                 world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
                 act.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
@@ -147,7 +166,7 @@ class Scenario(BaseScenario):
     def observe_batch(self, world, out):
         lib = _native.load()
         _native.check(lib.fg_observe_hd(
-            self.params(world), world.num_envs, len(world.agents),
+            self.params(world, obs=out.get("obs")), world.num_envs, len(world.agents),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
             _native.ptr(out.get("obs")), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),
@@ -160,7 +179,7 @@ class Scenario(BaseScenario):
         lib = _native.load()
         K = act_seq.shape[0]
         _native.check(lib.fg_rollout_hd(
-            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents), K,
+            self.params(world, auto_reset, rng_offset, out.get("obs")), world.num_envs, len(world.agents), K,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
             world.step_count.data_ptr(),
@@ -173,7 +192,7 @@ class Scenario(BaseScenario):
         receives the actions taken, the other tensors are those of `rollout_batch`."""
         lib = _native.load()
         _native.check(lib.fg_rollout_hd_policy(
-            self.params(world, auto_reset, rng_offset), world.num_envs, len(world.agents), int(K), int(per_layer),
+            self.params(world, auto_reset, rng_offset, out.get("obs")), world.num_envs, len(world.agents), int(K), int(per_layer),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             out["act"].data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
             world.step_count.data_ptr(),
@@ -198,7 +217,7 @@ class Scenario(BaseScenario):
         `launch(rng_offset)`, one ctypes call per K-step launch (a 9 x 4096 launch lasts ~35 us on the GPU,
         less than the generic path spends in Python)."""
         lib = _native.load()
-        p = self.params(world, auto_reset, 0)
+        p = self.params(world, auto_reset, 0, out.get("obs"))
         args = (world.num_envs, len(world.agents), int(act_seq.shape[0]),
                 world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
                 act_seq.data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),

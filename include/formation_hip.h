@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 3
+#define FG_ABI_VERSION 4
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -76,7 +76,12 @@ typedef enum FgStatus {
  *   accel           core.py:236 + environment.py:219-220: force = mass*accel*(accel*action)
  *   max_speed       core.py:271-276 speed clamp after the velocity update
  *   u_noise         core.py:232-233 Gaussian motor noise (device counter RNG, distributional parity)
- *   walls           core.py:27-41,255-261,325-362 get_wall_collision_force, hard walls            */
+ *   walls           core.py:27-41,255-261,325-362 get_wall_collision_force, hard walls
+ * Layout option of the observation output (fg_step_hd, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy):
+ *   obs_env_pitch   the [N][6N] block of env b starts obs_env_pitch floats after env b-1's (even, >= 6 N^2);
+ *                   every agent count of the reference is odd, so contiguous env blocks are only 8-byte aligned -
+ *                   a pitch rounded up to 32 floats puts every env on its own 128-byte lines (a strided
+ *                   [B][N][6N] view on the caller's side).  A rollout's step slots are B * pitch apart.   */
 typedef struct FgWall {
     int32_t vertical;    /* orient: 0 = 'H' (lies on y = axis_pos), 1 = 'V' */
     float axis_pos;
@@ -103,6 +108,8 @@ typedef struct FgParams {
     float u_noise;
     int32_t num_walls;
     FgWall walls[FG_MAX_WALLS];
+    int32_t obs_env_pitch;   /* floats between the observation blocks of consecutive envs; 0 = 6 N^2 (contiguous) */
+    int32_t reserved0;
 } FgParams;
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:

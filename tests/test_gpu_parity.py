@@ -2,12 +2,17 @@
 against the golden fixtures captured from the reference and against the CPU
 oracle.  Run with `pytest -m gpu` on an MI355X.
 
-Tolerances (BASELINE.json north_star): 1e-5 abs in fp32 for state, observations
-and individual rewards, checked PER STEP with the state re-seeded from the
-reference (teacher forcing) and free-running over a short horizon - stiff
-contact springs make longer fp32 trajectories diverge chaotically (SURVEY.md
-7.3 H1).  The shared reward is a sum of N individual rewards (|r| up to ~270 at
-N=243, fp32 ulp 3e-5), so it is checked at 1e-5 relative + 1e-5 abs (H2).
+Tolerances (BASELINE.json north_star): 1e-5 abs in fp32 for positions, velocities,
+observations and individual rewards - every such bound in this file is ATOL = 1e-5, none is
+looser; the maxima actually measured are 3e-7 (positions), 2.6e-6 (velocities = position
+error / dt), 1.1e-6 (observations), 2.8e-7 (individual rewards), committed per fixture in
+profiles/r02_parity_errors.md.  They are checked PER STEP with the state re-seeded from the
+reference (teacher forcing) and free-running over a short horizon - stiff contact springs make
+longer fp32 trajectories diverge chaotically; the full-length free-running
+check is the fp64 build of the same kernel source, tests/test_gpu_f64_parity.py (<= 7e-12).
+The ONE relative bound: the shared reward is a sum of N individual rewards (|r| up to ~270 at
+N=243, where one fp32 ulp is 3e-5 > 1e-5 abs), so it is checked at 2e-6 relative + 1e-5 abs
+(measured: 1.8e-7 relative) (H2).
 done masks are bit-exact; landmark-index assignments are bit-exact except
 where the reference's own top-2 gap is < 1e-6 (a genuine fp32 near-tie, H5).
 """
@@ -58,7 +63,7 @@ def test_step_teacher_forced(golden, name):
         obs, rew, done, info = env.step(act)
         pos, vel = env.world.get_state()
         np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL * 10)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
         # rewards are functions of the post-step state; compare on the GPU's own state
         # against the oracle evaluated on that same fp32 state ...
         r = O.reward_hd(_np(pos), _np(vel), g["ideal_shape"].astype(np.float32).astype(np.float64),
@@ -68,8 +73,8 @@ def test_step_teacher_forced(golden, name):
         np.testing.assert_allclose(ind[margin_ok], r["indiv"][margin_ok], rtol=0, atol=ATOL)
         # ... and against the reference's numbers where no collision count sits on the edge
         ref_ok = g["cnt_margin"][t] > 1e-5
-        np.testing.assert_allclose(ind[ref_ok], g["indiv"][t][ref_ok], rtol=0, atol=5 * ATOL)
-        np.testing.assert_allclose(_np(rew)[ref_ok, :, 0], g["shared"][t][ref_ok], rtol=1e-5, atol=5 * ATOL)
+        np.testing.assert_allclose(ind[ref_ok], g["indiv"][t][ref_ok], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(rew)[ref_ok, :, 0], g["shared"][t][ref_ok], rtol=2e-6, atol=ATOL)
         assert rew.shape == (B, N, 1) and done.shape == (B, N) and done.dtype == torch.bool
         np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
         _check_indices(env._out["near_lm"].cpu().numpy(), r["near_lm"], r["gap_lm"], "near_lm")
@@ -80,7 +85,7 @@ def test_step_teacher_forced(golden, name):
         if (t + 1) in g["obs_steps"]:
             want = O.observation_hd(_np(pos), _np(vel), g["ideal_shape"], g["ideal_vel"])
             np.testing.assert_allclose(_np(obs), want, rtol=0, atol=2e-7)       # same fp32 state
-            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=2 * ATOL)
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=ATOL)
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
 
 
@@ -90,12 +95,14 @@ def test_free_running_short_horizon(golden, name):
     T, B, N = g["acts"].shape[:3]
     env = _make(N, B)
     _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
-    H = 8 if "crowd" in name else 10
+    # fp32 free-running error per fixture and step: profiles/r02_parity_errors.md (hd_n81: 6.4e-6 after 10 steps,
+    # hd_n27_crowd: 1.1e-6 after 5, 1e-5 after 10).  The horizon is what stays inside 1e-5; beyond it contacts amplify
+    # fp32 rounding chaotically (H1) and the fp64 build of the kernel carries the check (test_gpu_f64_parity.py)
+    H = 5 if "crowd" in name else 10
     for t in range(min(H, T)):
         env.step(torch.as_tensor(g["acts"][t]).cuda())
         pos, vel = env.world.get_state()
-        tol = (2e-4 if "crowd" in name else 2e-5)        # contacts amplify fp32 rounding (H1)
-        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=tol)
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
     assert (env.world.step_count.cpu().numpy() == min(H, T)).all()
 
 
@@ -186,11 +193,11 @@ def test_full_size_against_oracle_and_invariants(N, B):
         sub = {k: v[sl] for k, v in st32.items()}
         new, out = O.step_hd(sub, act[sl].astype(np.float64))
         np.testing.assert_allclose(pos[sl], new["pos"], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(vel[sl], new["vel"], rtol=0, atol=10 * ATOL)
+        np.testing.assert_allclose(vel[sl], new["vel"], rtol=0, atol=ATOL)
         ok = out["cnt_margin"] > 1e-5
         np.testing.assert_allclose(ind[sl][ok], out["indiv"][ok], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(shared[sl][ok], out["reward"][ok][..., 0], rtol=1e-5, atol=ATOL)
-        np.testing.assert_allclose(o[sl], out["obs"], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(shared[sl][ok], out["reward"][ok][..., 0], rtol=2e-6, atol=ATOL)
+        np.testing.assert_allclose(o[sl], out["obs"], rtol=0, atol=ATOL)
     # invariants
     assert not done.any()
     np.testing.assert_allclose(ind.sum(1), shared[:, 0], rtol=2e-6, atol=1e-4)   # shared = sum of individuals
@@ -228,9 +235,9 @@ def test_reference_style_api_single_env(golden):
         keep = [a.copy() for a in act_n]
         obs_n, rew_n, done_n, info_n = env.step(act_n)
         np.testing.assert_allclose(np.array(act_n), 5.0 * np.array(keep))          # scaled in place
-        np.testing.assert_allclose(np.array([x['individual_reward'] for x in info_n]), g["indiv"][t, 0], atol=5 * ATOL)
+        np.testing.assert_allclose(np.array([x['individual_reward'] for x in info_n]), g["indiv"][t, 0], atol=ATOL)
         assert rew_n[0] == rew_n[8] and isinstance(rew_n[0], list)
-        np.testing.assert_allclose(rew_n[0][0], g["shared"][t, 0, 0], rtol=1e-5, atol=ATOL)
+        np.testing.assert_allclose(rew_n[0][0], g["shared"][t, 0, 0], rtol=2e-6, atol=ATOL)
         assert done_n == [False] * 9
     with pytest.raises(TypeError):
         env.step([[0.0, 0.0]] * 9)                                                # lists rejected like the reference
@@ -266,9 +273,9 @@ def test_basic_formation_env(golden):
         obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
         pos, vel = env.world.get_state()
         np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=2 * ATOL)
-        np.testing.assert_allclose(_np(info["individual_reward"]), g["indiv"][t], rtol=0, atol=2 * ATOL)
-        np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=1e-5, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(info["individual_reward"]), g["indiv"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=2e-6, atol=ATOL)
         np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
 
@@ -385,14 +392,14 @@ def test_remaining_scenarios_teacher_forced(golden, scenario, kind, name):
         obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
         pos, vel = env.world.get_state()
         np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
         if P.num_obstacles:
             np.testing.assert_allclose(_np(env.world.obstacle_pos), g["lm"][t][:, L:], rtol=0, atol=ATOL)
             np.testing.assert_allclose(_np(env.world.obstacle_vel), g["lmvel"][t][:, L:], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=ATOL)
         # collision counts are integers: excuse only pairs sitting on the threshold
         want = g["indiv"][t]
-        bad = np.abs(_np(info["individual_reward"]) - want) > 2 * ATOL
+        bad = np.abs(_np(info["individual_reward"]) - want) > ATOL
         if bad.any():
             new, _ = O.step_scn(kind, dict(pos=g["pos"][t - 1] if t else g["pos0"], vel=g["vel"][t - 1] if t else g["vel0"],
                                            landmarks=(g["lm"][t - 1] if t else g["lm0"])[:, :L],
@@ -402,7 +409,7 @@ def test_remaining_scenarios_teacher_forced(golden, scenario, kind, name):
             PD = np.sqrt(((new["pos"][:, :, None] - new["pos"][:, None]) ** 2).sum(-1)) + 10 * np.eye(N)
             assert (np.abs(PD - P.collide_thresh).min() < 1e-5), "individual reward mismatch away from a threshold"
         else:
-            np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=1e-5, atol=5 * ATOL)
+            np.testing.assert_allclose(_np(rew)[..., 0], g["shared"][t], rtol=2e-6, atol=ATOL)
         np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
 
 
@@ -458,7 +465,7 @@ def test_bench_json_contract_single_and_two_ranks():
     # ONE clock: value, ms_per_step and roofline.achieved all come from the median HIP-event block, and a short
     # --steps block is repeated until >= 50 ms have been timed
     t = d["timing"]
-    assert t["blocks"] >= 3 and t["timed_ms_total"] >= 35.0 and t["block_ms_min"] <= t["block_ms_median"] <= t["block_ms_max"]
+    assert t["blocks"] >= 3 and t["timed_ms_total"] >= 40.0 and t["block_ms_min"] <= t["block_ms_median"] <= t["block_ms_max"]
     assert abs(d["ms_per_step"] * 30 - t["block_ms_median"]) < 1e-3 * t["block_ms_median"] + 1e-5
     assert abs(d["value"] - 512 * 30 / (t["block_ms_median"] * 1e-3)) < 1e-3 * d["value"]
     alg = d["roofline"]["algorithmic_bytes_per_launch"] / d["config"]["steps_per_launch"] * 30
@@ -561,7 +568,7 @@ def test_world_options_teacher_forced(golden, name, opts):
         obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
         pos, vel = env.world.get_state()
         np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
     if opts.get("max_speed"):
         assert float(torch.stack(env.world.get_state()[1:]).norm(dim=-1).max()) <= opts["max_speed"] * (1 + 1e-5)
@@ -587,13 +594,13 @@ def test_non_default_world_constants_teacher_forced(golden, name):
         obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
         pos, vel = env.world.get_state()
         np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=10 * ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
         ok = g["cnt_margin"][t] > 1e-5
-        np.testing.assert_allclose(_np(info["individual_reward"])[ok], g["indiv"][t][ok], rtol=0, atol=5 * ATOL)
-        np.testing.assert_allclose(_np(rew)[ok, :, 0], g["shared"][t][ok], rtol=1e-5, atol=5 * ATOL)
+        np.testing.assert_allclose(_np(info["individual_reward"])[ok], g["indiv"][t][ok], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(rew)[ok, :, 0], g["shared"][t][ok], rtol=2e-6, atol=ATOL)
         np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
         if (t + 1) in g["obs_steps"]:
-            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=2 * ATOL)
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=ATOL)
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
     # the same constants through a K-step rollout launch: bit-identical to single steps
     _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
@@ -764,11 +771,11 @@ def test_generic_agent_counts_against_oracle(N, B):
     new, out = O.step_hd(st, act.astype(np.float64))
     pos, vel = (_np(x) for x in env.world.get_state())
     np.testing.assert_allclose(pos, new["pos"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(vel, new["vel"], rtol=0, atol=10 * ATOL)
+    np.testing.assert_allclose(vel, new["vel"], rtol=0, atol=ATOL)
     r = O.reward_hd(pos, vel, st["ideal_shape"], st["ideal_vel"], O.HdParams())       # on the GPU's own state
     ok = r["cnt_margin"] > 1e-6
     np.testing.assert_allclose(_np(info["individual_reward"])[ok], r["indiv"][ok], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=1e-5, atol=ATOL)
+    np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=2e-6, atol=ATOL)
     np.testing.assert_allclose(_np(obs), O.observation_hd(pos, vel, st["ideal_shape"], st["ideal_vel"]), rtol=0, atol=2e-7)
     _check_indices(env._out["near_lm"].cpu().numpy(), r["near_lm"], r["gap_lm"], "near_lm")
     _check_indices(env._out["near_ag"].cpu().numpy(), r["near_ag"], r["gap_ag"], "near_ag")
@@ -806,14 +813,16 @@ def test_randomised_shapes_and_constants_against_oracle():
             obs, rew, done, info = env.step(torch.as_tensor(act).cuda())
             st, out = O.step_hd(st, act.astype(np.float64), P)
             pos, vel = (_np(x) for x in env.world.get_state())
+            # non-default constants (mass 0.5, contact force 200, dt 0.2 ...) drive speeds well above 1, where an fp32
+            # ulp is proportionally larger: the 1e-5 bound is scaled by the largest speed in the batch (1 at the defaults)
             scale = max(1.0, float(np.abs(st["vel"]).max()))
             msg = "case %d N=%d B=%d t=%d" % (case, N, B, t)
             np.testing.assert_allclose(pos, st["pos"], rtol=0, atol=ATOL * scale, err_msg=msg)
-            np.testing.assert_allclose(vel, st["vel"], rtol=0, atol=10 * ATOL * scale, err_msg=msg)
+            np.testing.assert_allclose(vel, st["vel"], rtol=0, atol=ATOL * scale, err_msg=msg)
             r = O.reward_hd(pos, vel, st["ideal_shape"], st["ideal_vel"], P)       # on the GPU's own fp32 state
             ok = r["cnt_margin"] > 1e-6
             np.testing.assert_allclose(_np(info["individual_reward"])[ok], r["indiv"][ok], rtol=0, atol=ATOL * scale, err_msg=msg)
-            np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=1e-5, atol=ATOL * scale, err_msg=msg)
+            np.testing.assert_allclose(_np(rew)[ok, :, 0], r["shared"][ok][:, None].repeat(N, 1), rtol=2e-6, atol=ATOL * scale, err_msg=msg)
             np.testing.assert_allclose(_np(obs), O.observation_hd(pos, vel, st["ideal_shape"], st["ideal_vel"]), rtol=0, atol=5e-7 * scale, err_msg=msg)
             np.testing.assert_array_equal(done.cpu().numpy(), out["done"], err_msg=msg)
             st = dict(st, pos=pos, vel=vel)            # continue from the GPU's state: one-step comparisons, no chaotic drift
@@ -965,7 +974,7 @@ def test_env_step_rebinds_when_inputs_or_world_constants_change():
         cur, out = O.step_hd(cur, _np(act), **world_options)
         pos, vel = (_np(x) for x in env.world.get_state())
         np.testing.assert_allclose(pos, cur["pos"], rtol=0, atol=ATOL)
-        np.testing.assert_allclose(_np(obs), out["obs"], rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(obs), out["obs"], rtol=0, atol=ATOL)
         cur = dict(cur, pos=pos, vel=vel)                 # teacher-force the oracle with the fp32 state
         return out
 
@@ -1025,8 +1034,8 @@ def test_action_modes_match_reference_fixtures(golden, name, mode):
         else:
             act_n = [g["acts"][t, i].astype(np.float64).copy() for i in range(N)]
         obs_n, rew_n, done_n, info_n = env1.step(act_n)
-        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=2 * ATOL)
-        np.testing.assert_allclose([r[0] for r in rew_n], g["shared"][t], rtol=1e-5, atol=ATOL)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose([r[0] for r in rew_n], g["shared"][t], rtol=2e-6, atol=ATOL)
         np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=ATOL)
         np.testing.assert_allclose(_np(env1.world.get_state()[0])[0], g["pos"][t], rtol=0, atol=ATOL)
         if mode != "index":
@@ -1035,7 +1044,7 @@ def test_action_modes_match_reference_fixtures(golden, name, mode):
         dt = torch.int32 if mode == "index" else torch.float32
         act = torch.as_tensor(np.repeat(g["acts"][t][None], 5, 0)).to(device="cuda", dtype=dt)
         obs, rew, done, info = envB.step(act)
-        np.testing.assert_allclose(_np(obs), np.repeat(g["obs"][t][None], 5, 0), rtol=0, atol=2 * ATOL)
+        np.testing.assert_allclose(_np(obs), np.repeat(g["obs"][t][None], 5, 0), rtol=0, atol=ATOL)
         np.testing.assert_allclose(_np(envB.world.get_state()[0]), np.repeat(g["pos"][t][None], 5, 0), rtol=0, atol=ATOL)
         if mode == "argmax":
             np.testing.assert_array_equal(_np(act)[0] * 5.0, g["acts_after"][t])   # one-hot written back
@@ -1077,8 +1086,8 @@ def test_baseline_full_size_per_gpu_properties(N, B):
     np.testing.assert_allclose(_np(pos)[idx], new["pos"], rtol=0, atol=ATOL)
     ok = out["cnt_margin"] > 1e-5
     np.testing.assert_allclose(_np(ind)[idx][ok], out["indiv"][ok], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(_np(rew)[idx][ok], out["reward"][ok], rtol=1e-5, atol=ATOL)
-    np.testing.assert_allclose(_np(obs[torch.as_tensor(idx, device=dev)]), out["obs"], rtol=0, atol=2 * ATOL)
+    np.testing.assert_allclose(_np(rew)[idx][ok], out["reward"][ok], rtol=2e-6, atol=ATOL)
+    np.testing.assert_allclose(_np(obs[torch.as_tensor(idx, device=dev)]), out["obs"], rtol=0, atol=ATOL)
     # batch independence, bit for bit
     nb = 13
     env2 = _make(N, nb)
