@@ -293,7 +293,6 @@ def main():
             env.scenario.reset_device(env.world, rng_offset=999)   # host MT19937 streams for > 65536 envs take minutes
         else:
             env.reset()
-        env.scenario._seed = 1 + rank                            # device auto-reset streams differ per rank
         env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device
         env.world.step_count.zero_()
 

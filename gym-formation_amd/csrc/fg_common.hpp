@@ -71,7 +71,7 @@ struct KParams {
     double accel, max_speed, u_noise;
     int32_t num_walls;
     FgWall walls[FG_MAX_WALLS];
-    int32_t obs_env_pitch, reserved0;
+    int32_t obs_env_pitch, env_index_base;
 };
 #else
 typedef FgParams KParams;

@@ -51,7 +51,7 @@ class FgParams(ctypes.Structure):
         ("num_walls", ctypes.c_int32),
         ("walls", FgWall * 4),
         ("obs_env_pitch", ctypes.c_int32),
-        ("reserved0", ctypes.c_int32),
+        ("env_index_base", ctypes.c_int32),
     ]
 
 

@@ -48,16 +48,16 @@ class Scenario(BaseScenario):
 
     # ---- RNG: the reference draws from the global legacy MT19937 ----------
     def seed(self, seed=None):
-        """env.seed(s) (environment.py:106-110).  Env b gets RandomState(s + 1000 b),
+        """env.seed(s) (environment.py:106-110).  Env b gets RandomState(s + 1000 (env_base + b)),
         the per-worker convention of train/maddpg-v2/main.py:19-30; b = 0 is the
-        reference's single env."""
+        reference's single env.  `env_base` = global index of this batch's env 0 (sharding.make_env_shard)."""
         self._seed = 1 if seed is None else int(seed)
         self._rngs = None
         self._mt_state = None
 
     def _streams(self, B):
         if self._rngs is None or len(self._rngs) != B:
-            self._rngs = [np.random.RandomState(self._seed + 1000 * b) for b in range(B)]
+            self._rngs = [np.random.RandomState(self._seed + 1000 * (getattr(self, "env_base", 0) + b)) for b in range(B)]
         return self._rngs
 
     def reset_world(self, world, env_mask=None):
@@ -108,6 +108,7 @@ class Scenario(BaseScenario):
         p = world.native_params(collide_thresh=(a0.size + a0.size) / 2,   # :121
                                 auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
         p.obs_env_pitch = self.obs_env_pitch(obs, len(world.agents))
+        p.env_index_base = int(getattr(self, "env_base", 0))
         return p
 
     @staticmethod
@@ -294,12 +295,16 @@ class Scenario(BaseScenario):
         return self._fresh(world)["indiv"][:, agent.i]
 
     def benchmark_data(self, agent, world):
-        """:97-117."""
+        """:97-117 for `agent` in every env -> dict of [B] tensors.  The env shell evaluates it right after
+        `observation` (environment.py:127-131), which has just re-centred the landmarks on the agents (:40-44):
+        the landmark positions it measures against are ideal_shape + centroid(agents)."""
         rew = self.reward(agent, world)
         pos, _ = world.get_state()
         d = (pos - pos[:, agent.i:agent.i + 1]).norm(dim=-1)
-        collisions = (d < world.agents[0].size).sum(1)          # self included, as in :101-104
-        dl = (pos[:, :, None, :] - world.landmark_pos[:, None, :, :]).norm(dim=-1).min(1).values
+        a0 = world.agents[0]
+        collisions = (d < (a0.size + a0.size) / 2).sum(1)       # is_collision (:119-121), `agent` itself included (:101-104)
+        lm = self.ideal_shape + pos.mean(1, keepdim=True)
+        dl = (pos[:, :, None, :] - lm[:, None, :, :]).norm(dim=-1).min(1).values     # per landmark: its nearest agent
         return {'reward': rew, 'collisions': collisions, 'min_dists': dl.sum(1),
                 'occupied_landmarks': (dl < 0.1).sum(1)}
 

@@ -61,7 +61,7 @@ class LandmarkScenario(BaseScenario):
 
     def _streams(self, B):
         if self._rngs is None or len(self._rngs) != B:
-            self._rngs = [np.random.RandomState(self._seed + 1000 * b) for b in range(B)]
+            self._rngs = [np.random.RandomState(self._seed + 1000 * (getattr(self, "env_base", 0) + b)) for b in range(B)]
         return self._rngs
 
     def reset_world(self, world, env_mask=None):

@@ -47,7 +47,8 @@ def make_env_shard(scenario_name, num_agents, global_envs, seed=1, rank=None, wo
     # allocates next to the env (action pools, rollout buffers, `torch.cuda.current_stream()`) lands on it too
     torch.cuda.set_device(device)
     env = formation_gym.make_env(scenario_name, False, num_agents, num_envs=hi - lo, device=device, **scenario_kwargs)
-    env.seed(int(seed) + 1000 * lo)              # env b of this rank: seed + 1000 (lo + b)
+    env.scenario.env_base = lo                   # env b of this rank IS global env lo + b: host reset streams
+    env.seed(int(seed))                          # RandomState(seed + 1000 (lo + b)), device counter RNG keyed alike
     return env, lo, hi
 
 

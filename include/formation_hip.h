@@ -109,7 +109,9 @@ typedef struct FgParams {
     int32_t num_walls;
     FgWall walls[FG_MAX_WALLS];
     int32_t obs_env_pitch;   /* floats between the observation blocks of consecutive envs; 0 = 6 N^2 (contiguous) */
-    int32_t reserved0;
+    int32_t env_index_base;  /* GLOBAL index of this batch's env 0 (a rank's slice of a sharded batch): the device
+                                counter RNG (auto-reset, fg_reset_hd, motor noise) is keyed by seed and GLOBAL env index,
+                                so its draws do not depend on how the batch is cut over GPUs */
 } FgParams;
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:

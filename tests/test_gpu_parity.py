@@ -1147,3 +1147,67 @@ def test_determinism_reentrancy_and_soak():
     assert float(pos.abs().max()) < 25.0 and float(vel.abs().max()) < 8.0
     assert int(e.world.step_count.max()) < 100 and int(e.world.step_count.min()) >= 0
     assert int(seq["done"].sum()) == B * N                       # launch 50 ends at step 1000: every env is done once in it
+
+
+def test_benchmark_flag_and_benchmark_data_match_reference(golden):
+    """make_env(..., benchmark=True) (reference __init__.py:13-14): step() returns exactly what it returns without
+    the flag (environment.py:130-133 forwards only a 'fail' key that benchmark_data never sets), and
+    Scenario.benchmark_data (formation_hd_env.py:97-117) gives the reference's numbers for every agent."""
+    import formation_gym
+    g = golden("benchmark_n9")
+    T, N = g["acts"].shape[:2]
+    env = formation_gym.make_env("formation_hd_env", True, N)                    # reference signature, one env
+    plain = formation_gym.make_env("formation_hd_env", False, N)
+    assert env.info_callback is not None and plain.info_callback is None
+    for e in (env, plain):
+        e.world.set_state(g["pos0"][None], g["vel0"][None])
+        e.scenario.set_formation(e.world, g["ideal_shape"][None], g["ideal_vel"][None])
+        e.world.step_count.zero_()
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        for e in (env, plain):                                                  # teacher-forced
+            e.world.set_state(prev_pos[None], prev_vel[None])
+        act = [g["acts"][t, i].astype(np.float64) for i in range(N)]
+        obs_n, rew_n, done_n, info_n = env.step([a.copy() for a in act])
+        obs_p, rew_p, done_p, info_p = plain.step([a.copy() for a in act])
+        assert all(sorted(i.keys()) == ["individual_reward"] for i in info_n)
+        assert rew_n == rew_p and done_n == done_p and info_n == info_p
+        assert all((a == b).all() for a, b in zip(obs_n, obs_p))
+        np.testing.assert_allclose(rew_n[0][0], g["shared"][t], rtol=2e-6, atol=ATOL)
+        for i, agent in enumerate(env.agents):
+            bd = env._get_info(agent)
+            assert set(bd) == {"reward", "collisions", "min_dists", "occupied_landmarks"}
+            np.testing.assert_allclose(float(bd["reward"][0]), g["b_reward"][t, i], rtol=0, atol=ATOL)
+            assert int(bd["collisions"][0]) == int(g["b_collisions"][t, i])
+            np.testing.assert_allclose(float(bd["min_dists"][0]), g["b_min_dists"][t, i], rtol=2e-6, atol=ATOL)
+            assert int(bd["occupied_landmarks"][0]) == int(g["b_occupied"][t, i])
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+def test_rank_processes_on_the_hip_path_reproduce_the_one_process_batch(tmp_path):
+    """Multi-GPU plumbing with the REAL per-rank compute: 2 and 3 rank processes (sharing this box's one GPU), each
+    stepping its slice of a global batch through libformation_hip under torch.distributed (gloo rendezvous, host-side
+    gather), reproduce bit for bit what one process computes for the whole batch - reset streams by GLOBAL env index,
+    device auto-resets keyed by global env, no collective on the data path."""
+    from formation_gym import sharding
+    N, G, K = 9, 37, 12
+    whole, lo, hi = sharding.make_env_shard("formation_hd_env", N, G, seed=5, rank=0, world_size=1, local_rank=0)
+    whole.auto_reset = True
+    whole.reset()
+    whole.world.step_count.copy_((torch.arange(G, dtype=torch.int32) * 7 % 100).cuda())
+    gen = torch.Generator(); gen.manual_seed(123)
+    acts = (torch.rand((K, G, N, 2), generator=gen) * 2 - 1).cuda()
+    obs, rew, done, info = whole.rollout(acts)
+    for ws in (2, 3):
+        out = str(tmp_path / ("shards_%d.npz" % ws))
+        _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ws), "--master-addr", "127.0.0.1",
+              "--master-port", _free_port(), "tests/helpers/shard_worker.py", out, str(N), str(G), str(K)],
+             env_extra={"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        r = np.load(out)
+        assert r["slices"][0, 0] == 0 and r["slices"][-1, 1] == G and (r["slices"][1:, 0] == r["slices"][:-1, 1]).all()
+        np.testing.assert_array_equal(r["obs_last"], obs[-1].cpu().numpy())
+        np.testing.assert_array_equal(r["rew"], rew[..., 0].permute(1, 0, 2).cpu().numpy())
+        np.testing.assert_array_equal(r["done"], done.permute(1, 0, 2).cpu().numpy().astype(np.uint8))
+        np.testing.assert_array_equal(r["pos_x"], whole.world.pos_x.cpu().numpy())
+        np.testing.assert_array_equal(r["shape"], whole.scenario.ideal_shape.cpu().numpy())
+    assert done.any()
