@@ -147,6 +147,7 @@ struct ScnArgs {
     float* px; float* py; float* vx; float* vy;
     const float* act; const float* lm; float* opos; float* ovel; int32_t* step;
     float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
+    int stage;     // compose the workgroup's observation rows in LDS and stream them out as ONE contiguous span
 };
 
 template <int G, int T>
@@ -294,7 +295,11 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         if (a.rew) a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
         if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
         if (a.done) a.done[sidx] = is_done ? 1 : 0;
-        float2* o = reinterpret_cast<float2*>(a.obs + sidx * D);
+        // every lane composes its own row: straight to global memory (rows D floats apart: one 8-byte piece per lane
+        // and instruction), or into the workgroup's LDS image of its [E][N][D] block, which all lanes then copy out
+        // with consecutive 8-byte stores (a.stage; 16 x 65536 obstacle envs: 203 -> see profiles/r02_aux_kernels.md)
+        float2* const stage0 = smem + E * (2 * NE + L);                              // behind the last env's tables
+        float2* o = a.stage ? stage0 + (size_t)(e * N + i) * (D / 2) : reinterpret_cast<float2*>(a.obs + sidx * D);
         int w = 0;
         o[w++] = v;
         if (kind == FG_SCN_BASIC) o[w++] = p;
@@ -316,6 +321,15 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             }
         }
         for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
+    }
+    if (a.stage) {
+        __syncthreads();
+        const float2* const img = smem + E * (2 * NE + L);
+        const int b0 = blockIdx.x * E;
+        const int El = min(E, a.B - b0);
+        const int units = El * N * (D / 2);
+        float2* const out = reinterpret_cast<float2*>(a.obs + (size_t)b0 * N * D);
+        for (int q = tid; q < units; q += T) out[q] = img[q];
     }
     if (a.do_phys && a.step && live && i == 0) a.step[b] = t_step;
 }

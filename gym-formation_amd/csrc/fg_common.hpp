@@ -125,7 +125,15 @@ struct Args {
     // evaluated on the workgroup's own state instead of from `act`
     FgPolicyLevels pl;
     real* act_out;            // [K][B][N][2] the actions taken
+#ifdef FG_TRACE
+    long long* trace;          // diagnostic build only (profiles/r02_trace.py): 8 realtime stamps (100 MHz) per workgroup
+#endif
 };
+#ifdef FG_TRACE
+#define FG_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FG_STAMP(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------
 // reductions over the lanes of one environment

@@ -63,6 +63,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     const real thr2 = (real)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
     const real invN = NC ? 1.0f / (real)(NC ? NC : 1) : a.inv_n;      // compile-time N: folded to the same correctly rounded value
 
+    FG_STAMP(0);
     // ---- phase 1: state -> registers + LDS --------------------------------
     real2 p = make_real2(0.f, 0.f), v = make_real2(0.f, 0.f), s = make_real2(0.f, 0.f);
     int t_step = 0;
@@ -85,6 +86,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     if (env_ok && pre_step) t_step = pre_step[b];
     if (tid < 2) reset_flag[tid] = 0;
     __syncthreads();
+    FG_STAMP(1);
 
     for (int k = 0; k < a.K; ++k) {
         int slot = k;
@@ -118,6 +120,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             // so the common no-reset step pays no extra barrier later.
             if (a.p.auto_reset && env_ok && i == 0 && t_step >= a.p.world_length) reset_flag[k & 1] = 1;
             __syncthreads();
+            FG_STAMP(2);
             // the other parity slot is re-armed every step (it was last read in step k-1, which the barrier above
             // closed, and is next written in step k+1, after the barrier that ends this step)
             if (tid == 0) reset_flag[(k + 1) & 1] = 0;
@@ -197,6 +200,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 __syncthreads();
             }
 
+            FG_STAMP(3);
             // ---- phase 5: observations --------------------------------------
             if (want_obs && !FLAT) {
                 if constexpr (NC > 0)
@@ -255,6 +259,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             }
         }
 
+        FG_STAMP(4);
         if (k + 1 < a.K) {
             __syncthreads();            // obs phase done reading A/V before the next step writes them
             if (valid) { QX[i] = p.x; QY[i] = p.y; }
@@ -267,6 +272,10 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
     }
     if (a.do_phys && a.step && env_ok && i == 0) a.step[b] = t_step;
+#ifdef FG_TRACE
+    __builtin_amdgcn_s_waitcnt(0);      // every store of this wave has been acknowledged
+    FG_STAMP(5);
+#endif
 }
 
 }  // namespace fg

@@ -27,6 +27,7 @@
 // tables, dispatch and the extern "C" entry points.
 
 #include <atomic>
+#include <cstdlib>
 #include "fg_common.hpp"
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
@@ -137,6 +138,9 @@ static bool world_options_set(const FgParams& p) {
 }
 
 static int launch_step(Args a, hipStream_t st) {
+#ifdef FG_TRACE
+    { const char* e = getenv("FG_TRACE_PTR"); a.trace = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
+#endif
     Geometry g;
     const bool opts = world_options_set(a.p);
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
@@ -431,7 +435,14 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     const int G = pow2ceil(N + M) < 4 ? 4 : pow2ceil(N + M);
     const int E = 64 / G;
     const int grid = (B + E - 1) / E;
-    const int lds = E * (2 * (N + M) + L) * (int)sizeof(float2);
+    int lds = E * (2 * (N + M) + L) * (int)sizeof(float2);
+    {   // observation rows composed in LDS and streamed out contiguously when the workgroup's block fits
+        const int nbr = (sc->kind == FG_SCN_PARTIAL) ? sc->num_obs : (N - 1);
+        const long long D = 2 + (sc->kind == FG_SCN_BASIC ? 2 : 0) + 2LL * L + 2LL * M + 2LL * nbr + 2LL * (N - 1);
+        const long long stage = (long long)E * N * D * (long long)sizeof(float);
+        a.stage = (lds + stage <= 48 * 1024) ? 1 : 0;
+        if (a.stage) lds += (int)stage;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (G == 4) hipLaunchKernelGGL((scn_kernel<4, 64>), dim3(grid), dim3(64), lds, st, a);
     else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);

@@ -82,6 +82,13 @@ class FormationVecEnv(object):
             raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
         return self.env.rollout(action_seq, out=out, obs_every=obs_every)
 
+    def rollout_policy(self, K, num_agents_per_layer=3, out=None, obs_every=1):
+        """K vec-env steps driven by the reference's built-in controller (`env.rollout_policy`): the demo loop of
+        test.py:17-27 in one call; infos carries the actions taken ('device' reset mode only)."""
+        if self.reset_mode != "device":
+            raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
+        return self.env.rollout_policy(K, num_agents_per_layer, out=out, obs_every=obs_every)
+
     def step_async(self, actions):
         self._pending = self.step(actions)
 
