@@ -233,7 +233,12 @@ def main():
         import datetime
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
         sync_backend = "gloo"
-        if a.backend == "nccl":
+        if a.backend == "nccl" and ndev < world_size:
+            # ranks share a GPU (fewer devices than ranks): RCCL cannot form a communicator over duplicate devices and
+            # its bring-up may hang rather than fail - decided from the device count alone, identically on every rank
+            if rank == 0:
+                print("bench: %d ranks on %d GPU(s): timing barrier stays on gloo" % (world_size, ndev), file=sys.stderr, flush=True)
+        elif a.backend == "nccl":
             ok, why = 1, ""
             try:
                 g = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))

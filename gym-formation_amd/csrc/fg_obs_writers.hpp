@@ -126,13 +126,20 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
 // (tiles of an odd N start 8 bytes off every other time), so both sides of the copy are
 // naturally aligned.  Only the issuing wave touches its tile: LDS operations of one wave
 // complete in order, no barrier is needed.
+// Line ownership (waves own whole envs, E >= NW): every agent count of the reference is odd, so consecutive env
+// blocks share a 128-byte line, and that line would be written in two instalments by two different waves at
+// different times - partial-line writes that cost ~4 % of the stream (profiles/r02_store/env_order.txt: "pad
+// written" against "pad skipped").  The wave of env e therefore also stores the first units of env e+1 up to the next
+// line boundary (composed from env e+1's tables, same LDS buffer) and the wave of env e+1 starts at that boundary;
+// a workgroup's 16-env span starts and ends on line boundaries, so every store covers whole lines.  With a padded env
+// pitch (next multiple of 128 bytes) the same slot holds the pad, which is then written as zeros.
 // ---------------------------------------------------------------------------
-template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 2 + 1) & ~1; }
+template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 16 + 2 + 1) & ~1; }
 
 // `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
 template <int NC, int NW, int E, int RT>
 FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
-                            float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El) {
+                            float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El, bool line_own) {
     constexpr int N = NC;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
@@ -152,6 +159,25 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     const int t_first = (E >= NW) ? 0 : w % WPE;
     const int n_env = (El > e_first) ? (El - e_first + e_step - 1) / e_step : 0;
     const int total = n_env * MY_TILES;
+
+    // line ownership: units of the NEXT env (or pad) a wave appends to its env's last tile / skips at its first tile
+    constexpr unsigned ENVU = ROWU * N;
+    const unsigned pad = (unsigned)(env_units - ENVU);
+    // (27 agents: 1-3.5 % on a good box, 12 % on one whose allocation took partial lines badly, and a steadier rate;
+    //  9 agents, one 1 944-byte tile per env: the extra compose step costs more than the lines save - not applied)
+    // Measured (profiles/r02_pitch/line_ownership_box*.txt, interleaved rounds against the previous library): 27 x 4096
+    // 13.7-14.7 -> 12.8-13.7 us/step (the old writer's rate swings with the allocation, this one's does not), 27 x 16384
+    // even, 27 x 65536 194 -> 204 us/step: the host switches it on below 16 384 envs (Args.line_own).
+    const bool own = line_own && (E >= NW) && (NC >= 16) && ((unit0 & 15) == 0) &&
+                     (pad == 0 || (pad < 16 && (env_units & 15) == 0));
+    auto head_units = [&](int ee) -> unsigned {                        // of env ee, owned by the wave of env ee - 1
+        return (own && pad == 0) ? (16u - (unsigned)(((size_t)ee * env_units) & 15)) & 15u : 0u;
+    };
+    auto extra_units = [&](int ee) -> unsigned {                       // appended behind env ee's last row
+        if (!own) return 0u;
+        if (pad) return pad;
+        return (ee + 1 < El) ? head_units(ee + 1) : 0u;
+    };
 
     int cur_env = -1;
     const float2* __restrict__ AA = tables0;
@@ -188,6 +214,20 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             const int rl = rb + ssub;
             if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
         }
+        if (r0 + RT == N) {                                            // last tile of the env: the line's remainder
+            const unsigned x = extra_units(ee);
+            if ((unsigned)lane < x) {
+                float2 val = make_float2(0.f, 0.f);                    // padded pitch: zeros
+                if (pad == 0) {                // row 0 of env ee + 1: [v_0 | p_u - p_0 (1 <= u < N) | A[u] (u >= N) ...]
+                    static_assert(ROWU >= 16, "the line remainder must stay inside row 0 of the next env");
+                    const float2* __restrict__ A1 = tables0 + (size_t)(ee + 1) * env_stride;
+                    const float2 a = A1[lane == 0 ? 3 * N : lane], b = A1[0];
+                    const bool rel = lane >= 1 && lane < N;
+                    val = make_float2(a.x - (rel ? b.x : 0.f), a.y - (rel ? b.y : 0.f));
+                }
+                img[TU + (unsigned)lane] = val;
+            }
+        }
     };
     auto stream = [&](int t) {
         int ee, r0; locate(t, ee, r0);
@@ -195,17 +235,20 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
         const unsigned par = (unsigned)((unit0 + (size_t)ee * env_units + (size_t)r0 * ROWU) & 1);
         const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
         float2* __restrict__ out = out_env0 + (size_t)ee * env_units + (size_t)r0 * ROWU;
-        if (par && lane == 0) out[0] = img[0];
-        constexpr unsigned NPMAX = TU >> 1;
-        const unsigned npair = (TU - par) >> 1;
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + par);
-        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
+        const unsigned s = (r0 == 0) ? head_units(ee) : 0u;            // first unit this wave stores
+        const unsigned end = TU + ((r0 + RT == N) ? extra_units(ee) : 0u);
+        const unsigned p2 = (par + s) & 1u;                            // 8-byte head to reach 16-byte alignment
+        if (p2 && lane == 0) out[s] = img[s];
+        constexpr unsigned NPMAX = (TU + 16) >> 1;
+        const unsigned npair = (end - s - p2) >> 1;
+        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + s + p2);
+        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + s + p2);
 #pragma unroll
         for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
             const unsigned q = q0 + lane;
             if (q < npair) dst4[q] = src4[q];
         }
-        if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
+        if (((end - s - p2) & 1u) && lane == 63) out[end - 1] = img[end - 1];
     };
     if (total > 0) compose(0);
     for (int t = 0; t < total; ++t) {

@@ -25,8 +25,11 @@ namespace fg {
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
 
+// Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
+// workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.
 template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY = false>
-__global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
+__global__ __launch_bounds__(TP + TW) __attribute__((amdgpu_waves_per_eu((TP + TW) <= 512 ? 4 : 3)))
+void rollout_kernel(const Args a) {
     // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
     // POLICY: closed loop - the action of step k is the demo controller (3-ary hierarchy) on the state step k-1
     //         left, evaluated by the env's own lane group; a.act is not read, a.act_out records the actions
@@ -204,7 +207,8 @@ __global__ __launch_bounds__(TP + TW) void rollout_kernel(const Args a) {
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                         reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
-                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
+                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El,
+                                                        a.line_own != 0);
             }
         }
         __syncthreads();

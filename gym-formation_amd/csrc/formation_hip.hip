@@ -184,8 +184,9 @@ static int launch_wide(const Args& a, hipStream_t st) {
 
 // N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
 template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY>
-static int launch_roll_v(const Args& a, hipStream_t st) {
+static int launch_roll_v(Args a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
+    a.line_own = a.B < 16384;          // line ownership of the tile writer pays for batches of a few generations only
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
     if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
     if (POLICY) lds += E * policy_block_units(NC) * (int)sizeof(float2);

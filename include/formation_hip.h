@@ -81,7 +81,8 @@ typedef enum FgStatus {
  *   obs_env_pitch   the [N][6N] block of env b starts obs_env_pitch floats after env b-1's (even, >= 6 N^2);
  *                   every agent count of the reference is odd, so contiguous env blocks are only 8-byte aligned -
  *                   a pitch rounded up to 32 floats puts every env on its own 128-byte lines (a strided
- *                   [B][N][6N] view on the caller's side).  A rollout's step slots are B * pitch apart.   */
+ *                   [B][N][6N] view on the caller's side).  A rollout's step slots are B * pitch apart.  The pad
+ *                   floats between env blocks belong to the library: they may be overwritten with zeros.      */
 typedef struct FgWall {
     int32_t vertical;    /* orient: 0 = 'H' (lies on y = axis_pos), 1 = 'V' */
     float axis_pos;

@@ -438,15 +438,25 @@ def _free_port():
         return str(sk.getsockname()[1])
 
 
-def _run(cmd, env_extra=None, timeout=600):
+def _run(cmd, env_extra=None, timeout=300):
+    """Run a Python command from the repo root; on a timeout the WHOLE process group is killed (a launcher's rank
+    processes would otherwise keep the pipes open and block this test for good)."""
     import os
+    import signal
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **(env_extra or {}))
-    out = subprocess.run([sys.executable] + cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    return out.stdout
+    proc = subprocess.Popen([sys.executable] + cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                            text=True, start_new_session=True)
+    try:
+        stdout, stderr = proc.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, stderr = proc.communicate()
+        raise AssertionError("timed out after %d s: %s\n%s" % (timeout, " ".join(cmd), (stdout[-1500:] + stderr[-1500:])))
+    assert proc.returncode == 0, stdout[-2000:] + stderr[-2000:]
+    return stdout
 
 
 def test_bench_json_contract_single_and_two_ranks():
@@ -488,15 +498,15 @@ def test_bench_json_contract_single_and_two_ranks():
         assert abs(g["env_steps_per_s"] - n_env / (g["ms_per_step"] * 1e-3)) < 2e-3 * g["env_steps_per_s"]
         assert abs(g["agent_steps_per_s"] - n_ag * g["env_steps_per_s"]) < 1e-3 * g["agent_steps_per_s"]
         assert "scaling_efficiency_vs_n1" in g
-    # default backend with two ranks on ONE GPU: RCCL cannot come up (duplicate device), every rank agrees to
-    # keep the timing barrier on gloo and the run still completes
+    # default backend (nccl = RCCL) with more ranks than GPUs: RCCL cannot form a communicator over duplicate devices, so
+    # bench.py keeps the timing barrier on gloo without trying (decided from the device count, same on every rank)
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", _free_port(), "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256",
-                "--agents", "9", "--no-extra", "--min-timed-ms", "5"], timeout=600)
+                "--agents", "9", "--no-extra", "--min-timed-ms", "5"])
     line = [l for l in out.splitlines() if l.startswith("{")]
     assert len(line) == 1
     d3 = json.loads(line[0])
-    assert d3["n_gpus"] == 2 and d3["config"]["timing_barrier"] in ("gloo", "rccl")
+    assert d3["n_gpus"] == 2 and d3["config"]["timing_barrier"] == ("gloo" if torch.cuda.device_count() < 2 else "rccl")
     # without a launcher, `--gpus 2` starts its own ranks
     out = _run(["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs", "256", "--agents", "9",
                 "--backend", "gloo", "--no-extra", "--min-timed-ms", "5"])
