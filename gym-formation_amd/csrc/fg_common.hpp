@@ -117,7 +117,6 @@ struct Args {
     int32_t* step;             // [B]
     real* obs;                // [slots][B] env blocks of [N][6N], obs_pitch float2 units apart
     long long obs_pitch;       // float2 units between consecutive env blocks: 3 N^2 (contiguous) or a padded pitch
-    int line_own;              // LDS-tile writer: waves own whole 128-byte lines across env boundaries (fg_obs_writers.hpp)
     real* rew;                // [K][B][N]
     real* indiv;              // [K][B][N] or NULL
     uint8_t* done;             // [K][B][N] or NULL

@@ -137,9 +137,11 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
 template <int NC, int RT> constexpr int tile_units() { return (3 * NC * RT + 16 + 2 + 1) & ~1; }
 
 // `tiles` holds TWO tiles per writing wave: tile t+1 is composed while tile t drains.
-template <int NC, int NW, int E, int RT>
+// STREAM: the HBM-streaming form (line ownership + paced stores, see above and stream() below); false: the plain form
+// (every wave stores exactly its env's bytes, all LDS reads of a tile in flight before its stores).
+template <int NC, int NW, int E, int RT, bool STREAM>
 FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, int w, float2* __restrict__ tiles,
-                            float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El, bool line_own) {
+                            float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El) {
     constexpr int N = NC;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;
     static_assert((E >= NW) ? (E % NW == 0) : (NW % E == 0), "waves and envs must tile");
@@ -165,11 +167,10 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     const unsigned pad = (unsigned)(env_units - ENVU);
     // (27 agents: 1-3.5 % on a good box, 12 % on one whose allocation took partial lines badly, and a steadier rate;
     //  9 agents, one 1 944-byte tile per env: the extra compose step costs more than the lines save - not applied)
-    // Measured (profiles/r02_pitch/line_ownership_box*.txt, interleaved rounds against the previous library): 27 x 4096
-    // 13.7-14.7 -> 12.8-13.7 us/step (the old writer's rate swings with the allocation, this one's does not), 27 x 16384
-    // even, 27 x 65536 194 -> 204 us/step: the host switches it on below 16 384 envs (Args.line_own).
-    const bool own = line_own && (E >= NW) && (NC >= 16) && ((unit0 & 15) == 0) &&
-                     (pad == 0 || (pad < 16 && (env_units & 15) == 0));
+    // STREAM = the launch streams to HBM (host: < 16 384 envs and a rollout buffer beyond the Infinity Cache): line
+    // ownership here, paced stores in stream().  Ownership alone is worth ~2 % and a steadier rate, the pacing ~8 %.
+    static_assert(!STREAM || (E >= NW && NC >= 16), "streaming form: waves own whole envs, rows of >= 16 units");
+    const bool own = STREAM && ((unit0 & 15) == 0) && (pad == 0 || (pad < 16 && (env_units & 15) == 0));
     auto head_units = [&](int ee) -> unsigned {                        // of env ee, owned by the wave of env ee - 1
         return (own && pad == 0) ? (16u - (unsigned)(((size_t)ee * env_units) & 15)) & 15u : 0u;
     };
@@ -214,7 +215,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             const int rl = rb + ssub;
             if (ssub < RS && rl < RT) img[(unsigned)rl * ROWU + (unsigned)(N + sidx)] = sv;
         }
-        if (r0 + RT == N) {                                            // last tile of the env: the line's remainder
+        if (STREAM && r0 + RT == N) {                                  // last tile of the env: the line's remainder
             const unsigned x = extra_units(ee);
             if ((unsigned)lane < x) {
                 float2 val = make_float2(0.f, 0.f);                    // padded pitch: zeros
@@ -235,20 +236,48 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
         const unsigned par = (unsigned)((unit0 + (size_t)ee * env_units + (size_t)r0 * ROWU) & 1);
         const float2* img = tile0 + (t & 1) * tile_units<NC, RT>() + par;
         float2* __restrict__ out = out_env0 + (size_t)ee * env_units + (size_t)r0 * ROWU;
-        const unsigned s = (r0 == 0) ? head_units(ee) : 0u;            // first unit this wave stores
-        const unsigned end = TU + ((r0 + RT == N) ? extra_units(ee) : 0u);
-        const unsigned p2 = (par + s) & 1u;                            // 8-byte head to reach 16-byte alignment
-        if (p2 && lane == 0) out[s] = img[s];
-        constexpr unsigned NPMAX = (TU + 16) >> 1;
-        const unsigned npair = (end - s - p2) >> 1;
-        const f32x4* src4 = reinterpret_cast<const f32x4*>(img + s + p2);
-        f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + s + p2);
+        if constexpr (!STREAM) {
+            if (par && lane == 0) out[0] = img[0];
+            constexpr unsigned NPMAX = TU >> 1;
+            const unsigned npair = (TU - par) >> 1;
+            const f32x4* src4 = reinterpret_cast<const f32x4*>(img + par);
+            f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + par);
 #pragma unroll
-        for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
-            const unsigned q = q0 + lane;
-            if (q < npair) dst4[q] = src4[q];
+            for (unsigned q0 = 0; q0 < NPMAX; q0 += 64) {
+                const unsigned q = q0 + lane;
+                if (q < npair) dst4[q] = src4[q];
+            }
+            if (((TU - par) & 1u) && lane == 63) out[TU - 1] = img[TU - 1];
+        } else {
+            const unsigned s = (r0 == 0) ? head_units(ee) : 0u;        // first unit this wave stores
+            const unsigned end = TU + ((r0 + RT == N) ? extra_units(ee) : 0u);
+            const unsigned p2 = (par + s) & 1u;                        // 8-byte head to reach 16-byte alignment
+            if (p2 && lane == 0) out[s] = img[s];
+            constexpr unsigned NPMAX = (TU + 16) >> 1;
+            const unsigned npair = (end - s - p2) >> 1;
+            const f32x4* src4 = reinterpret_cast<const f32x4*>(img + s + p2);
+            f32x4* __restrict__ dst4 = reinterpret_cast<f32x4*>(out + s + p2);
+            // The first NFULL store instructions are full whatever s / end are (at most 15 units are skipped): ONE 1 KiB
+            // store per LDS round trip and wave, then 64 idle cycles - no bursts.  Interleaved rounds on several boxes,
+            // 27 x 4096 x 20 steps: 12.8-13.4 us/step against 13.6-14.7 for bursts of five stores (13.3-13.8 without the
+            // pause, 14.3 with twice the pause: profiles/r02_pitch/pacing.txt).  Buffers that live in the Infinity Cache
+            // and batches of many workgroup generations are faster in the plain form (host: launch_roll).
+            constexpr unsigned NFULL = ((TU - 16) >> 1) / 64;
+#pragma unroll
+            for (unsigned c = 0; c < NFULL; ++c) {
+                const f32x4 v = src4[c * 64 + lane];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dst4[c * 64 + lane] = v;
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (unsigned q0 = NFULL * 64; q0 < NPMAX; q0 += 64) {
+                const unsigned q = q0 + lane;
+                if (q < npair) dst4[q] = src4[q];
+            }
+            if (((end - s - p2) & 1u) && lane == 63) out[end - 1] = img[end - 1];
         }
-        if (((end - s - p2) & 1u) && lane == 63) out[end - 1] = img[end - 1];
     };
     if (total > 0) compose(0);
     for (int t = 0; t < total; ++t) {

@@ -27,10 +27,11 @@ __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 *
 
 // Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
 // workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.
-template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY = false>
+template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY = false, bool STREAM = false>
 __global__ __launch_bounds__(TP + TW) __attribute__((amdgpu_waves_per_eu((TP + TW) <= 512 ? 4 : 3)))
 void rollout_kernel(const Args a) {
     // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
+    // STREAM: HBM-streaming form of the LDS-tile writer (fg_obs_writers.hpp)
     // POLICY: closed loop - the action of step k is the demo controller (3-ary hierarchy) on the state step k-1
     //         left, evaluated by the env's own lane group; a.act is not read, a.act_out records the actions
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
@@ -205,10 +206,9 @@ void rollout_kernel(const Args a) {
                     write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                reinterpret_cast<float2*>(a.obs) + unit0, env_units, El, 3);
                 else
-                    write_obs_tiled<NC, NWW, E, WR - 1>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                                        reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
-                                                        reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El,
-                                                        a.line_own != 0);
+                    write_obs_tiled<NC, NWW, E, WR - 1, STREAM>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                                                reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
+                                                                reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
             }
         }
         __syncthreads();

@@ -183,17 +183,16 @@ static int launch_wide(const Args& a, hipStream_t st) {
 }
 
 // N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
-template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY>
-static int launch_roll_v(Args a, hipStream_t st) {
+template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY, bool STREAM = false>
+static int launch_roll_v(const Args& a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
-    a.line_own = a.B < 16384;          // line ownership of the tile writer pays for batches of a few generations only
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
     if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
     if (POLICY) lds += E * policy_block_units(NC) * (int)sizeof(float2);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, POLICY>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, POLICY, STREAM>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR, POLICY>), dim3(grid), dim3(TP + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR, POLICY, STREAM>), dim3(grid), dim3(TP + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
@@ -205,7 +204,13 @@ static int launch_roll(const Args& a, hipStream_t st) {
     // writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.  9 agents: a batch of <= 4096 envs is
     // bound by the producers' dependent chain and wants many small workgroups with the row writer; larger
     // batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
-    if (a.N == 27) return launch_roll_v<27, 32, 512, 256, 16, 10, POLICY>(a, st);
+    if (a.N == 27) {
+        // HBM-streaming form of the tile writer (line ownership + paced stores, fg_obs_writers.hpp): batches of a few
+        // workgroup generations whose rollout buffer does not fit the 256 MiB Infinity Cache; else the plain form
+        const bool stream = a.B < 16384 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+        return stream ? launch_roll_v<27, 32, 512, 256, 16, 10, POLICY, true>(a, st)
+                      : launch_roll_v<27, 32, 512, 256, 16, 10, POLICY, false>(a, st);
+    }
     if (a.N == 9) {
         if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10, POLICY>(a, st);
         if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10, POLICY>(a, st);

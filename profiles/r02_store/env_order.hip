@@ -54,7 +54,7 @@ int main() {
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const char* names[4] = {"blocked", "wg_rr", "wave_rr", "piece_rr"};
     for (int pass = 0; pass < 2; ++pass)
-        for (int nw : {4, 8})
+        for (int nw : {1, 2, 4})
             for (int pitch : {17496, 17536})
                 for (int fill_pad = 0; fill_pad < (pitch == 17496 ? 1 : 2); ++fill_pad)      // 17 536: also write the 40 pad bytes (whole lines)
                 for (int mode = 0; mode < 4; ++mode) {
