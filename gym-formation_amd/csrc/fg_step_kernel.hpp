@@ -204,7 +204,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             // ---- phase 5: observations --------------------------------------
             if (want_obs && !FLAT) {
                 if constexpr (NC > 0)
-                    write_obs_rows<NC, T / 64, E>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
+                    write_obs_rows<NC, T / 64, E, (NC > 64 ? 1 : 0)>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
                                                   reinterpret_cast<real2*>(a.obs) +
                                                   ((size_t)slot * pre_B + b0) * (size_t)a.obs_pitch, (size_t)a.obs_pitch, El, 3);
             } else if (want_obs) {
