@@ -13,8 +13,11 @@
 // the ideal velocity): centroid DIFFERENCES do not depend on whose row they are taken from, and `ezpolicy` never
 // uses the velocity it unpacks (:24).  Here one env is evaluated by a group of lanes:
 //   bottom-up   per-level sums of relative positions and ideal points (each level adds `per` child sums),
-//   top-down    one lane per sub-group runs `ezpolicy` on its group's `per` child sums (registers, PER is a
-//               compile-time constant) and stores the sub-group's target velocity for the next level.
+//   all levels  one lane per (level, sub-group) PROBLEM - N + N/per + ... + per of them, dealt over the lanes in one
+//               flattened pass - runs `ezpolicy` on its group's `per` child sums (registers, PER is a compile-time
+//               constant).  Only the last line of `ezpolicy` depends on the level above (act += w * target velocity,
+//               :43-46), so the pass stores (act, w) and
+//   top-down    a two-instruction combine per level hands the target velocities down (x level, :78-79).
 // The same device function serves the stand-alone launch (`fg_policy_bfs`, tables filled from the observation) and
 // the closed-loop rollout kernels (tables filled from the workgroup's LDS state), so both give the same bits.
 #ifndef FG_POLICY_KERNELS_HPP_
@@ -25,8 +28,10 @@
 namespace fg {
 
 // LDS of one env for the controller, in float2 units:
-//   R[N] relative positions | S[N] ideal shape | SR[N] SS[N] level sums (levels 1 .. L-1 back to back) | TV[2][N]
-__host__ __device__ constexpr int policy_block_units(int n) { return 6 * n; }
+//   R[N] relative positions | S[N] ideal shape | SR[N] SS[N] level sums (levels 1 .. L-1 back to back) |
+//   BA[2N] per problem: act, then in place the sub-group's target velocity (levels top .. leaf back to back; the leaf
+//   level's N entries are the actions) | BW[2N floats] per problem: the weight of the level above (1 or 0.3)
+__host__ __device__ constexpr int policy_block_units(int n) { return 7 * n; }
 
 struct BlockSync { FG_DEV void operator()() const { __syncthreads(); } };
 // the lanes of one env sit in ONE wave: its LDS operations complete in order, only the compiler has to be held back
@@ -44,9 +49,10 @@ struct WaveSync {
 //   marks sorted by distance to me (:35); the first mark whose closest agent (np.argmin: first minimum, me is
 //   LAST, so me wins only strictly) is me, else the last mark of the order (:36-40); act = clip(0.5 (mark - me)) (:39)
 //   done = ||ideal - cur||_F < 0.01 (:42) -> act += ideal_vel (x 0.3 while not done) (:43-46)
+//   Returns act BEFORE the ideal-velocity term and, in `w`, that term's weight.
 template <int PER>
 FG_DEV float2 ez_policy(const float2* __restrict__ cR, const float2* __restrict__ cS, int base, int i,
-                        float inv_sub, float inv_per, float2 tv) {
+                        float inv_sub, float inv_per, float& w) {
     float2 cen[PER], ideal[PER], cur[PER];
     float2 tsum = make_float2(0.f, 0.f);
 #pragma unroll
@@ -106,8 +112,7 @@ FG_DEV float2 ez_policy(const float2* __restrict__ cR, const float2* __restrict_
         const float dx = ideal[s].x - c.x, dy = ideal[s].y - c.y;
         nsq += dx * dx + dy * dy;
     }
-    const float w = (nsq < 1.0e-4f) ? 1.0f : 0.3f;
-    act.x += tv.x * w; act.y += tv.y * w;
+    w = (nsq < 1.0e-4f) ? 1.0f : 0.3f;
     return act;
 }
 
@@ -121,7 +126,6 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     float2* const S = tab + N;
     float2* const SR = tab + 2 * N;
     float2* const SS = tab + 3 * N;
-    float2* const TV = tab + 4 * N;
     // ---- bottom-up: level l holds the sums over per^l consecutive agents ------------
     const float2* srcR = R;
     const float2* srcS = S;
@@ -141,29 +145,38 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
         srcR = SR + off; srcS = SS + off;
         off += n_l;
     }
-    // ---- top-down: level lev solves one `per`-agent problem per sub-group -------------
-    int n_child = PER;                       // sub-groups at the current level = entries of the child level
-    int off_l = off - PER;                   // where the child level (l = lev - 1 >= 1) starts in SR / SS
-    int buf = 0;
+    // ---- every (level, sub-group) problem, flattened: levels top .. leaf back to back -------------------
+    float2* const BA = tab + 4 * N;
+    float* const BW = reinterpret_cast<float*>(tab + 6 * N);
+    int P = 0;
+    for (int lev = pl.L, n = PER; lev >= 1; --lev, n *= PER) P += n;
+    for (int p = lane; p < P; p += lanes) {
+        int lev = pl.L, start = 0, n = PER, off_l = off - PER;   // level of problem p: its first index, its size,
+        while (p >= start + n) {                                  // where its child level starts in SR / SS
+            start += n; n *= PER; off_l -= n; --lev;
+        }
+        const int sg = p - start, l = lev - 1;
+        const int g = sg / PER, i = sg - g * PER;
+        float w;
+        BA[p] = ez_policy<PER>(l ? SR + off_l : R, l ? SS + off_l : S, g * PER, i, pl.inv_sub[l], pl.inv_per, w);
+        BW[p] = w;
+    }
+    sync();
+    // ---- top-down: target velocity of a sub-group = (act + w * target velocity of its group) x level (:43-46, :78-79)
+    int start = 0, n = PER, pstart = 0;
     for (int lev = pl.L; lev >= 1; --lev) {
-        const int l = lev - 1;
-        const float2* cR = l ? SR + off_l : R;
-        const float2* cS = l ? SS + off_l : S;
-        const float2* tvp = TV + buf * N;    // target velocities of this level's groups (the top group: ideal_vel)
-        float2* tvc = TV + (buf ^ 1) * N;
         const float flev = (float)lev;
-        for (int sg = lane; sg < n_child; sg += lanes) {
-            const int g = sg / PER, i = sg - g * PER;
-            const float2 tv = (lev == pl.L) ? iv : tvp[g];
-            const float2 a = ez_policy<PER>(cR, cS, g * PER, i, pl.inv_sub[l], pl.inv_per, tv);
-            tvc[sg] = make_float2(a.x * flev, a.y * flev);                 // :78-79
+        for (int sg = lane; sg < n; sg += lanes) {
+            const float2 tv = (lev == pl.L) ? iv : BA[pstart + sg / PER];
+            float2 a = BA[start + sg];
+            const float w = BW[start + sg];
+            a.x += tv.x * w; a.y += tv.y * w;
+            BA[start + sg] = make_float2(a.x * flev, a.y * flev);
         }
         sync();
-        buf ^= 1;
-        n_child *= PER;
-        off_l -= n_child;                    // the next child level is PER times longer and sits in front
+        pstart = start; start += n; n *= PER;
     }
-    return TV + buf * N;
+    return BA + pstart;                       // the leaf level: N actions
 }
 
 // Stand-alone launch: one env per `lpe` lanes (power of two >= min(N, 256)), tables from observation row 0.

@@ -504,7 +504,7 @@ static int launch_policy_state(int B, int N, const FgPolicyLevels& pl, const flo
     const int lpe = N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 256;      // lanes per env
     const int E = 256 / lpe;
     const int grid = (B + E - 1) / E;
-    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 48 KiB
+    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 56 KiB
 #define FG_POLICY(PER) case PER: hipLaunchKernelGGL((policy_state_kernel<PER>), dim3(grid), dim3(256), lds, st, B, N, lpe, pl, \
                                                    px, py, shape, ivel, act); break;
     switch (pl.per) { FG_POLICY(2) FG_POLICY(3) FG_POLICY(4) FG_POLICY(5) FG_POLICY(6) FG_POLICY(7) FG_POLICY(8) }
@@ -598,7 +598,7 @@ int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env
     const int lpe = N <= 16 ? 16 : N <= 32 ? 32 : N <= 64 ? 64 : 256;      // lanes per env
     const int E = 256 / lpe;
     const int grid = (B + E - 1) / E;
-    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 48 KiB
+    const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 56 KiB
     hipStream_t st = (hipStream_t)stream;
 #define FG_POLICY(PER) case PER: hipLaunchKernelGGL((policy_bfs_kernel<PER>), dim3(grid), dim3(256), lds, st, B, N, lpe, pl, \
                                                    obs, (long long)stride, act); break;
