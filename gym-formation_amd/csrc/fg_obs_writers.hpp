@@ -169,10 +169,9 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     // line ownership: units of the NEXT env (or pad) a wave appends to its env's last tile / skips at its first tile
     constexpr unsigned ENVU = ROWU * N;
     const unsigned pad = (unsigned)(env_units - ENVU);
-    // (27 agents: 1-3.5 % on a good box, 12 % on one whose allocation took partial lines badly, and a steadier rate;
-    //  9 agents, one 1 944-byte tile per env: the extra compose step costs more than the lines save - not applied)
-    // STREAM = the launch streams to HBM (host: < 16 384 envs and a rollout buffer beyond the Infinity Cache): line
+    // STREAM = the launch streams to HBM (host: 27 agents, < 16 384 envs, rollout buffer beyond the Infinity Cache): line
     // ownership here, paced stores in stream().  Ownership alone is worth ~2 % and a steadier rate, the pacing ~8 %.
+    // (9 agents, one 1 944-byte tile per env: the extra compose step costs more than the lines save - plain form.)
     static_assert(!STREAM || (E >= NW && NC >= 16), "streaming form: waves own whole envs, rows of >= 16 units");
     const bool own = STREAM && ((unit0 & 15) == 0) && (pad == 0 || (pad < 16 && (env_units & 15) == 0));
     auto head_units = [&](int ee) -> unsigned {                        // of env ee, owned by the wave of env ee - 1
