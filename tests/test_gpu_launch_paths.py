@@ -60,10 +60,12 @@ def _snapshot(env):
 
 
 @pytest.mark.parametrize("N,B,K", [(27, 4096, 20), (9, 4096, 20), (81, 2048, 20), (243, 8192, 4),
-                                    (9, 5003, 7), (9, 8200, 6), (9, 32768, 4), (27, 16384, 3), (27, 4099, 5)])
+                                    (9, 5003, 7), (9, 8200, 6), (9, 32768, 4), (27, 16384, 3), (27, 4099, 7), (27, 4099, 3)])
 def test_bench_launches_equal_single_steps_and_oracle(N, B, K):
-    # the last five: the batch-size classes that select other instantiations (9 agents: 8- and 16-env workgroups with
-    # the LDS-tile writer above 4096 envs) and batches that are not a multiple of the workgroup's env count
+    # the last six: the batch-size classes that select other instantiations (9 agents: 8- and 16-env workgroups with
+    # the LDS-tile writer above 4096 envs; 27 agents: the plain tile writer from 16 384 envs and for buffers that fit
+    # the Infinity Cache, the HBM-streaming one otherwise) and batches that are not a multiple of the workgroup's env
+    # count (a partial last workgroup, step slots that do not start on a 128-byte line)
     rs = np.random.RandomState(N)
     # episode phases: a third of the envs ends its episode inside the launch (at different steps), the rest does not
     step0 = np.where(np.arange(B) % 3 == 0, 100 - 1 - (np.arange(B) // 3) % K, rs.randint(0, 100 - K, B))
@@ -170,7 +172,8 @@ def _strided_obs(shape_prefix, N, pitch, fill):
     return buf, buf[..., :6 * N * N].view(tuple(shape_prefix) + (N, 6 * N))
 
 
-@pytest.mark.parametrize("N,B,K", [(27, 70, 5), (9, 130, 6), (3, 40, 4), (81, 7, 4), (243, 5, 3), (10, 33, 4), (100, 3, 3)])
+@pytest.mark.parametrize("N,B,K", [(27, 70, 5), (9, 130, 6), (3, 40, 4), (81, 7, 4), (243, 5, 3), (10, 33, 4), (100, 3, 3),
+                                    (27, 4100, 8)])          # the last: large enough for the HBM-streaming tile writer
 def test_padded_observation_env_pitch(N, B, K):
     """FgParams.obs_env_pitch: env blocks on their own 128-byte lines (a strided [B, N, 6N] view).  Every entry point
     that writes observations gives the bits of the contiguous layout, the pad is left alone (rollout launches may
