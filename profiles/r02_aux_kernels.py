@@ -16,9 +16,12 @@ dev = "cuda:0"
 
 
 def timed(fn, reps=200, warm=20):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t_end = time.perf_counter() + 0.15            # bring the clocks up first (short timings are otherwise taken on the ramp)
+    while time.perf_counter() < t_end:
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
