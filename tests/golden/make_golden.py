@@ -340,7 +340,7 @@ def shape_fixture(fg):
     return res
 
 
-def policy_fixture(fg, N, T, seed):
+def policy_fixture(fg, N, T, seed, per=3):
     """ezpolicy / get_action_BFS driven closed loop (reference __init__.py:19-99)."""
     env = fg.make_env("formation_hd_env", False, N)
     env.seed(seed)
@@ -350,7 +350,7 @@ def policy_fixture(fg, N, T, seed):
     rec = {k: [] for k in ("act", "pos", "vel", "shared")}
     obs_first = np.array(obs_n)
     for t in range(T):
-        act_n = fg.get_action_BFS(fg.ezpolicy, obs_n, 3)
+        act_n = fg.get_action_BFS(fg.ezpolicy, obs_n, per)
         rec["act"].append(np.array(act_n, dtype=np.float64))   # before env.step scales it in place
         obs_n, rew_n, done_n, _ = env.step([np.array(a, dtype=np.float64) for a in act_n])
         p, v = _state(env)
@@ -358,7 +358,7 @@ def policy_fixture(fg, N, T, seed):
         rec["shared"].append(rew_n[0][0])
     res = {k: np.array(v) for k, v in rec.items()}
     res.update(pos0=p0, vel0=v0, ideal_shape=np.array(sc.ideal_shape),
-               ideal_vel=np.array(sc.ideal_vel), obs0=obs_first, seed=np.array(seed))
+               ideal_vel=np.array(sc.ideal_vel), obs0=obs_first, seed=np.array(seed), per=np.array(per))
     # single-agent-view ezpolicy known answers on the initial observations
     res["ez_act0"] = np.array([fg.ezpolicy(o) for o in obs_first]) if N == 3 else np.zeros(0)
     return res
@@ -450,6 +450,10 @@ def main():
     save("policy_n9", lambda: policy_fixture(fg, 9, 30, seed=42))
     save("policy_n27", lambda: policy_fixture(fg, 27, 12, seed=43))
     save("policy_n81", lambda: policy_fixture(fg, 81, 4, seed=44))
+    # other hierarchies: test.py -n 2 --num-layer 3, -n 4 --num-layer 2, -n 5 --num-layer 1
+    save("policy_n8_per2", lambda: policy_fixture(fg, 8, 10, seed=45, per=2))
+    save("policy_n16_per4", lambda: policy_fixture(fg, 16, 8, seed=46, per=4))
+    save("policy_n5_per5", lambda: policy_fixture(fg, 5, 10, seed=47, per=5))
     save("benchmark_n9", lambda: benchmark_fixture(fg, 9, 10, seed=91, act_seed=92, crowd=0.12))
     save("hausdorff_kat", lambda: hausdorff_kat())
     # non-default action modes of _set_action (environment.py:187-216)

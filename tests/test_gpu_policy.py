@@ -46,17 +46,20 @@ def _fixture_obs(g):
     return O.observation_hd(pos, vel, shape, ivel), pos, vel
 
 
-@pytest.mark.parametrize("name", ["policy_n3", "policy_n9", "policy_n27", "policy_n81"])
+@pytest.mark.parametrize("name", ["policy_n3", "policy_n9", "policy_n27", "policy_n81",
+                                  "policy_n8_per2", "policy_n16_per4", "policy_n5_per5"])
 def test_policy_kernel_matches_reference_actions(golden, name):
     import formation_gym
-    from formation_gym.policy_bfs import bfs_actions
+    from formation_gym.policy_bfs import bfs_actions as _bfs
     g = golden(name)
+    per = int(g["per"]) if "per" in g else 3
+    bfs_actions = lambda o, p_=None, out=None: _bfs(o, per, out=out)          # the fixture's own hierarchy
     T, N = g["act"].shape[:2]
     obs64, pos, vel = _fixture_obs(g)
-    margins = np.stack([O.bfs_margins(list(obs64[t]), 3) for t in range(T)])
+    margins = np.stack([O.bfs_margins(list(obs64[t]), per) for t in range(T)])
     # (1) the reference's observations rounded to fp32, every recorded step as one env of a batch of T
     obs = torch.as_tensor(obs64.astype(np.float32)).cuda()
-    act = formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3)          # product entry point -> fg_policy_bfs
+    act = formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, per)        # product entry point -> fg_policy_bfs
     assert act.shape == (T, N, 2) and act.dtype == torch.float32 and act.is_cuda
     excused = _check_actions(_np(act), g["act"], margins, name)
     assert excused <= max(1, T * N // 50)                                         # near-ties are rare

@@ -136,7 +136,8 @@ def test_hausdorff_known_answer(golden):
     assert d2 == float(g["d_vu"]) == 3.0
 
 
-@pytest.mark.parametrize("name,per", [("policy_n3", 3), ("policy_n9", 3), ("policy_n27", 3), ("policy_n81", 3)])
+@pytest.mark.parametrize("name,per", [("policy_n3", 3), ("policy_n9", 3), ("policy_n27", 3), ("policy_n81", 3),
+                                      ("policy_n8_per2", 2), ("policy_n16_per4", 4), ("policy_n5_per5", 5)])
 def test_bfs_policy_matches_reference(golden, name, per):
     g = golden(name)
     N = g["pos0"].shape[0]
