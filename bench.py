@@ -415,6 +415,15 @@ def main():
                           "achieved_GBps": round(bytes_per_env_step * B * other_steps / (m2 * 1e-3) / 1e9, 1)}
             if other == "rollout":
                 r["extra"]["chunk"] = chunk
+            if policy:
+                # the demo loop one step at a time in ONE launch per step: fg_rollout_hd_policy with K = 1
+                one = {k2: v[:1] for k2, v in seq.items()}
+                d3, _, _ = timed(lambda n_, s_: [env.rollout_policy(1, 3, out=one) for _ in range(n_)], other_steps, min(warmup, 40))
+                m3 = median(d3)
+                r["extra"]["fused_single_step_launch"] = {
+                    "what": "env.rollout_policy(1): controller + step in one launch per step",
+                    "ms_per_step": round(m3 / other_steps, 5),
+                    "env_steps_per_s": round(world_size * B * other_steps / (m3 * 1e-3), 1)}
         pos, _ = env.world.get_state()
         r["finite"] = bool(torch.isfinite(pos).all())
         del env, act_pool, launchers, seq, out

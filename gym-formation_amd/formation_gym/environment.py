@@ -234,14 +234,34 @@ class MultiAgentEnv(object):
         D = self._out["obs"].shape[-1]
         f = dict(dtype=torch.float32, device=self._act.device)
         want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N), act=(K, B, N, 2))
+        own_buffers = out is not None
         if out is None:
             out = {k: (torch.zeros(shp, dtype=torch.uint8, device=self._act.device) if k == "done"
                        else torch.empty(shp, **f)) for k, shp in want.items()}
-        for k, shp in want.items():
-            if k not in out or tuple(out[k].shape) != shp or not (out[k].is_contiguous() or k == "obs"):
-                raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))       # obs: or a padded env pitch
-        roll(self.world, K, num_agents_per_layer, out, obs_every=obs_every, auto_reset=self.auto_reset,
-             rng_offset=self._rng_offset + 1)
+        # launches into CALLER-OWNED buffers are bound once (cf. rollout): a loop that steps K = 1 at a time pays one
+        # ctypes call per launch
+        bind = getattr(self.scenario, "bind_rollout_policy", None)
+        key = None
+        if own_buffers and bind is not None and all(k in out for k in want):
+            key = ("pol", K, int(num_agents_per_layer), tuple(out[k].data_ptr() for k in sorted(want)), obs_every,
+                   self.auto_reset, _native.current_stream_fast(self.world.device), self.world.params_signature(),
+                   getattr(self.scenario, "_seed", 0))
+        launch = self._roll_launchers.get(key) if key is not None else None
+        if launch is None:
+            for k, shp in want.items():
+                if k not in out or tuple(out[k].shape) != shp or not (out[k].is_contiguous() or k == "obs"):
+                    raise ValueError("out[%r] must be a contiguous tensor of shape %s" % (k, shp))   # obs: or a padded env pitch
+            if key is not None:
+                if len(self._roll_launchers) >= 8:
+                    self._roll_launchers.clear()
+                launch = self._roll_launchers[key] = bind(self.world, K, num_agents_per_layer, out, obs_every=obs_every,
+                                                          auto_reset=self.auto_reset)
+        if launch is not None:
+            launch(self._rng_offset + 1)
+            self.scenario._cache = None
+        else:
+            roll(self.world, K, num_agents_per_layer, out, obs_every=obs_every, auto_reset=self.auto_reset,
+                 rng_offset=self._rng_offset + 1)
         self._rng_offset += K
         self.current_step += K
         self.world.world_step += K

@@ -201,6 +201,28 @@ class Scenario(BaseScenario):
             _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device)))
         self._cache = None
 
+    def bind_rollout_policy(self, world, K, per_layer, out, obs_every=1, auto_reset=False):
+        """`rollout_policy_batch` with every pointer and the FgParams struct resolved once: returns
+        `launch(rng_offset)`, one ctypes call per closed-loop launch."""
+        lib = _native.load()
+        p = self.params(world, auto_reset, 0, out.get("obs"))
+        args = (world.num_envs, len(world.agents), int(K), int(per_layer),
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                out["act"].data_ptr(), self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(),
+                world.step_count.data_ptr(),
+                _native.ptr(out.get("obs")), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), int(obs_every), _native.current_stream(world.device))
+        fn = lib.fg_rollout_hd_policy
+        keep = out
+
+        def launch(rng_offset=0):
+            p.rng_offset = rng_offset
+            rc = fn(p, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        return launch
+
     def policy_actions(self, world, per_layer, out=None):
         """get_action_BFS(ezpolicy, obs, per_layer) for the CURRENT state of every env, straight from the
         simulator state (`fg_policy_bfs_state`): raw actions [B, N, 2]."""

@@ -181,6 +181,16 @@ def test_closed_loop_rollout_equals_policy_plus_step_calls(N, B, K, per):
     for x, y in zip(a.world.get_state(), b.world.get_state()):
         assert torch.equal(x, y)
     assert torch.equal(a.world.step_count, b.world.step_count) and torch.equal(a.scenario.ideal_shape, b.scenario.ideal_shape)
+    # caller-owned buffers (launch bound once per buffer set), one step per launch, continuing the episode
+    f = dict(dtype=torch.float32, device="cuda")
+    bufs = dict(obs=torch.empty((1, B, N, 6 * N), **f), reward=torch.empty((1, B, N), **f), indiv=torch.empty((1, B, N), **f),
+                done=torch.zeros((1, B, N), dtype=torch.uint8, device="cuda"), act=torch.empty((1, B, N, 2), **f))
+    for _ in range(3):
+        o1, r1, d1, i1 = b.rollout_policy(1, per, out=bufs)
+        act = formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, per)
+        obs, rew, done, info = a.step(act)
+        assert torch.equal(i1["actions"][0], act) and torch.equal(o1[0], obs) and torch.equal(r1[0], rew)
+    assert len(b._roll_launchers) == 1
     # obs_every: rewards unchanged, every 2nd observation
     c = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
     c.scenario.seed(17); c.scenario.reset_device(c.world, rng_offset=777)
