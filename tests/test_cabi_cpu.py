@@ -176,3 +176,31 @@ def test_bench_cli_and_cpp_example_build(tmp_path):
                     os.path.join(root, "examples", "c_abi_rollout.cpp"), "-L", lib, "-lformation_hip",
                     "-Wl,-rpath," + lib, "-o", exe], check=True, capture_output=True, timeout=600)
     assert os.path.getsize(exe) > 0
+
+
+def test_observation_pitch_detection_is_host_logic():
+    """Scenario.obs_env_pitch: which observation tensors the kernels can be told about (contiguous -> 0, a uniform even
+    env pitch >= 6 N^2 -> that pitch, anything else refused).  Pure stride arithmetic: runs on CPU tensors."""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location(
+        "fg_hd_scn", os.path.join(ROOT, "gym-formation_amd", "formation_gym", "envs", "formation_hd_env.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pitch_of = mod.Scenario.obs_env_pitch
+    N, B, K = 9, 5, 3
+    D = 6 * N
+    assert pitch_of(None, N) == 0
+    assert pitch_of(torch.zeros((B, N, D)), N) == 0 and pitch_of(torch.zeros((K, B, N, D)), N) == 0
+    padded = torch.zeros((B, N * D + 26))[:, :N * D].view(B, N, D)
+    assert pitch_of(padded, N) == N * D + 26
+    padded4 = torch.zeros((K, B, N * D + 32))[:, :, :N * D].view(K, B, N, D)
+    assert pitch_of(padded4, N) == N * D + 32
+    assert pitch_of(padded4[:2], N) == N * D + 32                           # a leading slice keeps the slot stride
+    assert pitch_of(torch.zeros((2 * B, N, D))[::2], N) == 2 * N * D        # every other env: a uniform pitch of 2 blocks
+    for bad in (torch.zeros((B, N * D + 1))[:, :N * D].view(B, N, D),     # odd pitch
+                torch.zeros((B, N, D + 2))[:, :, :D],                     # padded ROWS
+                torch.zeros((K, 2 * B, N, D))[:, ::2][:, :, :, :],         # every other env of 2 B: slots are 2 B pitches apart
+                torch.zeros((2 * K, B, N * D + 32))[::2, :, :N * D].view(K, B, N, D)):   # step slots not B pitches apart
+        with pytest.raises(ValueError):
+            pitch_of(bad, N)
