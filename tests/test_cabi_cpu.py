@@ -200,7 +200,6 @@ def test_observation_pitch_detection_is_host_logic():
     assert pitch_of(torch.zeros((2 * B, N, D))[::2], N) == 2 * N * D        # every other env: a uniform pitch of 2 blocks
     for bad in (torch.zeros((B, N * D + 1))[:, :N * D].view(B, N, D),     # odd pitch
                 torch.zeros((B, N, D + 2))[:, :, :D],                     # padded ROWS
-                torch.zeros((K, 2 * B, N, D))[:, ::2][:, :, :, :],         # every other env of 2 B: slots are 2 B pitches apart
                 torch.zeros((2 * K, B, N * D + 32))[::2, :, :N * D].view(K, B, N, D)):   # step slots not B pitches apart
         with pytest.raises(ValueError):
             pitch_of(bad, N)
