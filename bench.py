@@ -222,6 +222,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = max(1, torch.cuda.device_count())
+    gpu_share = max(1, -(-world_size // ndev))                   # ranks per GPU (1 on a real multi-GPU node)
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     # The only communication of this benchmark is the timing barrier and a MAX (no data-path
@@ -302,7 +303,8 @@ def main():
         env.world.step_count.zero_()
 
         # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
-        chunk = max(1, min(chunk_req, int(48e9 // max(1, B * N * 6 * N * 4)) or 1))
+        # (ranks that SHARE a GPU - a rehearsal of N ranks on one device - share its memory too)
+        chunk = max(1, min(chunk_req, int(48e9 / gpu_share // max(1, B * N * 6 * N * 4)) or 1))
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
         out = env._out
@@ -482,7 +484,7 @@ def main():
         # world_size contiguous slices (strong scaling: the global batch is fixed, each rank owns 1/world_size)
         for n2, g2, st2 in ((81, 16384 // a.global_div, 40), (243, 65536 // a.global_div, 8)):
             per_gpu = g2 // world_size
-            if per_gpu * n2 * 6 * n2 * 4 > 150e9:                 # the observation buffer of ONE step must fit beside the rest
+            if per_gpu * n2 * 6 * n2 * 4 > 150e9 / gpu_share:     # the observation buffer of ONE step must fit beside the rest
                 global_cfgs.append({"workload": "formation_hd_env, %d agents x %d envs GLOBAL" % (n2, g2),
                                     "skipped": "a slice of %d envs per GPU needs %.0f GB of observations per step"
                                                % (per_gpu, per_gpu * n2 * 6 * n2 * 4 / 1e9)})
