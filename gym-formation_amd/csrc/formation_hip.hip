@@ -23,8 +23,9 @@
 //
 // Source layout: fg_common.hpp (arguments, LDS layout, reductions, RNG, World options),
 // fg_pair_loops.hpp, fg_obs_writers.hpp, fg_step_kernel.hpp, fg_rollout_kernels.hpp,
-// fg_aux_kernels.hpp (resets, landmark scenarios); this file holds the host side: variant
-// tables, dispatch and the extern "C" entry points.
+// fg_policy_kernels.hpp (the reference's demo controller), fg_aux_kernels.hpp (resets, landmark
+// scenarios); this file holds the host side: variant tables, dispatch and the extern "C" entry
+// points.  formation_hip_f64.hip builds the step kernel's source in double (tests only).
 
 #include <atomic>
 #include <cstdlib>
