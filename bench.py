@@ -575,6 +575,14 @@ def main():
             res["config1"] = c1
         if world_size == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(N)
+            if others:
+                # the per-env port beside the other agent counts too (short samples; N = 243 costs ~1 s per
+                # env-step and core, so it gets its minimum of 3 steps per process)
+                res["cpu_baseline_other_shapes"] = []
+                for n2 in (9, 81, 243):
+                    cb = cpu_baseline(n2, budget_s=4.0)
+                    res["cpu_baseline_other_shapes"].append({k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "agent_steps_per_s")}
+                                                            | {"agents": n2})
         print(json.dumps(res), flush=True)
     if world_size > 1:
         dist.barrier()
