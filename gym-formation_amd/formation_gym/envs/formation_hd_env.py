@@ -120,12 +120,22 @@ class Scenario(BaseScenario):
             return 0
         D = 6 * N
         ok = obs.dim() in (3, 4) and obs.stride(-1) == 1 and obs.stride(-2) == D and obs.shape[-2:] == (N, D)
-        pitch = obs.stride(-3) if ok else 0
-        if ok and obs.dim() == 4 and obs.shape[0] > 1:
-            ok = obs.stride(0) == obs.shape[1] * pitch
+        B = obs.shape[-3] if ok else 0
+        slots = obs.shape[0] if ok and obs.dim() == 4 else 1
+        # a dimension of size 1 has no meaningful stride: the pitch is read from whichever of (env, step slot) moves
+        if ok and B > 1:
+            pitch = obs.stride(-3)
+            if slots > 1:
+                ok = obs.stride(0) == B * pitch
+        elif ok and slots > 1:
+            pitch = obs.stride(0)                    # one env per slot: slots are one pitch apart
+        else:
+            pitch = N * D
         if not ok or pitch < N * D or pitch % 2:
             raise ValueError("observation tensor must be [.., B, N, 6N] with dense rows and a uniform even env pitch "
                              ">= 6 N^2 floats; got shape %s strides %s" % (tuple(obs.shape), tuple(obs.stride())))
+        if pitch == N * D:
+            return 0
         return int(pitch)
 
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):

@@ -198,6 +198,9 @@ def test_observation_pitch_detection_is_host_logic():
     assert pitch_of(padded4, N) == N * D + 32
     assert pitch_of(padded4[:2], N) == N * D + 32                           # a leading slice keeps the slot stride
     assert pitch_of(torch.zeros((2 * B, N, D))[::2], N) == 2 * N * D        # every other env: a uniform pitch of 2 blocks
+    one = torch.zeros((K, 1, N * D + 32))[:, :, :N * D].view(K, 1, N, D)    # B = 1: the size-1 env axis has no stride of
+    assert pitch_of(one, N) == N * D + 32                                   # its own, the slot stride IS the pitch
+    assert pitch_of(torch.zeros((1, N * D + 32))[:, :N * D].view(1, N, D), N) == 0 and pitch_of(one[:1], N) == 0
     for bad in (torch.zeros((B, N * D + 1))[:, :N * D].view(B, N, D),     # odd pitch
                 torch.zeros((B, N, D + 2))[:, :, :D],                     # padded ROWS
                 torch.zeros((2 * K, B, N * D + 32))[::2, :, :N * D].view(K, B, N, D)):   # step slots not B pitches apart
