@@ -100,6 +100,10 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
                                        &launch_v<NC, G, T, E, true, false>, &launch_v<NC, G, T, E, true, true>}
 #define FG_VARIANT_BIG(NC, G, T, E, MINB) {NC, G, T, E, MINB, &launch_v<NC, G, T, E, false, false>, nullptr, nullptr}
 
+#ifndef FG_WIDE243_MIN_B
+#define FG_WIDE243_MIN_B 4096      // single-step launches at 243 agents: below this the pipelined kernel's 4-env batches leave CUs
+                                   // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
+#endif
 static const Variant kVariants[] = {
     FG_VARIANT(3, 4, 128, 16, 0),
     FG_VARIANT(9, 16, 128, 4, 0), FG_VARIANT_BIG(9, 16, 128, 8, 16384),
@@ -294,10 +298,10 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
-    // 243 agents: pipeline over env batches inside the launch (no index outputs, no World options):
+    // 243 agents, >= 4096 envs: pipeline over env batches inside the launch (no index outputs, no World options):
     // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192.  At 81 agents the plain kernel is as fast or faster
     // (74 vs 80 us at 81 x 2048 on the same box, profiles/README.md).
-    if (N == 243 && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
+    if (N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
         return launch_wide(a, (hipStream_t)stream);
     return launch_step(a, (hipStream_t)stream);
 }
@@ -373,7 +377,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
     // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
-    if (K == 1 && N == 243 && !world_options_set(a.p)) return launch_wide(a, (hipStream_t)stream);   // as fg_step_hd
+    if (K == 1 && N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p)) return launch_wide(a, (hipStream_t)stream);   // as fg_step_hd
     if (K >= 2 && !world_options_set(a.p)) {
         if (N == 81 || N == 243) return launch_wide(a, (hipStream_t)stream);
         if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);
