@@ -22,7 +22,7 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
     const int b = blockIdx.x * E + e;
     const bool valid = (b < a.B) && (i < N);
     const bool mine = valid && (mask == nullptr || mask[b] != 0);
-    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)rng_base(a.p), (uint32_t)(rng_base(a.p) >> 32)};
     philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
     float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
     const float rx = raw[0], ry = raw[1];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
         a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
         reinterpret_cast<float2*>(a.shape)[sidx] = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));
         if (i == 0) {
-            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)a.p.rng_offset, (uint32_t)(a.p.rng_offset >> 32)};
+            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)rng_base(a.p), (uint32_t)(rng_base(a.p) >> 32)};
             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
             reinterpret_cast<float2*>(a.ivel)[b] = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
             if (a.step) a.step[b] = 0;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             }
             if (is_agent) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
-                const float2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, a.p.rng_offset);
+                const float2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p));
                 fx += fa.x; fy += fa.y;
             }
             if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);

@@ -72,10 +72,13 @@ struct KParams {
     int32_t num_walls;
     FgWall walls[FG_MAX_WALLS];
     int32_t obs_env_pitch, env_index_base;
+    const uint64_t* rng_offset_dev;
 };
 #else
 typedef FgParams KParams;
 #endif
+// per-launch offset of the counter RNG: by-value part + the caller's optional device counter (FgParams.rng_offset_dev)
+FG_DEV uint64_t rng_base(const KParams& p) { return p.rng_offset + (p.rng_offset_dev ? *p.rng_offset_dev : 0ull); }
 
 // LDS block of one environment, in floats:
 //   float2 tables  A[3N] = post pos[N] | zeros[N-1] | ideal_shape[N] | ideal_vel[1],  V[N],  NV[N] = -V

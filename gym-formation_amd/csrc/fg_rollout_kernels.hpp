@@ -151,14 +151,14 @@ void rollout_kernel(const Args a) {
         if (a.p.auto_reset) {
             const bool mine = is_done && env_ok;
             if (__any(mine) != 0) {
-                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
-                                 (uint32_t)((a.p.rng_offset + k) >> 32)};
+                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(rng_base(a.p) + k),
+                                 (uint32_t)((rng_base(a.p) + k) >> 32)};
                 philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                 float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
                 const float rx = raw[0], ry = raw[1];
                 env_reduce<G, G, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, nullptr);
-                uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
-                                  (uint32_t)((a.p.rng_offset + k) >> 32)};
+                uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rng_base(a.p) + k),
+                                  (uint32_t)((rng_base(a.p) + k) >> 32)};
                 philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                 if (mine) {
                     iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             uint32_t c0[A], c1[A];
 #pragma unroll
             for (int q = 0; q < A; ++q) {
-                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)(lane + 64 * q), (uint32_t)(a.p.rng_offset + k),
-                                 (uint32_t)((a.p.rng_offset + k) >> 32)};
+                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)(lane + 64 * q), (uint32_t)(rng_base(a.p) + k),
+                                 (uint32_t)((rng_base(a.p) + k) >> 32)};
                 philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                 c0[q] = c[0]; c1[q] = c[1];
                 rx[q] = valid[q] ? u_pm1(c[2]) : 0.f; ry[q] = valid[q] ? u_pm1(c[3]) : 0.f;
@@ -449,8 +449,8 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 env_reduce<64, 64, 2, R_SUM, R_SUM, R_SUM, R_SUM>(rawp[q], nullptr);
                 if (q == 0) { raw[0] = rawp[0][0]; raw[1] = rawp[0][1]; } else { raw[0] += rawp[q][0]; raw[1] += rawp[q][1]; }
             }
-            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
-                              (uint32_t)((a.p.rng_offset + k) >> 32)};
+            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rng_base(a.p) + k),
+                              (uint32_t)((rng_base(a.p) + k) >> 32)};
             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
             iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
             t_step = 0;

@@ -99,7 +99,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 real2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
-                    const real2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, a.p.rng_offset + k);
+                    const real2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p) + k);
                     f.x += fa.x; f.y += fa.y;
                     if (a.p.num_walls > 0) wall_forces(a.p, p, 0.5f * a.p.dist_min, f.x, f.y);
                 } else {
@@ -173,8 +173,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             if (a.p.auto_reset && reset_flag[k & 1] != 0) {          // workgroup-uniform
                 const bool mine = is_done && env_ok;
                 if (G > 64 ? mine : (__any(mine) != 0)) {
-                    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(a.p.rng_offset + k),
-                                     (uint32_t)((a.p.rng_offset + k) >> 32)};
+                    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(rng_base(a.p) + k),
+                                     (uint32_t)((rng_base(a.p) + k) >> 32)};
                     philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                     real raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
                     const real rx = raw[0], ry = raw[1];
@@ -187,8 +187,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
                         reinterpret_cast<real2*>(a.shape)[sidx] = s;
                         if (i == 0) {
-                            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(a.p.rng_offset + k),
-                                              (uint32_t)((a.p.rng_offset + k) >> 32)};
+                            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rng_base(a.p) + k),
+                                              (uint32_t)((rng_base(a.p) + k) >> 32)};
                             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                             const real2 niv = make_real2(u_pm1(c2[0]), u_pm1(c2[1]));
                             A[3 * N - 1] = niv;

@@ -14,7 +14,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_WALLS = 4
 
 FG_OK = 0
@@ -52,6 +52,7 @@ class FgParams(ctypes.Structure):
         ("walls", FgWall * 4),
         ("obs_env_pitch", ctypes.c_int32),
         ("env_index_base", ctypes.c_int32),
+        ("rng_offset_dev", ctypes.c_void_p),
     ]
 
 

@@ -182,6 +182,7 @@ class World(object):
         self.cache_dists = False
         self.world_length = world_length
         self.world_step = 0
+        self.rng_counter = None          # device int64 [1]: see MultiAgentEnv.use_device_rng_counter
         self.num_agents = 0
         self.num_landmarks = 0
         # batched extension
@@ -240,12 +241,16 @@ class World(object):
             l.state = EntityState(self, "landmark", i) if i < L else EntityState(self, "obstacle", i - L)
 
     def set_state(self, pos=None, vel=None):
-        """Upload [B,N,2] positions / velocities (any array-like) into the SoA tensors."""
+        """Upload [B,N,2] positions / velocities (any array-like, or a tensor on any device) into the SoA tensors."""
+        def as_dev(x):
+            if not torch.is_tensor(x):
+                x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
+            return x.to(device=self.device, dtype=torch.float32)
         if pos is not None:
-            pos = torch.as_tensor(np.asarray(pos), dtype=torch.float32).to(self.device)
+            pos = as_dev(pos)
             self.pos_x.copy_(pos[..., 0]); self.pos_y.copy_(pos[..., 1])
         if vel is not None:
-            vel = torch.as_tensor(np.asarray(vel), dtype=torch.float32).to(self.device)
+            vel = as_dev(vel)
             self.vel_x.copy_(vel[..., 0]); self.vel_y.copy_(vel[..., 1])
 
     def get_state(self):
@@ -280,6 +285,9 @@ class World(object):
             seed=int(seed), rng_offset=int(rng_offset),
             accel=float(a0.accel or 0.0), max_speed=float(a0.max_speed or 0.0),
             u_noise=float(a0.u_noise or 0.0), num_walls=len(self.walls))
+        counter = self.rng_counter               # MultiAgentEnv.use_device_rng_counter
+        if counter is not None:
+            p.rng_offset_dev = counter.data_ptr()
         for k, w in enumerate(self.walls):
             p.walls[k] = _native.FgWall(vertical=0 if w.orient == "H" else 1, axis_pos=float(w.axis_pos),
                                         end0=float(w.endpoints[0]), end1=float(w.endpoints[1]),
@@ -292,6 +300,7 @@ class World(object):
         a0 = self.agents[0]
         return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
                 len(self.agents), a0.size, a0.initial_mass, a0.accel, a0.max_speed, a0.u_noise,
+                None if self.rng_counter is None else self.rng_counter.data_ptr(),
                 tuple((w.orient, float(w.axis_pos), float(w.endpoints[0]), float(w.endpoints[1]), float(w.width), w.hard)
                       for w in self.walls))
 

@@ -138,10 +138,10 @@ class MultiAgentEnv(object):
                 act = self._act
         else:
             act = self._stage_reference_actions(action_n)
-        self._rng_offset += 1
-        if not self._bound_step(act):
-            self.scenario.step_batch(self.world, act, self._out, auto_reset=self.auto_reset,
-                                     rng_offset=self._rng_offset)
+        off = self._launch_rng_offset()
+        if not self._bound_step(act, off):
+            self.scenario.step_batch(self.world, act, self._out, auto_reset=self.auto_reset, rng_offset=off)
+        self._advance_rng(1)
         self.world.world_step += 1
         if self.post_step_callback is not None:
             self.post_step_callback(self.world)
@@ -204,11 +204,11 @@ class MultiAgentEnv(object):
                 launch = self._roll_launchers[key] = bind(self.world, act, out, obs_every=obs_every,
                                                           auto_reset=self.auto_reset)
         if launch is not None:
-            launch(self._rng_offset + 1)
+            launch(self._launch_rng_offset())
             self.scenario._cache = None
         else:
-            roll(self.world, act, out, obs_every=obs_every, auto_reset=self.auto_reset, rng_offset=self._rng_offset + 1)
-        self._rng_offset += K
+            roll(self.world, act, out, obs_every=obs_every, auto_reset=self.auto_reset, rng_offset=self._launch_rng_offset())
+        self._advance_rng(K)
         self.current_step += K
         self.world.world_step += K
         rew = out["reward"] if self.shared_reward else out["indiv"]
@@ -257,19 +257,43 @@ class MultiAgentEnv(object):
                 launch = self._roll_launchers[key] = bind(self.world, K, num_agents_per_layer, out, obs_every=obs_every,
                                                           auto_reset=self.auto_reset)
         if launch is not None:
-            launch(self._rng_offset + 1)
+            launch(self._launch_rng_offset())
             self.scenario._cache = None
         else:
             roll(self.world, K, num_agents_per_layer, out, obs_every=obs_every, auto_reset=self.auto_reset,
-                 rng_offset=self._rng_offset + 1)
-        self._rng_offset += K
+                 rng_offset=self._launch_rng_offset())
+        self._advance_rng(K)
         self.current_step += K
         self.world.world_step += K
         rew = out["reward"] if self.shared_reward else out["indiv"]
         return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), \
             {"individual_reward": out["indiv"], "actions": out["act"]}
 
-    def _bound_step(self, act):
+    def use_device_rng_counter(self, on=True):
+        """Keep the per-step offset of the device counter RNG (auto-reset draws, motor noise) in DEVICE memory
+        (`FgParams.rng_offset_dev`) and advance it with a device-side add after every launch, instead of passing it
+        by value.  Needed when the step loop is captured in a hipGraph (torch.cuda.CUDAGraph) with auto-reset on: by-value
+        launch arguments are frozen at capture, so every replay would repeat the same reset draws.  The draws are the
+        same in both modes (a captured loop, replayed, equals the loop run launch by launch)."""
+        if on and self.world.rng_counter is None:
+            self.world.rng_counter = torch.full((1,), int(self._rng_offset), dtype=torch.int64, device=self.world.device)
+        elif not on and self.world.rng_counter is not None:
+            self._rng_offset = int(self.world.rng_counter.item())
+            self.world.rng_counter = None
+        self._launchers.clear()
+        self._roll_launchers.clear()
+
+    def _launch_rng_offset(self):
+        """By-value offset of the next launch's first step: steps taken so far + 1; with the device counter that
+        count lives on the device and the by-value part is the constant 1."""
+        return 1 if self.world.rng_counter is not None else self._rng_offset + 1
+
+    def _advance_rng(self, K):
+        self._rng_offset += K
+        if self.world.rng_counter is not None:
+            self.world.rng_counter.add_(K)             # stream-ordered after the launch that read it
+
+    def _bound_step(self, act, rng_offset):
         """Per-step host work kept to one ctypes call: the scenario resolves every pointer and the
         FgParams struct once (`bind_step`), keyed by everything the binding depends on - action
         buffer, output buffers, stream, auto-reset flag and the world's physics constants - so a
@@ -286,7 +310,7 @@ class MultiAgentEnv(object):
             if len(self._launchers) >= 64:
                 self._launchers.clear()
             launch = self._launchers[key] = bind(self.world, act, self._out, auto_reset=self.auto_reset)
-        launch(self._rng_offset)
+        launch(rng_offset)
         self.scenario._cache = self._out
         return True
 

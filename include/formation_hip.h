@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 4
+#define FG_ABI_VERSION 5
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -113,6 +113,10 @@ typedef struct FgParams {
     int32_t env_index_base;  /* GLOBAL index of this batch's env 0 (a rank's slice of a sharded batch): the device
                                 counter RNG (auto-reset, fg_reset_hd, motor noise) is keyed by seed and GLOBAL env index,
                                 so its draws do not depend on how the batch is cut over GPUs */
+    const uint64_t* rng_offset_dev;  /* optional DEVICE counter added to rng_offset when the launch runs (NULL = none): a
+                                caller that replays a captured hipGraph keeps its per-step offset here and advances it
+                                with a device-side add between launches, since by-value arguments are frozen in a graph.
+                                The library only reads it. */
 } FgParams;
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:

@@ -52,7 +52,7 @@ class Env64(object):
         self.vx = torch.as_tensor(np.ascontiguousarray(vel[..., 0]), **f)
         self.vy = torch.as_tensor(np.ascontiguousarray(vel[..., 1]), **f)
         self.shape = torch.as_tensor(np.array(np.broadcast_to(ideal_shape, (B, N, 2))), **f)
-        self.ivel = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(ideal_vel, (B, 2))), **f)
+        self.ivel = torch.as_tensor(np.array(np.broadcast_to(ideal_vel, (B, 2))), **f)
         self.step_count = torch.as_tensor(np.zeros(B, dtype=np.int32) if step is None else np.asarray(step, dtype=np.int32)).cuda()
         self.obs = torch.empty((B, N, 6 * N), **f)
         self.reward = torch.empty((B, N), **f)

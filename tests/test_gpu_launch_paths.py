@@ -219,3 +219,125 @@ def test_padded_observation_env_pitch(N, B, K):
     p.obs_env_pitch = 6 * N * N - 2
     assert _native.load().fg_observe_hd(p, B, N, *([b.world.pos_x.data_ptr()] * 7), view.data_ptr(), *([None] * 7)) \
         == _native.FG_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("N,B", [(27, 256), (9, 1000), (81, 64), (16, 100)])
+def test_step_loop_can_be_captured_in_a_hip_graph(N, B):
+    """A caller with a device-side policy between the steps (here a fixed linear map of the observation, torch ops)
+    can capture the whole loop - policy, fg_step_hd, the built-in controller fg_policy_bfs - in a hipGraph and replay
+    it: the library only enqueues kernels on the caller's stream (no allocation, no synchronisation, no host read-back).
+    The replay must give what the same loop gives launch by launch.  Auto-reset is off inside the graph: `rng_offset`
+    is a by-value launch argument, so a replayed graph would repeat its reset draws."""
+    import formation_gym
+    T = 6
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev); gen.manual_seed(N)
+    W = (torch.rand((6 * N, 2), generator=gen, device=dev) - 0.5) * 0.2
+    per = 3 if N in (9, 27, 81) else 4
+
+    def loop(env, obs, rec):
+        for t in range(T):
+            act = torch.tanh(obs @ W) if t % 2 == 0 else formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, per)
+            obs, rew, done, info = env.step(act.contiguous())
+            rec["obs"][t].copy_(obs); rec["rew"][t].copy_(rew); rec["ind"][t].copy_(info["individual_reward"])
+
+    def fresh():
+        env = _make(N, B)
+        env.seed(4); env.reset()
+        env.auto_reset = False
+        rec = dict(obs=torch.zeros((T, B, N, 6 * N), device=dev), rew=torch.zeros((T, B, N, 1), device=dev),
+                   ind=torch.zeros((T, B, N), device=dev))
+        return env, rec
+
+    eager, rec_e = fresh()
+    loop(eager, eager._out["obs"], rec_e)
+
+    env, rec_g = fresh()
+    state0 = [x.clone() for x in env.world.get_state()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up on the capture stream (binds launchers, raises LDS limits)
+        loop(env, env._out["obs"], rec_g)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        loop(env, env._out["obs"], rec_g)
+    for replay in range(2):                               # the state the graph starts from is restored by the caller
+        env.world.set_state(*state0)
+        env.world.step_count.zero_()
+        env.scenario.observe_batch(env.world, env._out)
+        for v in rec_g.values():
+            v.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in rec_e:
+            assert torch.equal(rec_e[k], rec_g[k]), "graph replay %d differs from the launch-by-launch loop in %s" % (replay, k)
+    for x, y in zip(eager.world.get_state(), env.world.get_state()):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("N,B", [(27, 300), (9, 64)])
+def test_captured_loop_with_auto_reset_uses_the_device_rng_counter(N, B):
+    """Auto-reset inside a replayed hipGraph: the per-step offset of the counter RNG is read from device memory
+    (FgParams.rng_offset_dev) and advanced by a device-side add the graph contains, so every replay draws NEW reset
+    states - exactly those of the same number of steps taken launch by launch (with or without the device counter)."""
+    T, R = 5, 3                                           # steps per graph, replays
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    acts = torch.rand((T, B, N, 2), generator=gen, device=dev) * 2 - 1
+
+    def fresh(counter):
+        env = _make(N, B)
+        env.seed(9); env.reset()
+        env.auto_reset = True
+        env.world.world_length = 3                         # short episodes: every env restarts in every replay
+        env.world.step_count.copy_(torch.arange(B, dtype=torch.int32, device=dev) % 3)
+        if counter:
+            env.use_device_rng_counter()
+        return env
+
+    def loop(env, rec, base):
+        for t in range(T):
+            obs, rew, done, info = env.step(acts[t])
+            rec["obs"][base + t].copy_(obs); rec["done"][base + t].copy_(done)
+
+    def rec():
+        return dict(obs=torch.zeros((T * (R + 1), B, N, 6 * N), device=dev), done=torch.zeros((T * (R + 1), B, N), dtype=torch.bool, device=dev))
+
+    plain, rec_p = fresh(False), rec()                    # by-value offsets, launch by launch
+    for r in range(R + 1):
+        loop(plain, rec_p, r * T)
+    eager, rec_e = fresh(True), rec()                     # device counter, launch by launch
+    for r in range(R + 1):
+        loop(eager, rec_e, r * T)
+    assert torch.equal(rec_p["obs"], rec_e["obs"]) and torch.equal(rec_p["done"], rec_e["done"])
+    assert int(eager.world.rng_counter.item()) == T * (R + 1)
+
+    env, rec_g = fresh(True), rec()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                         # warm-up on the capture stream = the first T steps
+        loop(env, rec_g, 0)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    scratch = rec()
+    graph = torch.cuda.CUDAGraph()
+    state = [x.clone() for x in (env.world.pos_x, env.world.pos_y, env.world.vel_x, env.world.vel_y, env.world.step_count,
+                                 env.scenario.ideal_shape, env.scenario.ideal_vel, env.world.rng_counter)]
+    with torch.cuda.graph(graph, stream=side):
+        loop(env, scratch, 0)
+    for dst, src in zip((env.world.pos_x, env.world.pos_y, env.world.vel_x, env.world.vel_y, env.world.step_count,
+                         env.scenario.ideal_shape, env.scenario.ideal_vel, env.world.rng_counter), state):
+        dst.copy_(src)                                    # capture does not execute, but be explicit about the start state
+    for r in range(1, R + 1):
+        graph.replay()
+        torch.cuda.synchronize()
+        rec_g["obs"][r * T:(r + 1) * T].copy_(scratch["obs"][:T]); rec_g["done"][r * T:(r + 1) * T].copy_(scratch["done"][:T])
+    assert torch.equal(rec_g["done"], rec_p["done"])
+    assert torch.equal(rec_g["obs"], rec_p["obs"])
+    for r in range(R + 1):                                               # every env restarted in every block of T steps,
+        assert bool(rec_p["done"][r * T:(r + 1) * T, :, 0].any(0).all())
+    blocks = rec_p["obs"].view(R + 1, T, B, N, 6 * N)
+    assert not torch.equal(blocks[1], blocks[2])                         # ... with different draws from block to block
+    assert int(env.world.rng_counter.item()) == T * (R + 1)
