@@ -94,7 +94,7 @@ class Scenario(BaseScenario):
     def set_formation(self, world, ideal_shape=None, ideal_vel=None):
         """Upload explicit ideal shapes [B,N,2] / velocities [B,2] (parity tests, curricula)."""
         if ideal_shape is not None:
-            self.ideal_shape.copy_(torch.as_tensor(np.asarray(ideal_shape), dtype=torch.float32))
+            self.ideal_shape.copy_(torch.as_tensor(np.array(ideal_shape), dtype=torch.float32))
         if ideal_vel is not None:
             self.ideal_vel.copy_(torch.as_tensor(np.asarray(ideal_vel), dtype=torch.float32))
         self._cache = None
