@@ -130,10 +130,10 @@ __global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8
 }
 
 // ---------------------------------------------------------------------------
-// Landmark scenarios with few agents (N + M <= 64): basic_formation_env (BASELINE config 1),
+// Landmark scenarios (N + M <= 1024 movable entities): basic_formation_env (BASELINE config 1),
 // formation_hd_partial_env, formation_hd_partial_range_env, formation_hd_obs_env.
 // One lane per movable entity (N agents, then M obstacles), one env per aligned group of G
-// lanes of a wave.  Reference lines under formation_gym/envs/:
+// lanes of a wave (N + M <= 64) or per workgroup of G threads (beyond).  Reference lines under formation_gym/envs/:
 //   basic     observation basic_formation_env.py:29-41, reward :43-52 (self "collision" included)
 //   partial   observation formation_hd_partial_env.py:38-57 (ring neighbours), reward :59-72
 //   range     observation formation_hd_partial_range_env.py:38-52 (clipped), reward as partial
@@ -162,7 +162,10 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     const bool live = b < a.B;
     const bool is_agent = live && i < N;
     const bool is_obst = live && i >= N && i < NE;
-    float2* const PRE = smem + e * (2 * NE + L);
+    constexpr int SCR = (G > 64) ? 32 : 0;            // G > 64 (one env per workgroup): cross-wave partials of env_reduce
+    float* const scratch = reinterpret_cast<float*>(smem);
+    float2* const tables = smem + SCR;
+    float2* const PRE = tables + e * (2 * NE + L);
     float2* const POST = PRE + NE;
     float2* const LM = POST + NE;
     float2 p = make_float2(0.f, 0.f), v = p;
@@ -223,7 +226,6 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         t_step += 1;
         __syncthreads();
     }
-    float scratch_dummy[1];
     // ---- formation term ----
     float form = 0.f;      // basic: sum_l min_a |p_a - l| ; others: Hausdorff(centred agents, centred landmarks)
     if (kind == FG_SCN_BASIC) {
@@ -243,12 +245,12 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             }
         }
         float red[1] = {cover};
-        env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch_dummy);
+        env_reduce<G, T, 1, R_SUM, R_SUM, R_SUM, R_SUM>(red, scratch);
         form = red[0];
     } else {
         float s4[4] = {is_agent ? p.x : 0.f, is_agent ? p.y : 0.f, 0.f, 0.f};
         for (int l = i; live && l < L; l += G) { s4[2] += LM[l].x; s4[3] += LM[l].y; }
-        env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(s4, scratch_dummy);
+        env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(s4, scratch);
         const float mx = s4[0] / (float)N, my = s4[1] / (float)N;
         const float lx = s4[2] / (float)L, ly = s4[3] / (float)L;
         float rowmin = -INFINITY, colmax = -INFINITY;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             colmax = fmaxf(colmax, cm);
         }
         float red[2] = {rowmin, colmax};
-        env_reduce<G, G, 2, R_MAX, R_MAX, R_MAX, R_MAX>(red, scratch_dummy);
+        env_reduce<G, T, 2, R_MAX, R_MAX, R_MAX, R_MAX>(red, scratch);
         form = sqrtf(fmaxf(red[0], red[1]));
     }
     // ---- collision counts ----
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         }
     }
     float cs[1] = {(float)cnt};
-    env_reduce<G, G, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch_dummy);
+    env_reduce<G, T, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch);
     const bool is_done = t_step >= a.p.world_length;
     // ---- outputs ----
     const int nbr = (kind == FG_SCN_PARTIAL) ? a.sc.num_obs : (N - 1);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         // every lane composes its own row: straight to global memory (rows D floats apart: one 8-byte piece per lane
         // and instruction), or into the workgroup's LDS image of its [E][N][D] block, which all lanes then copy out
         // with consecutive 8-byte stores (a.stage; 16 x 65536 obstacle envs: 203 -> see profiles/r02_aux_kernels.md)
-        float2* const stage0 = smem + E * (2 * NE + L);                              // behind the last env's tables
+        float2* const stage0 = tables + E * (2 * NE + L);                              // behind the last env's tables
         float2* o = a.stage ? stage0 + (size_t)(e * N + i) * (D / 2) : reinterpret_cast<float2*>(a.obs + sidx * D);
         int w = 0;
         o[w++] = v;
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     }
     if (a.stage) {
         __syncthreads();
-        const float2* const img = smem + E * (2 * NE + L);
+        const float2* const img = tables + E * (2 * NE + L);
         const int b0 = blockIdx.x * E;
         const int El = min(E, a.B - b0);
         const int units = El * N * (D / 2);

@@ -430,7 +430,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     if (sc->kind < FG_SCN_BASIC || sc->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
     if (B == 0) return FG_OK;
     if (B < 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B >= 0, L > 0, M >= 0 required%s");
-    if (N < 2 || N + M > 64 || L > 1024) return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 64%s");
+    if (N < 2 || N + M > FG_MAX_AGENTS || L > 1024)
+        return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 1024, L <= 1024%s");
     if (sc->kind == FG_SCN_PARTIAL && (sc->num_obs < 0 || sc->num_obs > 1024)) return fail(FG_ERR_BAD_ARG, "bad num_obs%s");
     if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || !obs || (do_physics && (!act || !reward)) ||
         (M > 0 && (!obst_pos || !obst_vel)))
@@ -444,9 +445,9 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     a.opos = obst_pos; a.ovel = obst_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
     const int G = pow2ceil(N + M) < 4 ? 4 : pow2ceil(N + M);
-    const int E = 64 / G;
+    const int E = G <= 64 ? 64 / G : 1;               // more than 64 entities: one env per workgroup of G threads
     const int grid = (B + E - 1) / E;
-    int lds = E * (2 * (N + M) + L) * (int)sizeof(float2);
+    int lds = (E * (2 * (N + M) + L) + (G > 64 ? 32 : 0)) * (int)sizeof(float2);
     {   // observation rows composed in LDS and streamed out contiguously when the workgroup's block fits
         const int nbr = (sc->kind == FG_SCN_PARTIAL) ? sc->num_obs : (N - 1);
         const long long D = 2 + (sc->kind == FG_SCN_BASIC ? 2 : 0) + 2LL * L + 2LL * M + 2LL * nbr + 2LL * (N - 1);
@@ -459,7 +460,11 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);
     else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, 64>), dim3(grid), dim3(64), lds, st, a);
     else if (G == 32) hipLaunchKernelGGL((scn_kernel<32, 64>), dim3(grid), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((scn_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 64) hipLaunchKernelGGL((scn_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
+    else if (G == 128) hipLaunchKernelGGL((scn_kernel<128, 128>), dim3(grid), dim3(128), lds, st, a);
+    else if (G == 256) hipLaunchKernelGGL((scn_kernel<256, 256>), dim3(grid), dim3(256), lds, st, a);
+    else if (G == 512) hipLaunchKernelGGL((scn_kernel<512, 512>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((scn_kernel<1024, 1024>), dim3(grid), dim3(1024), lds, st, a);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario launch failed: %s", hipGetErrorString(err));
     return FG_OK;
@@ -496,7 +501,6 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   const float* act, const float* landmarks, int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_ag, void* stream) {
-    if (N > 64) return fail(FG_ERR_UNSUPPORTED_N, "basic_formation_env kernel needs 2 <= N <= 64%s");
     FgScenario sc; memset(&sc, 0, sizeof(sc));
     sc.kind = FG_SCN_BASIC; sc.num_landmarks = L; sc.penalty = 1.0f;
     return launch_scenario(params, &sc, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,

@@ -218,7 +218,8 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   int32_t* near_ag, void* stream);
 
 /* MultiAgentEnv.step for formation_hd_partial_env / formation_hd_partial_range_env /
- * formation_hd_obs_env (and basic_formation_env), N + M <= 64:
+ * formation_hd_obs_env (and basic_formation_env), N + M <= 1024 (one env per lane group of a wave up to 64 entities,
+ * per workgroup beyond):
  *   landmarks float [B][L][2]; obst_pos, obst_vel float [B][M][2] (updated in place, NULL if M = 0);
  *   obs float [B][N][D], D = 2 (+2 basic) + 2L + 2M + 2*nbr + 2(N-1), nbr = num_obs (partial) or N-1.
  * do_physics = 0 evaluates observation/reward/done on the current state (env.reset()). */

@@ -111,9 +111,9 @@ def test_argument_validation_before_any_launch(lib):
         == _native.FG_ERR_BAD_ARG                                                      # nothing to write
     assert lib.fg_rollout_hd(P, 4, 9, -1, *([p] * 12), 1, None) == _native.FG_ERR_BAD_ARG   # K < 0
     assert lib.fg_reset_hd(P, 4, 5000, *([p] * 9)) == _native.FG_ERR_UNSUPPORTED_N
-    assert lib.fg_step_basic(P, 4, 100, 3, 1, *([p] * 13)) == _native.FG_ERR_UNSUPPORTED_N
+    assert lib.fg_step_basic(P, 4, 1100, 3, 1, *([p] * 13)) == _native.FG_ERR_UNSUPPORTED_N
     sc = _native.FgScenario(kind=_native.FG_SCN_OBSTACLE, num_landmarks=4, num_obstacles=3, penalty=2.0)
-    assert lib.fg_step_scenario(P, sc, 4, 62, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 64
+    assert lib.fg_step_scenario(P, sc, 4, 1022, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 1024
     assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(0, 12, p, p, None) == _native.FG_ERR_BAD_ARG           # unknown mode

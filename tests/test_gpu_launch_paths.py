@@ -341,3 +341,55 @@ def test_captured_loop_with_auto_reset_uses_the_device_rng_counter(N, B):
     blocks = rec_p["obs"].view(R + 1, T, B, N, 6 * N)
     assert not torch.equal(blocks[1], blocks[2])                         # ... with different draws from block to block
     assert int(env.world.rng_counter.item()) == T * (R + 1)
+
+
+@pytest.mark.parametrize("scenario,kind,N,B", [("formation_hd_partial_env", "partial", 70, 9), ("formation_hd_partial_range_env", "range", 130, 5),
+                                                ("formation_hd_obs_env", "obstacle", 100, 6), ("formation_hd_obs_env", "obstacle", 62, 7),
+                                                ("formation_hd_partial_env", "partial", 300, 2), ("basic_formation_env", "basic", 90, 5)])
+def test_landmark_scenarios_beyond_64_entities(scenario, kind, N, B):
+    """fg_step_scenario / fg_step_basic with more than 64 movable entities (one env per workgroup instead of per lane
+    group of a wave; 62 agents + 3 obstacles crosses the limit through the obstacles) against the fp64 oracle on the same
+    crowded fp32 state, three steps teacher-forced."""
+    import formation_gym
+    rs = np.random.RandomState(N)
+    env = formation_gym.make_env(scenario, False, N, num_envs=B, device="cuda:0")
+    P = O.BasicParams() if kind == "basic" else O.ScnParams(kind)
+    L, M = P.num_landmarks, getattr(P, "num_obstacles", 0)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    state = dict(pos=f32(rs.uniform(-1, 1, (B, N, 2)) * 0.8), vel=f32(rs.uniform(-0.3, 0.3, (B, N, 2))),
+                 landmarks=f32(rs.uniform(-1, 1, (B, L, 2))), step=np.zeros(B, dtype=np.int32))
+    if M:
+        state["obst_pos"] = f32(rs.uniform(-0.5, 0.5, (B, M, 2)))
+        state["obst_vel"] = f32(np.tile(np.array(P.obstacle_vel), (B, M, 1)))
+    elif kind != "basic":
+        state["obst_pos"] = np.zeros((B, 0, 2)); state["obst_vel"] = np.zeros((B, 0, 2))
+    for t in range(3):
+        env.world.set_state(state["pos"], state["vel"])
+        env.world.landmark_pos.copy_(torch.as_tensor(state["landmarks"], dtype=torch.float32))
+        if M:
+            env.world.obstacle_pos.copy_(torch.as_tensor(state["obst_pos"], dtype=torch.float32))
+            env.world.obstacle_vel.copy_(torch.as_tensor(state["obst_vel"], dtype=torch.float32))
+        env.world.step_count.fill_(t)
+        act = f32(rs.uniform(-1, 1, (B, N, 2)))
+        obs, rew, done, info = env.step(torch.as_tensor(act, dtype=torch.float32).cuda())
+        new, out = (O.step_basic(state, act, P) if kind == "basic" else O.step_scn(kind, state, act, P))
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), new["pos"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), new["vel"], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs), out["obs"], rtol=0, atol=ATOL)
+        if M:
+            np.testing.assert_allclose(_np(env.world.obstacle_pos), new["obst_pos"], rtol=0, atol=ATOL)
+            np.testing.assert_allclose(_np(env.world.obstacle_vel), new["obst_vel"], rtol=0, atol=ATOL)
+        # collision counts are integers: compare where no pair sits within 1e-5 of a threshold
+        PD = np.sqrt(((new["pos"][:, :, None] - new["pos"][:, None]) ** 2).sum(-1)) + (0 if kind == "basic" else 10 * np.eye(N))
+        ok = np.abs(PD - P.collide_thresh).min((1, 2)) > 1e-5
+        if M:
+            OD = np.sqrt(((new["pos"][:, :, None] - new["obst_pos"][:, None]) ** 2).sum(-1))
+            ok &= np.abs(OD - (P.agent_size + P.obstacle_size)).min((1, 2)) > 1e-5
+        assert ok.sum() >= B - 2
+        np.testing.assert_allclose(_np(info["individual_reward"])[ok], out["indiv"][ok], rtol=0, atol=2 * ATOL)   # |r| up to ~20 at these counts
+        np.testing.assert_allclose(_np(rew)[ok][..., 0], np.repeat(out["shared"][:, None], N, 1)[ok], rtol=2e-6, atol=ATOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), out["done"])
+        state = dict(new, pos=f32(new["pos"]), vel=f32(new["vel"]))
+        if M:
+            state["obst_pos"] = f32(new["obst_pos"]); state["obst_vel"] = f32(new["obst_vel"])
