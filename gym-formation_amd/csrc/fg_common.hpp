@@ -113,6 +113,8 @@ struct Args {
                                // compile-time-N kernels constant-fold (-fapprox-func turns a device-side division into v_rcp_f32)
     int do_phys, do_post;
     int groups;                // wide pipelined kernel, K == 1: env batches per workgroup
+    int obs_only;              // step_kernel: only the observation stream (second launch of the split step)
+    int split;                 // step_kernel, one env per workgroup: workgroups per env in that launch (0 / 1 = one)
     real* px; real* py; real* vx; real* vy;
     const real* act;          // [K][B][N][2]
     real* shape;              // [B][N][2]

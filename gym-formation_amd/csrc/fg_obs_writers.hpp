@@ -26,12 +26,14 @@ FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
 
 template <int NC, int NW, int E, int PACE = 0>
 FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
-                           float2* __restrict__ out_env0, size_t env_units, int El, int parts) {
+                           float2* __restrict__ out_env0, size_t env_units, int El, int parts,
+                           int wg_part = 0, int wg_parts = 1) {
     // tables0 / env_stride: A-table of env 0 and the distance (float2) to the next env's;
     // out_env0 / env_units: observation block of env 0 and the distance (float2 units) to the next env's
     //   (3 N^2 when the [B][N][6N] tensor is contiguous; larger with a padded env pitch or strided env ownership)
     // w: index of this wave among the NW waves that share the job
     // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
+    // wg_part / wg_parts (N > 64, one env per workgroup): this workgroup is one of wg_parts that share the env
     constexpr int N = NC;
     constexpr int WPE = (E >= NW) ? 1 : NW / E;             // waves sharing one env
     constexpr int ESTEP = (E >= NW) ? NW : 1;               // env stride of one wave
@@ -95,10 +97,11 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             for (int c = 0; c < CS; ++c) sv[c] = lds_if(lane + 64 * c < 2 * N, AA, N + lane + 64 * c);
             // the WPE waves that share an env take contiguous row ranges (one contiguous run of the observation
             // block per wave; every WPE-th row measured 2-3 % slower at 81 x 2048, profiles/README.md)
-            constexpr int PER = (N + WPE - 1) / WPE;
-            const int r_end = min(N, (row0 + 1) * PER);
+            const int nshare = WPE * wg_parts, share = wg_part * WPE + row0;     // (wave, workgroup) shares of the rows
+            const int PER = (N + nshare - 1) / nshare;
+            const int r_end = min(N, (share + 1) * PER);
 #pragma unroll 2
-            for (int r = row0 * PER; r < r_end; ++r) {
+            for (int r = share * PER; r < r_end; ++r) {
                 const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
                 const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
                 float2* __restrict__ orow = out + (unsigned)r * ROWU;

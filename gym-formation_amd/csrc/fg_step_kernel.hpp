@@ -32,11 +32,16 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     constexpr bool FLAT = (NC == 0);          // observation writer: register-cached rows (compile-time N) or flat decode
     static_assert(E * G <= T && (G <= 64 || E == 1), "bad geometry");
     extern __shared__ __attribute__((aligned(16))) real2 smem[];
-    const int N = NC ? NC : pre_N;
+    const int N = NC ? NC : (pre_N & 0xFFFF);
+    // pre_N >> 16 = S > 1 (one env per workgroup only): S workgroups share an env and each streams 1/S of its
+    // observation block - the second launch of the split step for batches with fewer envs than the chip has CUs
+    // (host: launch_step).  Carried in the preloaded scalar so that the state loads do not wait for `a`.
+    const int split = (E == 1) ? (pre_N >> 16) : 0;
+    const int part = split > 1 ? (int)(blockIdx.x % (unsigned)split) : 0;
     const int tid = threadIdx.x;
     const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
     const int i = (E == 1) ? tid : tid % G;
-    const int b0 = blockIdx.x * E;
+    const int b0 = (split > 1 ? (int)(blockIdx.x / (unsigned)split) : (int)blockIdx.x) * E;
     const int b = b0 + e;
     const bool env_ok = (e < E) && (b < pre_B);   // this thread's lane group owns a live env
     const bool valid = env_ok && (i < N);
@@ -127,6 +132,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         }
 
         if (a.do_post) {
+          if (!a.obs_only) {
             // ---- phase 3: reward -------------------------------------------
             real sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
             env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, scratch);
@@ -201,12 +207,14 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             }
 
             FG_STAMP(3);
+          }
             // ---- phase 5: observations --------------------------------------
             if (want_obs && !FLAT) {
                 if constexpr (NC > 0)
                     write_obs_rows<NC, T / 64, E, (NC > 64 ? 1 : 0)>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
                                                   reinterpret_cast<real2*>(a.obs) +
-                                                  ((size_t)slot * pre_B + b0) * (size_t)a.obs_pitch, (size_t)a.obs_pitch, El, 3);
+                                                  ((size_t)slot * pre_B + b0) * (size_t)a.obs_pitch, (size_t)a.obs_pitch, El, 3,
+                                                  part, split > 1 ? split : 1);
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows
@@ -236,15 +244,18 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         val.y -= is_delta ? pi.y : 0.0f;
                         return val;
                     };
-                    if (head && tid == 0) out2[0] = unit(0u, 0u);
+                    if (head && tid == 0 && part == 0) out2[0] = unit(0u, 0u);
                     const unsigned npair = (total - head) >> 1;
                     realx4* const out4 = reinterpret_cast<realx4*>(out2 + head);
                     const unsigned du = (2u * T) % n3, drow = (2u * T) / n3;
-                    unsigned q = head + 2u * tid;
+                    // split step: this workgroup's share of the env's 16-byte pairs (all of them otherwise)
+                    const unsigned q_lo = split > 1 ? (unsigned)((unsigned long long)npair * (unsigned)part / (unsigned)split) : 0u;
+                    const unsigned q_hi = split > 1 ? (unsigned)((unsigned long long)npair * (unsigned)(part + 1) / (unsigned)split) : npair;
+                    unsigned q = head + 2u * (q_lo + tid);
                     unsigned rp = q / n3;
                     unsigned u = q - rp * n3;
 #pragma unroll 2
-                    for (unsigned q2 = tid; q2 < npair; q2 += T) {
+                    for (unsigned q2 = q_lo + tid; q2 < q_hi; q2 += T) {
                         unsigned u1 = u + 1u, rp1 = rp;
                         if (u1 == n3) { u1 = 0u; rp1 += 1u; }
                         const real2 x0 = unit(rp, u), x1 = unit(rp1, u1);
@@ -253,7 +264,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         u += du; rp += drow;
                         if (u >= n3) { u -= n3; rp += 1u; }
                     }
-                    if (((total - head) & 1u) && tid == T - 1)
+                    if (((total - head) & 1u) && tid == T - 1 && part == (split > 1 ? split - 1 : 0))
                         out2[total - 1] = unit((total - 1) / n3, (total - 1) % n3);
                 }
             }

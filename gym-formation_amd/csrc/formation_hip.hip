@@ -85,7 +85,7 @@ static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
     hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, OPTS>), dim3(grid), dim3(T), lds, st,
-                       a.B, a.N, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
+                       a.B, a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16), (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
                        (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
     return hipGetLastError();
 }
@@ -100,6 +100,9 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
                                        &launch_v<NC, G, T, E, true, false>, &launch_v<NC, G, T, E, true, true>}
 #define FG_VARIANT_BIG(NC, G, T, E, MINB) {NC, G, T, E, MINB, &launch_v<NC, G, T, E, false, false>, nullptr, nullptr}
 
+#ifndef FG_SPLIT_MAX_B
+#define FG_SPLIT_MAX_B 128         // split step (launch_step) up to this many envs
+#endif
 #ifndef FG_WIDE243_MIN_B
 #define FG_WIDE243_MIN_B 4096      // single-step launches at 243 agents: below this the pipelined kernel's 4-env batches leave CUs
                                    // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
@@ -152,6 +155,25 @@ static int launch_step(Args a, hipStream_t st) {
     const Variant* v = variant_for(a.N, a.B, opts || idx);
     if (!v || !geometry_for(a.N, &g, a.B, opts || idx)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     const int grid = (a.B + g.E - 1) / g.E;
+    // Split step: more than 64 agents (one env per workgroup) and fewer envs than half the chip's CUs.  One workgroup per
+    // env would leave most CUs idle during the observation stream, which is 99 % of the bytes; so the fused kernel runs
+    // WITHOUT the observation (state, reward, done, reset) and a second launch of S workgroups per env streams the
+    // observation from the final state - the very values the fused kernel holds in LDS, hence the same bits
+    // (243 x 64: 43.4 -> 37.4 us, 256 x 64: 69 -> 41, 1024 x 64: 581 -> 394-448; neutral at 81 agents; 243 x 128 loses 8 %,
+    // hence 96 there: profiles/r02_step/split_step.txt)
+    if (g.E == 1 && a.K == 1 && a.do_phys && a.do_post && a.obs && a.B <= (a.N == 243 ? (FG_SPLIT_MAX_B * 3) / 4 : FG_SPLIT_MAX_B)) {
+        int S = 256 / a.B;
+        if (S > 8) S = 8;
+        Args a1 = a; a1.obs = nullptr;
+        hipError_t err = (opts ? v->opts : idx ? v->idx : v->plain)(a1, grid, g.lds, st);
+        if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
+        Args a2 = a;
+        a2.do_phys = 0; a2.obs_only = 1; a2.split = S; a2.p.auto_reset = 0;
+        a2.rew = nullptr; a2.indiv = nullptr; a2.done = nullptr; a2.near_lm = nullptr; a2.near_ag = nullptr; a2.hd_idx = nullptr;
+        err = v->plain(a2, grid * S, g.lds, st);
+        if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
+        return FG_OK;
+    }
     const hipError_t err = (opts ? v->opts : idx ? v->idx : v->plain)(a, grid, g.lds, st);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
     return FG_OK;

@@ -393,3 +393,33 @@ def test_landmark_scenarios_beyond_64_entities(scenario, kind, N, B):
         state = dict(new, pos=f32(new["pos"]), vel=f32(new["vel"]))
         if M:
             state["obst_pos"] = f32(new["obst_pos"]); state["obst_vel"] = f32(new["obst_vel"])
+
+
+@pytest.mark.parametrize("N,B_split", [(243, 96), (100, 128), (81, 128), (300, 128), (1024, 5)])
+def test_split_step_equals_the_fused_launch(N, B_split):
+    """More than 64 agents and few envs: `fg_step_hd` runs the fused kernel without the observation and a second launch in
+    which several workgroups per env stream the observation (launch_step in formation_hip.hip).  The same envs stepped in a
+    batch one env larger - which takes the single fused launch - must give the same bits, auto-reset included."""
+    B = B_split + 1
+    if N == 1024:
+        B = 130                                            # the fused launch needs more than 128 envs
+    step0 = np.where(np.arange(B) % 3 == 0, 99, 5)
+    big, _ = _pair(N, B, seed=6, crowd=0.4, step0=step0)
+    small = _make(N, B_split)
+    small.scenario.seed(6)
+    pos, vel = big.world.get_state()
+    small.world.set_state(pos[:B_split], vel[:B_split])
+    small.scenario.ideal_shape.copy_(big.scenario.ideal_shape[:B_split]); small.scenario.ideal_vel.copy_(big.scenario.ideal_vel[:B_split])
+    small.world.step_count.copy_(big.world.step_count[:B_split])
+    small.auto_reset = True
+    gen = torch.Generator(device="cuda"); gen.manual_seed(N)
+    for t in range(3):
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") * 2 - 1
+        o1, r1, d1, i1 = big.step(act)
+        o2, r2, d2, i2 = small.step(act[:B_split].contiguous())
+        assert torch.equal(o1[:B_split], o2) and torch.equal(r1[:B_split], r2) and torch.equal(d1[:B_split], d2)
+        assert torch.equal(i1["individual_reward"][:B_split], i2["individual_reward"])
+        assert bool(d2.any()) == (t == 0)
+    for x, y in zip(big.world.get_state(), small.world.get_state()):
+        assert torch.equal(x[:B_split], y)
+    assert torch.equal(big.scenario.ideal_shape[:B_split], small.scenario.ideal_shape)
