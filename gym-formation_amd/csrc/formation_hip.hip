@@ -108,7 +108,7 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
                                    // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
 #endif
 static const Variant kVariants[] = {
-    FG_VARIANT(3, 4, 128, 16, 0),
+    FG_VARIANT(3, 4, 128, 16, 0), FG_VARIANT_BIG(3, 4, 128, 32, 65536),   // every lane owns an agent: 3 x 262144 35.3 -> 27.8 us (profiles/r02_step/n3_big_batches.txt)
     FG_VARIANT(9, 16, 128, 4, 0), FG_VARIANT_BIG(9, 16, 128, 8, 16384),
     FG_VARIANT(27, 32, 256, 4, 0), FG_VARIANT_BIG(27, 32, 256, 8, 32768),
     FG_VARIANT(81, 128, 128, 1, 0),

@@ -60,9 +60,11 @@ def _snapshot(env):
 
 
 @pytest.mark.parametrize("N,B,K", [(27, 4096, 20), (9, 4096, 20), (81, 2048, 20), (243, 8192, 4),
-                                    (9, 5003, 7), (9, 8200, 6), (9, 32768, 4), (27, 16384, 3), (27, 4099, 7), (27, 4099, 3)])
+                                    (9, 5003, 7), (9, 8200, 6), (9, 32768, 4), (27, 16384, 3), (27, 4099, 7), (27, 4099, 3),
+                                    (3, 66001, 3)])
 def test_bench_launches_equal_single_steps_and_oracle(N, B, K):
-    # the last six: the batch-size classes that select other instantiations (9 agents: 8- and 16-env workgroups with
+    # the last seven: the batch-size classes that select other instantiations (3 agents: 32-env workgroups from 65 536 envs;
+    # 9 agents: 8- and 16-env workgroups with
     # the LDS-tile writer above 4096 envs; 27 agents: the plain tile writer from 16 384 envs and for buffers that fit
     # the Infinity Cache, the HBM-streaming one otherwise) and batches that are not a multiple of the workgroup's env
     # count (a partial last workgroup, step slots that do not start on a 128-byte line)
