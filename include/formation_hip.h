@@ -153,7 +153,8 @@ int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes);
 /* Algorithmic bytes per env-step of fg_step_hd (24 N^2 + 53 N + 16). */
 int64_t fg_step_hd_bytes(int N);
 
-/* MultiAgentEnv.step for formation_hd_env, all B envs, ONE fused launch:
+/* MultiAgentEnv.step for formation_hd_env, all B envs, ONE fused launch (more than 64 agents in at most 128 envs: two
+ * launches - everything but the observation, then the observation streamed by several workgroups per env; same results):
  * _set_action (environment.py:187-236) -> World.step (core.py:206-225:
  * apply_action_force :228-237, apply_environment_force :240-262 with
  * get_entity_collision_force :289-322, integrate_state :264-277,
