@@ -14,7 +14,7 @@ namespace fg {
 // NPC: the padded partner count when it is a small compile-time constant (<= 16), else 0.  With
 // NPC every partner is fetched from LDS up front (one round trip instead of one per iteration:
 // at small N the producer chain is latency-bound); the arithmetic and its order are the same.
-template <int NPC = 0>
+template <int NPC = 0, int UNR = 2>
 FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __restrict__ QY, int NP,
                                    int i, real2 p, real cf, real kmargin, real dmin, real cutoff2) {
     real fx = 0.0f, fy = 0.0f;
@@ -67,7 +67,7 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
         for (int j0 = 0; j0 < NP; j0 += 32) {
             const int jn = NP - j0 < 32 ? NP - j0 : 32;
             uint32_t m = 0;
-#pragma unroll 2
+#pragma unroll UNR
             for (int t = 0; t < jn; t += 2)
                 m |= mark(t, *reinterpret_cast<const realx2*>(QX + j0 + t), *reinterpret_cast<const realx2*>(QY + j0 + t));
             if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
@@ -79,7 +79,7 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
 
 // Scenario.reward inner pass for agent i / ideal point i (formation_hd_env.py:61-75):
 //   rowmin = min_j |p~_i - s_j|^2,  colmin = min_j |p~_j - s_i|^2,  cnt = #{j != i : |p_j - p_i| < thr}
-template <bool IDX, int NPC = 0>
+template <bool IDX, int NPC = 0, int UNR = 2>
 FG_DEV void reward_pass_packed(const real* __restrict__ PX, const real* __restrict__ PY,
                                const real* __restrict__ SX, const real* __restrict__ SY, int NP,
                                real2 p, real ptx, real pty, real tx, real ty, real thr2,
@@ -117,7 +117,7 @@ FG_DEV void reward_pass_packed(const real* __restrict__ PX, const real* __restri
 #pragma unroll
         for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h], sx[h], sy[h]);
     } else {
-#pragma unroll 2
+#pragma unroll UNR
         for (int j = 0; j < NP; j += 2)
             pair(j, *reinterpret_cast<const realx2*>(PX + j), *reinterpret_cast<const realx2*>(PY + j),
                  *reinterpret_cast<const realx2*>(SX + j), *reinterpret_cast<const realx2*>(SY + j));

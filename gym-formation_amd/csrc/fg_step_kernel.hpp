@@ -49,6 +49,10 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
 
     const int NP = npad(N);
     constexpr int NPS = (NC > 0 && npad(NC > 0 ? NC : 1) <= 16) ? npad(NC > 0 ? NC : 1) : 0;   // small N: partners fetched up front
+    // pair loops of 17..32 agents: 7 iterations (14 partners) per unrolled block, so that a block's LDS reads are in flight
+    // together - only two of a SIMD's waves own agents in this geometry, little else hides the round trips
+    // (27 x 4096: 15.6 -> 15.3 us, profiles/r02_step/step27_micro.txt)
+    constexpr int UNR = (NC > 16 && NC <= 32) ? 7 : 2;
     real2* const A = env_tables(smem, e < E ? e : 0, N);
     real2* const V = A + 3 * N;
     real2* const NV = A + 4 * N;             // -velocity, read by the row writer
@@ -101,7 +105,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         if (a.do_phys) {
             if (valid) {
                 const real2 u = reinterpret_cast<const real2*>(a.act)[((size_t)k * pre_B + b) * N + i];
-                real2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+                real2 f = contact_force_packed<NPS, UNR>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                 a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
                     const real2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p) + k);
@@ -143,7 +147,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             real rowmin = INFINITY, colmin = INFINITY;
             int cnt = 0, arg_lm = 0, arg_ag = 0;
             if (valid)
-                reward_pass_packed<IDX, NPS>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
+                reward_pass_packed<IDX, NPS, UNR>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
                                         rowmin, colmin, cnt, arg_lm, arg_ag);
             real red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (real)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
