@@ -433,6 +433,12 @@ def main():
     # an even agent count and a non-power-of-3 one (generic-N kernel path)
     save("hd_n4", lambda: rollout_hd(fg, 4, 3, 10, seed=21, act_seed=31))
     save("hd_n10", lambda: rollout_hd(fg, 10, 2, 10, seed=22, act_seed=32, crowd=0.3))
+    # more run-time agent counts (lane groups of 8, 16, 64 lanes and a whole-workgroup env), sparse and crowded
+    save("hd_n5", lambda: rollout_hd(fg, 5, 3, 12, seed=27, act_seed=37))
+    save("hd_n6_crowd", lambda: rollout_hd(fg, 6, 3, 12, seed=28, act_seed=38, crowd=0.1))
+    save("hd_n16_crowd", lambda: rollout_hd(fg, 16, 2, 12, seed=29, act_seed=39, crowd=0.2))
+    save("hd_n50", lambda: rollout_hd(fg, 50, 2, 8, seed=30, act_seed=40, obs_at=[1, 8]))
+    save("hd_n100_crowd", lambda: rollout_hd(fg, 100, 1, 6, seed=31, act_seed=41, crowd=0.35, obs_at=[6]))
     # done flip of formation_hd_env at world_length = 100
     save("hd_n9_options", lambda: rollout_hd(fg, 9, 4, 30, seed=23, act_seed=33, options=dict(max_speed=0.6, accel=3.0, walls=True)))
     save("hd_n27_walls", lambda: rollout_hd(fg, 27, 2, 20, seed=24, act_seed=34, options=dict(walls=True)))

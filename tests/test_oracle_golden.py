@@ -7,7 +7,7 @@ import pytest
 from oracle import formation_oracle as O
 
 HD_CASES = ["hd_n3", "hd_n9", "hd_n27", "hd_n81", "hd_n9_crowd", "hd_n27_crowd",
-            "hd_n81_crowd", "hd_n243", "hd_n4", "hd_n10", "hd_n3_done"]
+            "hd_n81_crowd", "hd_n243", "hd_n4", "hd_n10", "hd_n5", "hd_n6_crowd", "hd_n16_crowd", "hd_n50", "hd_n100_crowd", "hd_n3_done"]
 TOL = 1e-12
 
 
