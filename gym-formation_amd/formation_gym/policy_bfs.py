@@ -124,6 +124,15 @@ def bfs_actions(obs, num_agents_per_layer, out=None):
         out = torch.empty((B, N, 2), dtype=torch.float32, device=obs.device)
     elif tuple(out.shape) != (B, N, 2) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != obs.device:
         raise ValueError("out must be a contiguous float32 tensor [B, N, 2] on the observations' device")
-    _native.check(_native.load().fg_policy_bfs(B, N, int(num_agents_per_layer), obs.data_ptr(), int(stride),
-                                               out.data_ptr(), _native.current_stream(obs.device)))
+    rc = _LIB()(B, N, int(num_agents_per_layer), obs.data_ptr(), int(stride), out.data_ptr(),
+                _native.current_stream_fast(obs.device))
+    if rc:
+        _native.check(rc)
     return out
+
+
+def _LIB(_cache=[]):
+    """The bound `fg_policy_bfs` entry point (per-step path: looked up once)."""
+    if not _cache:
+        _cache.append(_native.load().fg_policy_bfs)
+    return _cache[0]
