@@ -2,7 +2,7 @@
 """Single-step launches (fg_step_hd) over agent counts OUTSIDE the specialised set {3, 9, 27, 81, 243}: the run-time-N
 instantiations of fg::step_kernel (flat observation writer).  HIP events around 100 queued launches, batch sized for
 ~300 MB of observation per step so the launch is store-bound, not launch-bound.  The K-step call (fg_rollout_hd) at
-these agent counts is K chained single-step launches, so this is its rate as well."""
+these agent counts runs the same kernel with its K-loop (one launch, no producer / writer pipeline), so this is about its rate per step as well."""
 import os
 import sys
 import time

@@ -28,7 +28,7 @@ def _case(rs):
     elif N == 243:
         B = int(rs.choice([1, 2, 5, 9, 96, 97]))
     elif N >= 100:
-        B = int(rs.choice([1, 3, 40]))                        # run-time N, one env per workgroup: split steps, chained K-step calls
+        B = int(rs.choice([1, 3, 40]))                        # run-time N, one env per workgroup: split single steps, K-loop launches
     else:
         B = int(rs.choice([1, 7, 50]))
     big = N == 27 and 1300 <= B < 16384
