@@ -37,11 +37,12 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     // observation block - the second launch of the split step for batches with fewer envs than the chip has CUs
     // (host: launch_step).  Carried in the preloaded scalar so that the state loads do not wait for `a`.
     const int split = (E == 1) ? (pre_N >> 16) : 0;
-    const int part = split > 1 ? (int)(blockIdx.x % (unsigned)split) : 0;
+    const unsigned sdiv = split > 1 ? (unsigned)split : 1u;
+    const int part = (int)(blockIdx.x % sdiv);
     const int tid = threadIdx.x;
     const int e = (E == 1) ? 0 : tid / G;        // tid >= E*G: no agent, only streams observations
     const int i = (E == 1) ? tid : tid % G;
-    const int b0 = (split > 1 ? (int)(blockIdx.x / (unsigned)split) : (int)blockIdx.x) * E;
+    const int b0 = (int)(blockIdx.x / sdiv) * E;
     const int b = b0 + e;
     const bool env_ok = (e < E) && (b < pre_B);   // this thread's lane group owns a live env
     const bool valid = env_ok && (i < N);
