@@ -37,15 +37,19 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
     // evaluated afterwards in ascending j - the summation order, and with it every bit of the result, is that of the
     // plain loop.  The wave now runs the softplus max-over-lanes(#contacts) times per chunk: ~2 instead of ~20 at 27 agents.
     // beyond the cutoff the softplus penetration is below fp32 resolution of the force: skipped
-    auto mark = [&](int bit, realx2 qx, realx2 qy) -> uint32_t {
+    // The mark word is built by shifting: m = 2 m + (close ? 1 : 0) is ONE v_addc behind the compare, so the first partner
+    // of a chunk of n ends up in bit n - 1 and the marked partners are walked from the highest bit down (ascending j).
+    auto mark = [&](uint32_t& m, realx2 qx, realx2 qy) {
         const realx2 dx = px - qx, dy = py - qy;
         const realx2 d2 = dx * dx + dy * dy;
-        return (d2.x < cutoff2 ? (1u << bit) : 0u) | (d2.y < cutoff2 ? (2u << bit) : 0u);
+        m = m + m + (d2.x < cutoff2 ? 1u : 0u);
+        m = m + m + (d2.y < cutoff2 ? 1u : 0u);
     };
-    auto flush = [&](int j0, uint32_t m) {
+    auto flush = [&](int j0, int n, uint32_t m) {               // chunk of n partners starting at j0
         while (m) {
-            const int j = j0 + __builtin_ctz(m);
-            m &= m - 1;
+            const int hb = 31 - __builtin_clz(m);
+            m &= ~(1u << hb);
+            const int j = j0 + (n - 1 - hb);
             const realx2 qx = {QX[j], QX[j]}, qy = {QY[j], QY[j]};
             const realx2 dx = px - qx, dy = py - qy;
             const realx2 d2 = dx * dx + dy * dy;
@@ -61,17 +65,17 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
         }
         uint32_t m = 0;
 #pragma unroll
-        for (int h = 0; h < NPC / 2; ++h) m |= mark(2 * h, qx[h], qy[h]);
-        flush(0, m & ~(1u << i));
+        for (int h = 0; h < NPC / 2; ++h) mark(m, qx[h], qy[h]);
+        flush(0, NPC, m & ~(1u << (NPC - 1 - i)));
     } else {
         for (int j0 = 0; j0 < NP; j0 += 32) {
             const int jn = NP - j0 < 32 ? NP - j0 : 32;
             uint32_t m = 0;
 #pragma unroll UNR
             for (int t = 0; t < jn; t += 2)
-                m |= mark(t, *reinterpret_cast<const realx2*>(QX + j0 + t), *reinterpret_cast<const realx2*>(QY + j0 + t));
-            if ((unsigned)(i - j0) < 32u) m &= ~(1u << (i - j0));
-            flush(j0, m);
+                mark(m, *reinterpret_cast<const realx2*>(QX + j0 + t), *reinterpret_cast<const realx2*>(QY + j0 + t));
+            if ((unsigned)(i - j0) < (unsigned)jn) m &= ~(1u << (jn - 1 - (i - j0)));
+            flush(j0, jn, m);
         }
     }
     return make_real2(fx, fy);
