@@ -18,7 +18,7 @@ namespace fg {
 //   IDX also emit the landmark-index assignments
 // LDS per env: see env_block_floats(); observation unit u >= N of any row is A[u], unit 0 of row i is A[3N + i].
 // ---------------------------------------------------------------------------
-template <int NC, int G, int T, int E, bool IDX, bool OPTS>
+template <int NC, int G, int T, int E, bool IDX, bool OPTS, bool KONE = false>
 __global__ __launch_bounds__(T)
 void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_px, const real* __restrict__ pre_py,
                  const real* __restrict__ pre_vx, const real* __restrict__ pre_vy, const real* __restrict__ pre_shape,
@@ -98,10 +98,12 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     __syncthreads();
     FG_STAMP(1);
 
-    for (int k = 0; k < a.K; ++k) {
+    // KONE: the single-step instantiation (K = 1, obs_every = 1 known at compile time: no step loop, no slot arithmetic)
+    const int K = KONE ? 1 : a.K;
+    for (int k = 0; k < K; ++k) {
         int slot = k;
         bool want_obs = a.do_post && a.obs != nullptr;
-        if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
+        if (!KONE && a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
         // ---- phase 2: World.step ------------------------------------------
         if (a.do_phys) {
             if (valid) {
@@ -276,7 +278,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         }
 
         FG_STAMP(4);
-        if (k + 1 < a.K) {
+        if (k + 1 < K) {
             __syncthreads();            // obs phase done reading A/V before the next step writes them
             if (valid) { QX[i] = p.x; QY[i] = p.y; }
             __syncthreads();

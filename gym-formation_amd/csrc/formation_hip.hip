@@ -82,10 +82,24 @@ static hipError_t raise_lds_limit(const void* fn, int lds, std::atomic<unsigned 
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
+#ifndef FG_EXP_KONE
+#define FG_EXP_KONE 1      // 0: experiment builds without the single-step instantiations
+#endif
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
+    const int n_split = a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16);
+#if FG_EXP_KONE
+    // the single-step instantiation (no step loop, no slot arithmetic) of the plain variants from 27 agents up: 27 x 4096
+    // 15.15 -> 15.03 us, 81 x 2048 -1 %; at 3 and 9 agents it is slower (profiles/r02_step/kone.txt)
+    if (!IDX && !OPTS && NC >= 27 && a.K == 1 && a.obs_every == 1) {
+        hipLaunchKernelGGL((step_kernel<NC, G, T, E, false, false, (!IDX && !OPTS && NC >= 27)>), dim3(grid), dim3(T), lds, st,
+                           a.B, n_split, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
+                           (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
+        return hipGetLastError();
+    }
+#endif
     hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, OPTS>), dim3(grid), dim3(T), lds, st,
-                       a.B, a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16), (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
+                       a.B, n_split, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
                        (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
     return hipGetLastError();
 }
