@@ -425,3 +425,68 @@ def test_split_step_equals_the_fused_launch(N, B_split):
     for x, y in zip(big.world.get_state(), small.world.get_state()):
         assert torch.equal(x[:B_split], y)
     assert torch.equal(big.scenario.ideal_shape[:B_split], small.scenario.ideal_shape)
+
+
+def test_device_rng_counter_toggle_and_captured_rollouts():
+    """(1) Switching the device RNG counter on and off in the middle of a run changes nothing: the offsets continue.
+    (2) K-step launches (`env.rollout`, `env.rollout_policy` into caller-owned buffers) are capturable too: a graph of
+    two launches replayed three times equals the same launches issued one by one."""
+    N, B, K = 27, 200, 6
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    acts = torch.rand((K, B, N, 2), generator=gen, device=dev) * 2 - 1
+
+    def fresh():
+        env = _make(N, B)
+        env.seed(2); env.reset()
+        env.auto_reset = True
+        env.world.world_length = 4
+        env.world.step_count.copy_(torch.arange(B, dtype=torch.int32, device=dev) % 4)
+        return env
+
+    def bufs():
+        f = dict(dtype=torch.float32, device=dev)
+        return dict(obs=torch.empty((K, B, N, 6 * N), **f), reward=torch.empty((K, B, N), **f), indiv=torch.empty((K, B, N), **f),
+                    done=torch.zeros((K, B, N), dtype=torch.uint8, device=dev), act=torch.empty((K, B, N, 2), **f))
+
+    # (1) toggle
+    a, b = fresh(), fresh()
+    seq_a, seq_b = [], []
+    for t in range(9):
+        if t == 2:
+            b.use_device_rng_counter(True)
+        if t == 6:
+            b.use_device_rng_counter(False)
+        seq_a.append(a.step(acts[t % K])[0].clone()); seq_b.append(b.step(acts[t % K])[0].clone())
+    assert all(torch.equal(x, y) for x, y in zip(seq_a, seq_b))
+    assert b.world.rng_counter is None and a._rng_offset == b._rng_offset == 9
+
+    # (2) captured K-step launches
+    ref, out_r, pol_r = fresh(), bufs(), bufs()
+    rec = []
+    for r in range(4):
+        ref.rollout(acts, out={k: v for k, v in out_r.items() if k != "act"})
+        ref.rollout_policy(K, 3, out=pol_r)
+        rec.append((out_r["obs"].clone(), pol_r["obs"].clone(), pol_r["act"].clone()))
+    env, out_g, pol_g = fresh(), bufs(), bufs()
+    env.use_device_rng_counter()
+    out_g_roll = {k: v for k, v in out_g.items() if k != "act"}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                        # = block 0, launch by launch
+        env.rollout(acts, out=out_g_roll)
+        env.rollout_policy(K, 3, out=pol_g)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(out_g["obs"], rec[0][0]) and torch.equal(pol_g["obs"], rec[0][1])
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        env.rollout(acts, out=out_g_roll)
+        env.rollout_policy(K, 3, out=pol_g)
+    for r in range(1, 4):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_g["obs"], rec[r][0]), "replay %d: open-loop launch" % r
+        assert torch.equal(pol_g["obs"], rec[r][1]) and torch.equal(pol_g["act"], rec[r][2]), "replay %d: closed-loop launch" % r
+    for x, y in zip(ref.world.get_state(), env.world.get_state()):
+        assert torch.equal(x, y)
