@@ -56,8 +56,8 @@ class FormationVecEnv(object):
             if finished.any():
                 sc, world = self.env.scenario, self.env.world
                 mask = torch.as_tensor(finished.astype("uint8")).to(world.device, non_blocking=True)
-                rew, done = rew.clone(), done.clone()
-                info = {k: v.clone() for k, v in info.items()}
+                # the reset and the observation launch below write state and observations only: reward / done / info
+                # keep their pre-reset values (as in 'device' mode they are views of buffers the next step overwrites)
                 sc.reset_mt(world, mask)
                 sc.observe_batch(world, {"obs": self.env._out["obs"]})
                 self._host_steps[finished] = 0
