@@ -82,13 +82,13 @@ static hipError_t raise_lds_limit(const void* fn, int lds, std::atomic<unsigned 
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-#ifndef FG_EXP_KONE
-#define FG_EXP_KONE 1      // 0: experiment builds without the single-step instantiations
+#ifndef FG_SINGLE_STEP_VARIANTS
+#define FG_SINGLE_STEP_VARIANTS 1      // 0: experiment builds without the single-step instantiations
 #endif
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
     const int n_split = a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16);
-#if FG_EXP_KONE
+#if FG_SINGLE_STEP_VARIANTS
     // the single-step instantiation (no step loop, no slot arithmetic) of the plain variants from 27 agents up: 27 x 4096
     // 15.15 -> 15.03 us, 81 x 2048 -1 %; at 3 and 9 agents it is slower (profiles/r02_step/kone.txt)
     if (!IDX && !OPTS && NC >= 27 && a.K == 1 && a.obs_every == 1) {
