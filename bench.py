@@ -66,8 +66,9 @@ def measured_traffic(n_agents, envs, mode, steps_per_launch):
 
 
 def n1_reference(workload_key):
-    """env-steps/s of a GLOBAL-batch config measured on ONE GPU (profiles/r02_n1_global_configs.json, written from
-    this script's own N = 1 line): the denominator of `scaling_efficiency_vs_n1`."""
+    """env-steps/s of a GLOBAL-batch config measured on ONE GPU of ANOTHER box in round 2
+    (profiles/r02_n1_global_configs.json): reported for orientation only - the denominator of
+    `scaling_efficiency_vs_n1` is measured in the same run (see global_configs below)."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", "r02_n1_global_configs.json")))[workload_key]
     except Exception:
@@ -103,7 +104,11 @@ def cpu_baseline(n_agents, budget_s=12.0):
     """The oracle's per-env port (same loop structure as the reference) on the host
     cores: one env per process, bounded sample.  Reported baseline only."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 32)
+    host_cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))                  # the cores this process may actually use
+    except AttributeError:
+        cores = host_cores
     probe = _cpu_port_worker((n_agents, 2, 12345))          # seconds for 2 steps, 1 core
     per_step = max(probe / 2, 1e-4)
     steps = int(max(3, min(400, budget_s / per_step)))
@@ -113,7 +118,7 @@ def cpu_baseline(n_agents, budget_s=12.0):
         elapsed = pool.map(_cpu_port_worker, [(n_agents, steps, 1 + 1000 * r) for r in range(cores)])
     wall = max(elapsed)
     return {
-        "value": round(cores * steps / wall, 2), "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "value": round(cores * steps / wall, 2), "unit": "env-steps/s", "cores": cores, "host_cores": host_cores, "kind": "port",
         "sample": "%d envs x %d steps of formation_hd_env N=%d, one env per process "
                   "(oracle.PortEnv, numpy/scipy, fp64), wall = slowest worker %.1fs; "
                   "pool start-up excluded (%.1fs total)" % (cores, steps, n_agents, wall, time.perf_counter() - t0),
@@ -195,6 +200,9 @@ def main():
     ap.add_argument("--global-div", type=int, default=1,
                     help="test aid: run the GLOBAL-batch configs (BASELINE configs[3], [4]) with their batch sizes divided "
                          "by this, whatever the headline shape is (the lines are marked)")
+    ap.add_argument("--placement-candidates", type=int, default=4,
+                    help="observation buffers beyond the Infinity Cache: allocate up to this many candidates, time the launch "
+                         "on each, keep the fastest (formation_gym/placement.py); 1 = no probe")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
@@ -262,7 +270,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world_size > 1:
+        if world_size > 1 and not solo[0]:
             dist.barrier(group=sync_group)
         torch.cuda.synchronize()
 
@@ -276,7 +284,7 @@ def main():
 
     def max_vec(xs):
         """Element-wise MAX over ranks of a list of floats."""
-        if world_size == 1:
+        if world_size == 1 or solo[0]:
             return list(xs)
         t = torch.tensor(xs, dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=sync_group)
@@ -286,17 +294,20 @@ def main():
         s = sorted(xs)
         return s[len(s) // 2] if len(s) % 2 else 0.5 * (s[len(s) // 2 - 1] + s[len(s) // 2])
 
+    solo = [False]            # a measurement rank 0 takes ALONE (the others wait at a barrier): no collective inside
+
     def measure(N, B, mode, steps, warmup, chunk_req, other_steps=0, global_envs=None, policy=False):
         """Times blocks of `steps` env steps of N agents x B envs on this GPU in `mode` (and, if other_steps > 0,
         the other launch mode beside it).  global_envs: this rank owns its slice of a GLOBAL batch of that many envs
         (default: B per GPU, weak scaling).  policy: closed loop with the built-in controller (rollout_policy)."""
         # initial states: this rank owns the contiguous slice [lo, hi) of the global env range;
         # global env g is seeded 1 + 1000 g, so results do not depend on the GPU count
-        env, lo, hi = sharding.make_env_shard("formation_hd_env", N, global_envs or B * world_size, seed=1, rank=rank,
-                                              world_size=world_size, local_rank=local_rank)
+        ws = 1 if solo[0] else world_size
+        env, lo, hi = sharding.make_env_shard("formation_hd_env", N, global_envs or B * ws, seed=1, rank=0 if solo[0] else rank,
+                                              world_size=ws, local_rank=local_rank)
         B = hi - lo
-        if B > 65536:
-            env.scenario.reset_device(env.world, rng_offset=999)   # host MT19937 streams for > 65536 envs take minutes
+        if B * N > 4000000:
+            env.scenario.reset_device(env.world, rng_offset=999)   # host MT19937 streams: ~50 us per env and agent pair
         else:
             env.reset()
         env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device
@@ -307,6 +318,9 @@ def main():
         chunk = max(1, min(chunk_req, int(48e9 / gpu_share // max(1, B * N * 6 * N * 4)) or 1))
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
+        placed = {}
+        if a.placement_candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
+            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
         out = env._out
         act_pool, launchers = None, []
         if not policy:
@@ -361,7 +375,9 @@ def main():
                 cursor += n
                 cal[c_ + 1].record()
             torch.cuda.synchronize()
-            t1 = sharding.max_over_ranks(cal[1].elapsed_time(cal[4]) / 3.0, red_dev, sync_group)  # same value on every rank
+            t1 = cal[1].elapsed_time(cal[4]) / 3.0
+            if not solo[0]:
+                t1 = sharding.max_over_ranks(t1, red_dev, sync_group)   # same value on every rank
             R = int(min(4000, max(1, -(-a.min_timed_ms // max(t1, 1e-3)))))
             # the timed series: R consecutive blocks of exactly n steps, each delimited by HIP events on the launch
             # stream, the series bracketed by barrier + device synchronize.  The stream never idles between blocks
@@ -382,19 +398,25 @@ def main():
             barrier()
             local_blocks = [evs[r_].elapsed_time(evs[r_ + 1]) for r_ in range(R)]
             dev_blocks = max_vec(local_blocks)                 # per block: the slowest rank
-            wall_blocks = [sharding.max_over_ranks(wall, red_dev, sync_group) * 1e3 / R] * R
+            wall_blocks = [(wall if solo[0] else sharding.max_over_ranks(wall, red_dev, sync_group)) * 1e3 / R] * R
             return dev_blocks, wall_blocks, local_blocks
 
         seq = None
         if mode == "rollout" or other_steps > 0:
             f = dict(dtype=torch.float32, device=dev)
             pitch = a.obs_pitch if a.obs_pitch > 0 else (-(-6 * N * N // 32) * 32 if a.obs_pitch < 0 else 6 * N * N)
-            obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)
-            seq = dict(obs=obs_buf, reward=torch.empty((chunk, B, N), **f),
-                       indiv=torch.empty((chunk, B, N), **f),
-                       done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
-            if policy:
-                seq["act"] = torch.empty((chunk, B, N, 2), **f)
+            if a.obs_every == 1:
+                # the observation buffer is PLACED: candidates timed with this env's own launch, the fastest kept
+                seq = env.alloc_rollout_buffers(chunk, obs_env_pitch=0 if pitch == 6 * N * N else pitch, policy=policy,
+                                                candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
+                placed["rollout"] = env.placement
+            else:
+                obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)
+                seq = dict(obs=obs_buf, reward=torch.empty((chunk, B, N), **f),
+                           indiv=torch.empty((chunk, B, N), **f),
+                           done=torch.zeros((chunk, B, N), dtype=torch.uint8, device=dev))
+                if policy:
+                    seq["act"] = torch.empty((chunk, B, N, 2), **f)
         if policy:
             env.scenario.observe_batch(env.world, {"obs": out["obs"], "reward": out["reward"]})
             fns = {"step": run_policy_steps, "rollout": run_policy_rollout}
@@ -404,7 +426,7 @@ def main():
         bytes_per_env_step = _native.step_hd_bytes(N)
         med = median(dev_blocks)                                     # every block is already the MAX over ranks
         r = {"ms": med, "blocks": dev_blocks, "wall_blocks": wall_blocks, "local_ms": median(local_blocks),
-             "chunk": chunk, "B": B,
+             "chunk": chunk, "B": B, "placement": placed,
              "bytes_per_env_step": bytes_per_env_step, "extra": None,
              "GBps": bytes_per_env_step * B * steps / (med * 1e-3) / 1e9}
         if other_steps > 0:
@@ -442,6 +464,13 @@ def main():
                 "ms_per_step": round(m2["ms"] / st2, 5), "achieved_GBps": round(g, 1),
                 "frac_of_hbm_peak": round(g / HBM_PEAK_GBPS, 4), "other_mode": m2["extra"],
                 "state_finite": m2["finite"]}
+        if any(v and v.get("probed") for v in m2["placement"].values()):
+            line["placement"] = m2["placement"]
+        tr, src = measured_traffic(n2, m2["B"], mode, line["steps_per_launch"])
+        if tr:
+            alg = m2["bytes_per_env_step"] * m2["B"] * line["steps_per_launch"]
+            line["counter_to_algorithmic_bytes"] = round(tr / alg, 4)
+            line["traffic_source"] = src
         return line
 
     N, B = a.agents, a.envs
@@ -500,10 +529,28 @@ def main():
             ranks_ms = per_rank(m2["local_ms"])                   # each rank's own median block
             line["per_rank_ms_per_step"] = [round(x / st2, 5) for x in ranks_ms]
             line["slowest_rank"] = int(max(range(world_size), key=lambda r_: ranks_ms[r_]))
-            key = "%dx%d" % (n2, g2)
-            ref = n1_reference(key)
-            line["n1_env_steps_per_s"] = ref
+            # denominator of the scaling efficiency: the SAME global batch on ONE GPU, measured in THIS run on THIS
+            # node - at world_size 1 that is the line itself (efficiency 1.0 by construction); at world_size > 1 rank 0
+            # times it alone while the other ranks wait at the barrier (both global batches fit one 288 GB GPU)
+            if world_size == 1:
+                ref = line["env_steps_per_s"]
+            else:
+                ref_t = torch.zeros(1, dtype=torch.float64)
+                if rank == 0:
+                    solo[0] = True
+                    try:
+                        m1 = measure(n2, g2, a.mode, st2, max(2, st2 // 10), a.chunk, 0, global_envs=g2)
+                        ref_t[0] = g2 * st2 / (m1["ms"] * 1e-3)
+                    except Exception as exc:          # noqa: BLE001 - e.g. out of memory on a shared GPU: no denominator
+                        print("bench: N = 1 run of %d x %d failed: %r" % (n2, g2, exc), file=sys.stderr, flush=True)
+                    finally:
+                        solo[0] = False
+                dist.broadcast(ref_t, src=0)           # gloo group: also the barrier the other ranks wait at
+                ref = float(ref_t[0]) or None
+            line["n1_env_steps_per_s"] = round(ref, 1) if ref else None
+            line["n1_same_run"] = True
             line["scaling_efficiency_vs_n1"] = round(line["env_steps_per_s"] / (world_size * ref), 4) if ref else None
+            line["n1_other_box_r02"] = n1_reference("%dx%d" % (n2, g2))
             global_cfgs.append(line)
         if world_size == 1 and headline:
             c1 = config1(dev)
@@ -552,6 +599,8 @@ def main():
                          "frac_of_measured_copy_peak_6290": round(achieved / 6290.0, 4)},
             "state_finite": finite,
         }
+        if any(v and v.get("probed") for v in m["placement"].values()):
+            res["placement"] = m["placement"]
         if traffic:
             # the SURVEY 8(d) formula counts the pos/vel round trip of every step; a K-step launch keeps the state in
             # registers, so the PMC counters see fewer bytes (committed profile: ratio below); both are reported
@@ -581,7 +630,7 @@ def main():
                 res["cpu_baseline_other_shapes"] = []
                 for n2 in (9, 81, 243):
                     cb = cpu_baseline(n2, budget_s=4.0)
-                    res["cpu_baseline_other_shapes"].append({k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "agent_steps_per_s")}
+                    res["cpu_baseline_other_shapes"].append({k: cb[k] for k in ("value", "unit", "cores", "host_cores", "kind", "sample", "agent_steps_per_s")}
                                                             | {"agents": n2})
         print(json.dumps(res), flush=True)
     if world_size > 1:

@@ -43,6 +43,26 @@ __global__ __launch_bounds__(T) void reset_kernel(const Args a, const uint8_t* m
 }
 
 // ---------------------------------------------------------------------------
+// World.update_agent_state (core.py:279-286): state.c = action.c + c_noise * N(0,1), zeros for a silent agent
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void update_comm_kernel(const FgParams p, int B, int N, const float2* __restrict__ action_c,
+                                                          float2* __restrict__ comm) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * N) return;
+    const int b = (int)(t / N), i = (int)(t - (long long)b * N);
+    const float c_noise = p.agent_props ? p.agent_props[(size_t)i * FG_AGENT_PROPS + 5] : 0.0f;
+    float2 c = make_float2(0.f, 0.f);
+    if (c_noise >= 0.0f) {
+        c = action_c[t];
+        if (c_noise > 0.0f) {                                  // its own counter stream: agent index | 0x40000000
+            const real2 n = motor_noise(p.seed, (uint32_t)(b + p.env_index_base), (uint32_t)i | 0x40000000u, rng_base(p));
+            c.x += c_noise * n.x; c.y += c_noise * n.y;
+        }
+    }
+    comm[t] = c;
+}
+
+// ---------------------------------------------------------------------------
 // Bit-exact reset on device: Scenario.reset_world (formation_hd_env.py:77-95) drawing from the
 // env's own legacy NumPy MT19937 stream (environment.py:106-110 seeds it), so that multi-episode
 // rollouts keep matching the reference without a host round trip.  One workgroup per env; the
@@ -204,13 +224,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             }
             if (is_agent) {
                 const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
-                const float2 fa = action_force(a.p, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p));
+                const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p));   // uniform agents (no per-agent table in these scenarios)
                 fx += fa.x; fy += fa.y;
             }
             if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
             v.x = v.x * (1.0f - a.p.damping) + (fx / a.p.mass) * a.p.dt;
             v.y = v.y * (1.0f - a.p.damping) + (fy / a.p.mass) * a.p.dt;
-            if (is_agent) v = clamp_speed(a.p, v);
+            if (is_agent) v = clamp_speed(a.p.max_speed, v);
             p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
             POST[i] = p;
             if (is_agent) {

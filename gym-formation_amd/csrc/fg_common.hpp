@@ -73,6 +73,8 @@ struct KParams {
     FgWall walls[FG_MAX_WALLS];
     int32_t obs_env_pitch, env_index_base;
     const uint64_t* rng_offset_dev;
+    const double* agent_props;
+    const double* comm_state;
 };
 #else
 typedef FgParams KParams;
@@ -130,6 +132,8 @@ struct Args {
     // evaluated on the workgroup's own state instead of from `act`
     FgPolicyLevels pl;
     real* act_out;            // [K][B][N][2] the actions taken
+    real coll_scale;          // heterogeneous agents: collision-penalty distance of a pair = coll_scale * (size_a + size_b)
+                               // (= collide_thresh / dist_min of the uniform description, divided on the host)
 #ifdef FG_TRACE
     long long* trace;          // diagnostic build only (profiles/r02_trace.py): 8 realtime stamps (100 MHz) per workgroup
 #endif
@@ -271,22 +275,36 @@ FG_DEV real2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset)
     return make_real2(r * __cosf(a), r * __sinf(a));
 }
 
+// One agent's own properties (core.py:45-109): the World-wide scalars of FgParams, or its row of FgParams.agent_props
+struct AgentProps {
+    real mass, size, accel, max_speed, u_noise, sens;
+};
+FG_DEV AgentProps agent_props_of(const KParams& P, int i, bool in_range) {
+    AgentProps q = {P.mass, real(0.5f) * P.dist_min, P.accel, P.max_speed, P.u_noise, P.sensitivity};
+    if (P.agent_props && in_range) {
+        const auto* r = P.agent_props + (size_t)i * FG_AGENT_PROPS;
+        q.mass = r[0]; q.size = r[1]; q.accel = r[2]; q.max_speed = r[3]; q.u_noise = r[4];
+        q.sens = (q.accel > 0.0f) ? q.accel : P.sensitivity;               // environment.py:218-220
+    }
+    return q;
+}
+
 // action force incl. accel (core.py:236, environment.py:219-220) and motor noise (core.py:232-233)
-FG_DEV real2 action_force(const KParams& P, real2 u, uint32_t b, uint32_t i, uint64_t offset) {
-    const real gain = (P.accel > 0.0f) ? P.mass * P.accel : P.mass;
-    real2 f = make_real2(gain * (P.sensitivity * u.x), gain * (P.sensitivity * u.y));
-    if (P.u_noise > 0.0f) {
+FG_DEV real2 action_force(const KParams& P, const AgentProps& q, real2 u, uint32_t b, uint32_t i, uint64_t offset) {
+    const real gain = (q.accel > 0.0f) ? q.mass * q.accel : q.mass;
+    real2 f = make_real2(gain * (q.sens * u.x), gain * (q.sens * u.y));
+    if (q.u_noise > 0.0f) {
         const real2 n = motor_noise(P.seed, b, i, offset);
-        f.x += P.u_noise * n.x;
-        f.y += P.u_noise * n.y;
+        f.x += q.u_noise * n.x;
+        f.y += q.u_noise * n.y;
     }
     return f;
 }
 
-FG_DEV real2 clamp_speed(const KParams& P, real2 v) {                    // core.py:271-276
-    if (P.max_speed > 0.0f) {
+FG_DEV real2 clamp_speed(real max_speed, real2 v) {                      // core.py:271-276
+    if (max_speed > 0.0f) {
         const real speed = rsqrt_(v.x * v.x + v.y * v.y);
-        if (speed > P.max_speed) { v.x = v.x / speed * P.max_speed; v.y = v.y / speed * P.max_speed; }
+        if (speed > max_speed) { v.x = v.x / speed * max_speed; v.y = v.y / speed * max_speed; }
     }
     return v;
 }

@@ -81,6 +81,45 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
     return make_real2(fx, fy);
 }
 
+// The same sum for agents of different mass and size (FgParams.agent_props; no reference scenario has them): the
+// contact distance of a pair is size_i + size_j (core.py:307) and agent i receives force_ratio = m_j / m_i times the
+// pair's force (core.py:314-317: force_a = (m_b / m_a) f, force_b = -(m_a / m_b) f - for either role of i that is
+// (m_j / m_i) * contact_force * (p_i - p_j) / d * penetration).  Plain loop, ascending j as the reference accumulates.
+FG_DEV real2 contact_force_het(const real* __restrict__ QX, const real* __restrict__ QY, const real* __restrict__ MS,
+                               const real* __restrict__ SZ, int N, int i, real2 p, real m_i, real s_i, real cf, real kmargin) {
+    real fx = 0.0f, fy = 0.0f;
+    const real inv_k = 1.0f / kmargin;
+    const real inv_m = 1.0f / m_i;
+    const real far = (FG_F64 ? 40.0f : 18.0f) * kmargin;
+    for (int j = 0; j < N; ++j) {
+        const real dx = p.x - QX[j], dy = p.y - QY[j];
+        const real d2 = dx * dx + dy * dy;
+        const real dmin = s_i + SZ[j];
+        const real cut = dmin + far;
+        if (j != i && d2 < cut * cut) {
+            const real d = hw_sqrt(d2);
+            const real x = (dmin - d) * inv_k;
+            const real pen = kmargin * (rmax(x, real(0)) + hw_log(1.0f + hw_exp(-rabs(x))));
+            const real c = (MS[j] * inv_m) * (cf * pen * hw_rcp(d));
+            fx += dx * c;
+            fy += dy * c;
+        }
+    }
+    return make_real2(fx, fy);
+}
+
+// Scenario.is_collision with per-agent sizes (formation_hd_env.py:119-121): #{j != i : |p_j - p_i| < scale (size_i + size_j)}
+FG_DEV int collision_count_het(const real* __restrict__ PX, const real* __restrict__ PY, const real* __restrict__ SZ,
+                               int N, int i, real2 p, real s_i, real scale) {
+    int c = 0;
+    for (int j = 0; j < N; ++j) {
+        const real dx = PX[j] - p.x, dy = PY[j] - p.y;
+        const real t = scale * (s_i + SZ[j]);
+        c += (j != i && dx * dx + dy * dy < t * t) ? 1 : 0;
+    }
+    return c;
+}
+
 // Scenario.reward inner pass for agent i / ideal point i (formation_hd_env.py:61-75):
 //   rowmin = min_j |p~_i - s_j|^2,  colmin = min_j |p~_j - s_i|^2,  cnt = #{j != i : |p_j - p_i| < thr}
 template <bool IDX, int NPC = 0, int UNR = 2>

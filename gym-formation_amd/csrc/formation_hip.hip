@@ -51,16 +51,31 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 
 struct Geometry { int G, T, E, lds; };
 
-// A launch goes to the device its stream belongs to: if that is not the calling thread's current device (an env
-// living on cuda:1 driven from a thread whose current device is cuda:0), switch for the duration of the call.
-// The NULL stream means "the current device's default stream" and needs no switch.
+// A launch goes to the device its DATA lives on: if that is not the calling thread's current device (an env living
+// on cuda:1 driven from a thread whose current device is cuda:0), switch for the duration of the call.  A non-NULL
+// stream names its device; the NULL stream is "the default stream of whatever device is current", which says nothing
+// (torch hands out 0 for the default stream of EVERY device), so there the device is read off the first state pointer
+// (hipPointerGetAttributes).  A process that sees one GPU never pays for either query.
+static int visible_devices() {
+    static const int n = [] { int c = 0; return hipGetDeviceCount(&c) == hipSuccess ? c : 1; }();
+    return n;
+}
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
-    explicit DeviceGuard(void* stream) {
+    DeviceGuard(void* stream, const void* data) {
+        if (visible_devices() < 2) return;
+        int target = -1;
         hipDevice_t sdev = -1;
-        if (!stream || hipStreamGetDevice((hipStream_t)stream, &sdev) != hipSuccess) return;
-        if (hipGetDevice(&prev) == hipSuccess && prev != (int)sdev) switched = hipSetDevice((int)sdev) == hipSuccess;
+        if (stream) {
+            if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess) target = (int)sdev;
+        } else if (data) {
+            hipPointerAttribute_t attr;
+            if (hipPointerGetAttributes(&attr, data) == hipSuccess && attr.type == hipMemoryTypeDevice) target = attr.device;
+            else (void)hipGetLastError();                        // a host / unknown pointer: leave the error state clean
+        }
+        if (target < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != target) switched = hipSetDevice(target) == hipSuccess;
     }
     ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
     DeviceGuard(const DeviceGuard&) = delete;
@@ -88,6 +103,11 @@ static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
     const int n_split = a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16);
+    if (lds > 64 * 1024) {                 // run-time N close to 1024 (+ the per-agent tables of the OPTS instantiation)
+        static std::atomic<unsigned long long> raised{0};
+        const hipError_t err = raise_lds_limit((const void*)&step_kernel<NC, G, T, E, IDX, OPTS>, lds, &raised);
+        if (err != hipSuccess) return err;
+    }
 #if FG_SINGLE_STEP_VARIANTS
     // the single-step instantiation (no step loop, no slot arithmetic) of the plain variants from 27 agents up: 27 x 4096
     // 15.15 -> 15.03 us, 81 x 2048 -1 %; at 3 and 9 agents it is slower (profiles/r02_step/kone.txt)
@@ -133,11 +153,13 @@ static const Variant kVariants[] = {
 };
 
 // need_full: the launch wants the idx / opts instantiation (only the first entry of an agent count has them)
-static const Variant* variant_for(int N, int B = 0, bool need_full = false) {
+// generic: the run-time-N instantiation whatever N is (its flat observation writer is the one that knows the
+//          communication block of non-silent agents, FgParams.comm_state)
+static const Variant* variant_for(int N, int B = 0, bool need_full = false, bool generic = false) {
     if (N < 2 || N > FG_MAX_AGENTS) return nullptr;
     const Variant* best = nullptr;
     for (const Variant& v : kVariants) {
-        if (v.NC != N || B < v.min_B || (need_full && !v.opts)) continue;
+        if (generic || v.NC != N || B < v.min_B || (need_full && !v.opts)) continue;
         if (!best || v.min_B > best->min_B) best = &v;
     }
     if (best) return best;
@@ -147,8 +169,8 @@ static const Variant* variant_for(int N, int B = 0, bool need_full = false) {
     return nullptr;
 }
 
-static bool geometry_for(int N, Geometry* g, int B = 0, bool need_full = false) {
-    const Variant* v = variant_for(N, B, need_full);
+static bool geometry_for(int N, Geometry* g, int B = 0, bool need_full = false, bool generic = false) {
+    const Variant* v = variant_for(N, B, need_full, generic);
     if (!v) return false;
     g->G = v->G; g->T = v->T; g->E = v->E;
     g->lds = v->E * env_block_floats(N) * (int)sizeof(float) + 72 * (int)sizeof(float);
@@ -156,7 +178,7 @@ static bool geometry_for(int N, Geometry* g, int B = 0, bool need_full = false) 
 }
 
 static bool world_options_set(const FgParams& p) {
-    return p.num_walls > 0 || p.u_noise > 0.f || p.max_speed > 0.f || p.accel > 0.f;
+    return p.num_walls > 0 || p.u_noise > 0.f || p.max_speed > 0.f || p.accel > 0.f || p.agent_props || p.comm_state;
 }
 
 static int launch_step(Args a, hipStream_t st) {
@@ -166,8 +188,11 @@ static int launch_step(Args a, hipStream_t st) {
     Geometry g;
     const bool opts = world_options_set(a.p);
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
-    const Variant* v = variant_for(a.N, a.B, opts || idx);
-    if (!v || !geometry_for(a.N, &g, a.B, opts || idx)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    const bool generic = a.p.comm_state != nullptr;
+    const Variant* v = variant_for(a.N, a.B, opts || idx, generic);
+    if (!v || !geometry_for(a.N, &g, a.B, opts || idx, generic)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
+    if (opts) g.lds += (2 * npad(a.N) + 2 * g.E * a.N) * (int)sizeof(float);    // per-agent mass / size, per-env comm states
+    a.coll_scale = (float)((double)a.p.collide_thresh / (double)a.p.dist_min);
     const int grid = (a.B + g.E - 1) / g.E;
     // Split step: more than 64 agents (one env per workgroup) and fewer envs than half the chip's CUs.  One workgroup per
     // env would leave most CUs idle during the observation stream, which is 99 % of the bytes; so the fused kernel runs
@@ -184,7 +209,7 @@ static int launch_step(Args a, hipStream_t st) {
         Args a2 = a;
         a2.do_phys = 0; a2.obs_only = 1; a2.split = S; a2.p.auto_reset = 0;
         a2.rew = nullptr; a2.indiv = nullptr; a2.done = nullptr; a2.near_lm = nullptr; a2.near_ag = nullptr; a2.hd_idx = nullptr;
-        err = v->plain(a2, grid * S, g.lds, st);
+        err = (generic ? v->opts : v->plain)(a2, grid * S, g.lds, st);   // the communication block lives in the OPTS instantiation
         if (err != hipSuccess) return fail(FG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(err));
         return FG_OK;
     }
@@ -288,6 +313,9 @@ static int check_params(const FgParams* p) {
         return fail(FG_ERR_BAD_ARG, "params: mass, contact_margin and dt must be > 0%s");
     if (p->num_walls < 0 || p->num_walls > FG_MAX_WALLS || p->accel < 0.f || p->max_speed < 0.f || p->u_noise < 0.f)
         return fail(FG_ERR_BAD_ARG, "params: 0 <= num_walls <= 4, accel/max_speed/u_noise >= 0%s");
+    if (!(p->dist_min > 0.f)) return fail(FG_ERR_BAD_ARG, "params: dist_min must be > 0%s");
+    if (((uintptr_t)p->agent_props & 3u) || ((uintptr_t)p->comm_state & 7u))
+        return fail(FG_ERR_ALIGNMENT, "params: agent_props must be 4-byte, comm_state 8-byte aligned%s");
     return FG_OK;
 }
 
@@ -317,7 +345,7 @@ int fg_step_hd(const FgParams* params, int B, int N,
                const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
                float* obs, float* reward, float* indiv_reward, uint8_t* done,
                int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -345,7 +373,7 @@ int fg_step_hd(const FgParams* params, int B, int N,
 int fg_physics_step(const FgParams* params, int B, int N,
                     float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                     const float* act, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -366,7 +394,7 @@ int fg_observe_hd(const FgParams* params, int B, int N,
                   const float* ideal_shape, const float* ideal_vel, const int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -394,7 +422,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
                   const float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
                   float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
                   int obs_every, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0 || K == 0) return FG_OK;               // empty batch / zero steps: nothing to do
@@ -424,7 +452,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
 int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
                 float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                 float* ideal_shape, float* ideal_vel, int32_t* step, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
@@ -458,10 +486,12 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
                            const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
                            int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                            int32_t* near_ag, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (!sc) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
+    if (params->agent_props || params->comm_state)
+        return fail(FG_ERR_BAD_ARG, "agent_props / comm_state are honoured by the formation_hd_env entry points only%s");
     const int L = sc->num_landmarks, M = sc->num_obstacles;
     if (sc->kind < FG_SCN_BASIC || sc->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
     if (B == 0) return FG_OK;
@@ -509,7 +539,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
 int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                    float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
@@ -520,6 +550,24 @@ int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                        pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "mt reset launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, float* comm_state, void* stream) {
+    const DeviceGuard device_guard(stream, comm_state);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B == 0) return FG_OK;
+    if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
+    if (N < 1 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [1, 1024]%s");
+    if (!action_c || !comm_state) return fail(FG_ERR_BAD_ARG, "fg_update_comm: a required pointer is NULL%s");
+    if (((uintptr_t)action_c & 7u) || ((uintptr_t)comm_state & 7u))
+        return fail(FG_ERR_ALIGNMENT, "action_c and comm_state must be 8-byte aligned%s");
+    const long long count = (long long)B * N;
+    hipLaunchKernelGGL(update_comm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       *params, B, N, reinterpret_cast<const float2*>(action_c), reinterpret_cast<float2*>(comm_state));
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "comm launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
 
@@ -561,7 +609,7 @@ static int launch_policy_state(int B, int N, const FgPolicyLevels& pl, const flo
 
 int fg_policy_bfs_state(int B, int N, int per_layer, const float* pos_x, const float* pos_y,
                         const float* ideal_shape, const float* ideal_vel, float* act, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     if (B == 0) return FG_OK;
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
@@ -580,7 +628,7 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
                          float* act_seq, float* ideal_shape, float* ideal_vel, int32_t* step,
                          float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
                          int obs_every, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (B == 0 || K == 0) return FG_OK;
@@ -629,7 +677,7 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
 }
 
 int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, obs);
     if (B == 0) return FG_OK;
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
@@ -655,7 +703,7 @@ int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env
 }
 
 int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void* stream) {
-    const DeviceGuard device_guard(stream);
+    const DeviceGuard device_guard(stream, u_out);
     if (mode != FG_ACT_ONEHOT5 && mode != FG_ACT_INDEX && mode != FG_ACT_ARGMAX)
         return fail(FG_ERR_BAD_ARG, "fg_decode_actions: unknown mode%s");
     if (count == 0) return FG_OK;

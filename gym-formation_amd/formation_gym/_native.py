@@ -14,8 +14,9 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_WALLS = 4
+AGENT_PROPS = 6                 # floats per row of FgParams.agent_props: mass, size, accel, max_speed, u_noise, c_noise
 
 FG_OK = 0
 FG_ERR_BAD_ARG = -1
@@ -53,6 +54,8 @@ class FgParams(ctypes.Structure):
         ("obs_env_pitch", ctypes.c_int32),
         ("env_index_base", ctypes.c_int32),
         ("rng_offset_dev", ctypes.c_void_p),
+        ("agent_props", ctypes.c_void_p),       # device float [N][AGENT_PROPS] or NULL (uniform agents)
+        ("comm_state", ctypes.c_void_p),        # device float [B][N][2] or NULL (silent agents)
     ]
 
 
@@ -101,6 +104,7 @@ SIGNATURES = {
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
+    "fg_update_comm": (_I, [_PP, _I, _I, _P, _P, _P]),
     "fg_policy_bfs": (_I, [_I, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "fg_policy_bfs_state": (_I, [_I, _I, _I] + [_P] * 6),
     "fg_rollout_hd_policy": (_I, [_PP, _I, _I, _I, _I] + [_P] * 12 + [_I, _P]),

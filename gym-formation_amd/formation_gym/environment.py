@@ -98,6 +98,7 @@ class MultiAgentEnv(object):
             self._act_host = torch.zeros((1, N, 2), dtype=torch.float32).pin_memory()
         self._launchers = {}              # pre-bound step launches, see _bound_step
         self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
+        self.placement = None             # report of the last buffer placement probe (alloc_rollout_buffers)
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -189,8 +190,9 @@ class MultiAgentEnv(object):
         bind = getattr(self.scenario, "bind_rollout", None)
         key = None
         if own_buffers and bind is not None and all(k in out for k in ("obs", "reward", "indiv", "done")):
-            key = ("roll", act.data_ptr(), K, out["obs"].data_ptr(), out["reward"].data_ptr(), out["indiv"].data_ptr(),
-                   out["done"].data_ptr(), obs_every, self.auto_reset, _native.current_stream_fast(self.world.device),
+            key = ("roll", act.data_ptr(), K, out["obs"].data_ptr(), tuple(out["obs"].stride()), out["reward"].data_ptr(),
+                   out["indiv"].data_ptr(), out["done"].data_ptr(), obs_every, self.auto_reset,
+                   _native.current_stream_fast(self.world.device),
                    self.world.params_signature(), getattr(self.scenario, "_seed", 0))
         launch = self._roll_launchers.get(key) if key is not None else None
         if launch is None:
@@ -243,7 +245,8 @@ class MultiAgentEnv(object):
         bind = getattr(self.scenario, "bind_rollout_policy", None)
         key = None
         if own_buffers and bind is not None and all(k in out for k in want):
-            key = ("pol", K, int(num_agents_per_layer), tuple(out[k].data_ptr() for k in sorted(want)), obs_every,
+            key = ("pol", K, int(num_agents_per_layer), tuple(out[k].data_ptr() for k in sorted(want)),
+                   tuple(out["obs"].stride()), obs_every,
                    self.auto_reset, _native.current_stream_fast(self.world.device), self.world.params_signature(),
                    getattr(self.scenario, "_seed", 0))
         launch = self._roll_launchers.get(key) if key is not None else None
@@ -268,6 +271,118 @@ class MultiAgentEnv(object):
         rew = out["reward"] if self.shared_reward else out["indiv"]
         return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), \
             {"individual_reward": out["indiv"], "actions": out["act"]}
+
+    # ------------------------------------------------------------ buffers
+    def _snapshot(self):
+        """Everything a launch mutates (device state + host counters), for probes that must leave the env untouched."""
+        w, sc = self.world, self.scenario
+        dev = {k: getattr(w, k).clone() for k in ("pos_x", "pos_y", "vel_x", "vel_y", "step_count")}
+        scn = {k: getattr(sc, k).clone() for k in ("ideal_shape", "ideal_vel") if torch.is_tensor(getattr(sc, k, None))}
+        ctr = None if w.rng_counter is None else w.rng_counter.clone()
+        return dev, scn, ctr, (self._rng_offset, self.current_step, w.world_step)
+
+    def _restore(self, snap):
+        dev, scn, ctr, host = snap
+        w, sc = self.world, self.scenario
+        for k, v in dev.items():
+            getattr(w, k).copy_(v)
+        for k, v in scn.items():
+            getattr(sc, k).copy_(v)
+        if ctr is not None:
+            w.rng_counter.copy_(ctr)
+        self._rng_offset, self.current_step, w.world_step = host
+        sc._cache = None
+
+    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=4, mem_fraction=0.5):
+        """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
+        the bytes - PLACED: when it is larger than the Infinity Cache, up to `candidates` allocations are made, this
+        env's own K-step launch is timed on each and the fastest is kept (formation_gym/placement.py; the rate of a
+        launch depends on the allocation it streams into by up to 15 %).  The env's state is restored afterwards.
+        `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report is left in
+        `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`."""
+        from . import placement
+        K, obs_every = int(K), int(obs_every)
+        B, N = self.num_envs, self.num_agents
+        D = self._out["obs"].shape[-1]
+        dev = self._act.device
+        f = dict(dtype=torch.float32, device=dev)
+        slots = K // obs_every
+        pitch = int(obs_env_pitch) if obs_env_pitch else N * D
+        if pitch < N * D or pitch % 2:
+            raise ValueError("obs_env_pitch must be 0 or an even number of floats >= %d" % (N * D))
+        small = dict(reward=torch.empty((K, B, N), **f), indiv=torch.empty((K, B, N), **f),
+                     done=torch.zeros((K, B, N), dtype=torch.uint8, device=dev))
+        if policy:
+            small["act"] = torch.empty((K, B, N, 2), **f)
+
+        def alloc():
+            return torch.empty((slots, B, pitch), **f)[:, :, :N * D].view(slots, B, N, D)
+
+        nbytes = slots * B * pitch * 4
+        if slots == 0 or nbytes < placement.MIN_PROBE_BYTES or candidates < 2:
+            self.placement = {"tried": 1, "probed": False}
+            return dict(small, obs=alloc())
+        snap = self._snapshot()
+        acts = None if policy else torch.zeros((K, B, N, 2), **f)
+
+        def time_fn(obs):
+            out = dict(small, obs=obs)
+            if policy:
+                self.rollout_policy(K, 3, out=out, obs_every=obs_every)
+            else:
+                self.rollout(acts, out=out, obs_every=obs_every)
+
+        obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
+        self._roll_launchers.clear()                   # bindings made on the candidates keep them alive: drop them,
+        torch.cuda.empty_cache()                       # then hand the losers back to the driver
+        self._restore(snap)
+        report["buffer_MB"] = round(nbytes / 1e6, 1)
+        if report.get("probed"):
+            alg = _native.step_hd_bytes(N) * B * K if hasattr(_native, "step_hd_bytes") and D == 6 * N else None
+            if alg:
+                report["kept_GBps"] = round(alg / (report["kept_ms"] * 1e-3) / 1e9, 1)
+                report["worst_GBps"] = round(alg / (report["worst_ms"] * 1e-3) / 1e9, 1)
+        self.placement = report
+        return dict(small, obs=obs)
+
+    def place_step_buffers(self, candidates=4, mem_fraction=0.5):
+        """The same probe for the per-step output buffer `step` writes into (only batches whose single-step
+        observation tensor exceeds the Infinity Cache: 243 agents x >= 200 envs, 81 x >= 1700, 27 x >= 15 000)."""
+        from . import placement
+        B, N = self.num_envs, self.num_agents
+        obs_dim = self._out["obs"].shape[-1]
+        n_obs, n_bn = B * N * obs_dim, B * N
+        nflat = n_obs + 2 * n_bn + (n_bn + 3) // 4
+        dev = self._act.device
+        if n_obs * 4 < placement.MIN_PROBE_BYTES or candidates < 2:
+            self.placement = {"tried": 1, "probed": False}
+            return self.placement
+        extra = {k: v for k, v in self._out.items() if k not in ("obs", "reward", "indiv", "done")}
+
+        def views(flat):
+            return dict(extra, obs=flat[:n_obs].view(B, N, obs_dim), reward=flat[n_obs:n_obs + n_bn].view(B, N),
+                        indiv=flat[n_obs + n_bn:n_obs + 2 * n_bn].view(B, N),
+                        done=flat[n_obs + 2 * n_bn:].view(torch.uint8)[:n_bn].view(B, N))
+
+        snap = self._snapshot()
+        old_flat, self._flat, self._out = self._flat, None, None
+        del old_flat
+        torch.cuda.empty_cache()
+        act = torch.zeros_like(self._act)
+
+        def alloc():
+            return torch.zeros(nflat, dtype=torch.float32, device=dev)
+
+        def time_fn(flat):
+            self.scenario.step_batch(self.world, act, views(flat), auto_reset=self.auto_reset, rng_offset=1)
+
+        flat, report = placement.probe_allocation(alloc, time_fn, nflat * 4, dev, candidates=candidates, mem_fraction=mem_fraction)
+        self._flat, self._out = flat, views(flat)
+        self._launchers.clear()
+        self._restore(snap)
+        report["buffer_MB"] = round(nflat * 4 / 1e6, 1)
+        self.placement = report
+        return report
 
     def use_device_rng_counter(self, on=True):
         """Keep the per-step offset of the device counter RNG (auto-reset draws, motor noise) in DEVICE memory

@@ -71,14 +71,17 @@ class Scenario(BaseScenario):
         N, L = len(world.agents), len(world.landmarks)
         return 4 + 2 * L + 4 * (N - 1)
 
-    def params(self, world):
+    def params(self, world, rng_offset=0):
         a0 = world.agents[0]
-        return world.native_params(collide_thresh=a0.size + a0.size)     # :91
+        p = world.native_params(collide_thresh=a0.size + a0.size, seed=self._seed, rng_offset=rng_offset)     # :91
+        # the device counter RNG (motor noise) is keyed by seed, GLOBAL env index and the per-step offset, like formation_hd_env's
+        p.env_index_base = int(getattr(self, "env_base", 0))
+        return p
 
-    def _launch(self, world, act, out, do_physics):
+    def _launch(self, world, act, out, do_physics, rng_offset=0):
         lib = _native.load()
         _native.check(lib.fg_step_basic(
-            self.params(world), world.num_envs, len(world.agents), len(world.landmarks),
+            self.params(world, rng_offset), world.num_envs, len(world.agents), len(world.landmarks),
             1 if do_physics else 0,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
@@ -102,6 +105,7 @@ class Scenario(BaseScenario):
         keep = (act, out)
 
         def launch(rng_offset=0):
+            p.rng_offset = rng_offset
             rc = fn(p, *args)
             if rc:
                 _native.check(rc)
@@ -112,7 +116,7 @@ class Scenario(BaseScenario):
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
         if auto_reset:
             raise NotImplementedError("device auto-reset is built for formation_hd_env only")
-        self._launch(world, act, out, True)
+        self._launch(world, act, out, True, rng_offset)
 
     def observe_batch(self, world, out):
         self._launch(world, None, out, False)

@@ -102,9 +102,12 @@ class LandmarkScenario(BaseScenario):
         nbr = self.num_obs if self.KIND == _native.FG_SCN_PARTIAL else N - 1
         return 2 + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1)
 
-    def params(self, world):
+    def params(self, world, rng_offset=0):
         a0 = world.agents[0]
-        return world.native_params(collide_thresh=a0.size + a0.size)      # is_collision: size_a + size_b
+        p = world.native_params(collide_thresh=a0.size + a0.size, seed=self._seed, rng_offset=rng_offset)      # is_collision: size_a + size_b
+        # the device counter RNG (motor noise) is keyed by seed, GLOBAL env index and the per-step offset, like formation_hd_env's
+        p.env_index_base = int(getattr(self, "env_base", 0))
+        return p
 
     def descriptor(self):
         return _native.FgScenario(kind=self.KIND, num_landmarks=self.num_landmarks,
@@ -113,11 +116,11 @@ class LandmarkScenario(BaseScenario):
                                   obstacle_vx=self.OBSTACLE_VEL[0], obstacle_vy=self.OBSTACLE_VEL[1],
                                   obstacle_floor=self.OBSTACLE_FLOOR, penalty=self.PENALTY)
 
-    def _launch(self, world, act, out, do_physics):
+    def _launch(self, world, act, out, do_physics, rng_offset=0):
         lib = _native.load()
         M = self.num_obstacles
         _native.check(lib.fg_step_scenario(
-            self.params(world), self.descriptor(), world.num_envs, len(world.agents), 1 if do_physics else 0,
+            self.params(world, rng_offset), self.descriptor(), world.num_envs, len(world.agents), 1 if do_physics else 0,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(),
             world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
@@ -146,6 +149,7 @@ class LandmarkScenario(BaseScenario):
         keep = (act, out)
 
         def launch(rng_offset=0):
+            p.rng_offset = rng_offset
             rc = fn(p, d, *args)
             if rc:
                 _native.check(rc)
@@ -157,7 +161,7 @@ class LandmarkScenario(BaseScenario):
         if auto_reset:
             raise NotImplementedError("device auto-reset is built for formation_hd_env only; "
                                       "use FormationVecEnv(reset_mode='host')")
-        self._launch(world, act, out, True)
+        self._launch(world, act, out, True, rng_offset)
 
     def observe_batch(self, world, out):
         self._launch(world, None, out, False)

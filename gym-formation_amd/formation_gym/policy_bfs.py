@@ -67,8 +67,9 @@ def get_action_BFS(policy, obs, num_agents_per_layer):
     `policy` must be batched when a tensor is given (`ezpolicy` is)."""
     per = int(num_agents_per_layer)
     ref_style = not torch.is_tensor(obs)
-    if not ref_style and policy is ezpolicy and obs.is_cuda:
-        return bfs_actions(obs, per)
+    if (not ref_style and policy is ezpolicy and obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 3
+            and 2 <= per <= 8 and obs.shape[1] >= 3):
+        return bfs_actions(obs, per)               # anything else (float64, wider hierarchies): the tensor path below
     o = torch.as_tensor(np.asarray(obs, dtype=np.float64))[None] if ref_style else obs
     B, N, D = o.shape
     layers = math.log(N) / math.log(per)

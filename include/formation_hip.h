@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 5
+#define FG_ABI_VERSION 6
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -117,7 +117,26 @@ typedef struct FgParams {
                                 caller that replays a captured hipGraph keeps its per-step offset here and advances it
                                 with a device-side add between launches, since by-value arguments are frozen in a graph.
                                 The library only reads it. */
+    const float* agent_props;  /* optional DEVICE table float [N][FG_AGENT_PROPS], one row per agent (NULL = every agent
+                                takes the scalars above - all the reference's scenarios):
+                                  [0] mass       Entity.initial_mass, core.py:68-75: contact forces are scaled by
+                                                 force_ratio = m_b / m_a (core.py:314-317), velocity gains F / m (:270)
+                                  [1] size       Entity.size: contact distance of a pair = size_a + size_b (core.py:307),
+                                                 collision penalty distance = collide_thresh / dist_min * (size_a + size_b)
+                                                 (formation_hd_env.py:119-121), wall contact (core.py:340-344)
+                                  [2] accel      Entity.accel (0 = None): core.py:236, environment.py:219-220
+                                  [3] max_speed  Entity.max_speed (0 = None): core.py:271-276
+                                  [4] u_noise    Agent.u_noise (0 = None): core.py:232-233
+                                  [5] c_noise    Agent.c_noise for fg_update_comm (0 = None; < 0 = a silent agent)
+                                With a table, `sensitivity` is the value for agents whose accel is None (5.0) and
+                                mass / dist_min / accel / max_speed / u_noise above are not read.  Honoured by
+                                fg_step_hd, fg_physics_step, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy. */
+    const float* comm_state;   /* optional DEVICE float [B][N][2] = AgentState.c of every agent (World.dim_c = 2): copied
+                                into the communication block of the observation, row i = c_j for j != i in index order
+                                (formation_hd_env.py:48-51,59); NULL = zeros, the silent agents of every reference
+                                scenario (core.py:281-282).  Honoured by fg_step_hd, fg_observe_hd, fg_rollout_hd. */
 } FgParams;
+#define FG_AGENT_PROPS 6
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:
  *   kind            which Scenario file under formation_gym/envs/
@@ -208,6 +227,12 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
 int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                    float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream);
+
+/* World.update_agent_state (core.py:279-286) for all B x N agents: state.c = action.c + c_noise * N(0,1) for a
+ * non-silent agent, zeros for a silent one (agent_props[i][5] < 0; without a table every agent is non-silent and
+ * noise-free).  dim_c = 2.  action_c, comm_state float [B][N][2]; the noise comes from the device counter RNG
+ * (seed, env_index_base + b, agent, rng_offset: distributional parity, the reference draws np.random.randn). */
+int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, float* comm_state, void* stream);
 
 /* MultiAgentEnv.step for basic_formation_env (BASELINE config 1):
  * same physics; observation basic_formation_env.py:29-41, reward :43-52.

@@ -43,9 +43,29 @@ def main(src, dst):
         if not f:
             continue
         vals = sorted(float(r["Counter_Value"]) for r in csv.DictReader(open(f[0]))
-                      if "fg::" in r["Kernel_Name"] and r["Counter_Name"] == name)
+                      if "fg::" in r["Kernel_Name"] and r["Counter_Name"] == name
+                      and (not kernels or r["Kernel_Name"] == max(kernels, key=lambda k: k["pct"])["name"]))
         if vals:
             out[name + "_KiB_per_launch_median"] = vals[len(vals) // 2]
+    # every other counter pass (profiles/r03_wide_pmc.sh: pmc_<name>/): median per launch of the dominant fg:: kernel
+    dominant = max(kernels, key=lambda k: k["pct"])["name"] if kernels else None
+    counters = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d) or os.path.basename(d) in ("pmc_fetch", "pmc_write"):
+            continue
+        per = {}
+        for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if dominant is None or r["Kernel_Name"] == dominant:
+                    per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for name, vals in per.items():
+            vals.sort()
+            counters[name] = vals[len(vals) // 2]
+    if counters:
+        out["dominant_kernel"] = dominant
+        out["counters_per_launch_median"] = counters
+        if counters.get("TCC_EA0_WRREQ_sum"):
+            out["full_64B_write_request_ratio"] = round(counters.get("TCC_EA0_WRREQ_64B_sum", 0.0) / counters["TCC_EA0_WRREQ_sum"], 5)
     if "FETCH_SIZE_KiB_per_launch_median" in out and "WRITE_SIZE_KiB_per_launch_median" in out:
         out["hbm_traffic_bytes_per_launch"] = int(1024 * (2 * out["FETCH_SIZE_KiB_per_launch_median"]
                                                           + out["WRITE_SIZE_KiB_per_launch_median"]))
@@ -58,9 +78,10 @@ def main(src, dst):
         json.dump(out, f, indent=1)
     with open(dst + ".md", "w") as f:
         f.write("# rocprofv3 summary: %s\n\n" % out["source"])
-        f.write("command: `bash profiles/run_profile.sh <tag>` = rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE and\n"
-                "--pmc WRITE_SIZE in separate passes, each around `python3 bench.py --steps 300 --warmup 50\n"
-                "--no-cpu-baseline --no-extra` (27 agents x 4096 envs), then an un-profiled bench run.\n\n")
+        wl = out.get("bench", {}).get("config", {}).get("workload", "27 agents x 4096 envs")
+        f.write("command: `bash profiles/run_profile.sh <tag>` (or `profiles/r03_wide_pmc.sh`) = rocprofv3 --kernel-trace --stats, then\n"
+                "--pmc passes (FETCH_SIZE, WRITE_SIZE, ... each in its own run), each around a short `python3 bench.py\n"
+                "--no-cpu-baseline --no-extra` of the workload (%s), then an un-profiled bench run.\n\n" % wl)
         f.write("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|\n")
         for k in kernels:
             f.write("| `%s` | %d | %.2f | %.2f | %.2f | %.1f |\n" % (k["name"], k["calls"], k["avg_us"], k["min_us"], k["max_us"], k["pct"]))

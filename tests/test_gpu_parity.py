@@ -464,9 +464,12 @@ def test_bench_json_contract_single_and_two_ranks():
     ranks, sharded seeds, GLOBAL-batch configs) is exercised with two gloo ranks sharing this GPU."""
     import json
     line = [l for l in _run(["bench.py", "--steps", "30", "--warmup", "5", "--envs", "512", "--agents", "9",
-                             "--no-cpu-baseline"]).splitlines() if l.startswith("{")]
+                             "--no-cpu-baseline", "--global-div", "64"]).splitlines() if l.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
+    # one GPU: the scaling efficiency of the GLOBAL-batch configs is 1.0 by construction (same-run denominator)
+    assert [g["scaling_efficiency_vs_n1"] for g in d["global_configs"]] == [1.0, 1.0]
+    assert all(g["n1_same_run"] and g["n1_env_steps_per_s"] == g["env_steps_per_s"] for g in d["global_configs"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "timing"):
         assert k in d
@@ -497,7 +500,8 @@ def test_bench_json_contract_single_and_two_ranks():
         assert g["slowest_rank"] in (0, 1) and g["state_finite"] and g["test_scale_div"] == 64
         assert abs(g["env_steps_per_s"] - n_env / (g["ms_per_step"] * 1e-3)) < 2e-3 * g["env_steps_per_s"]
         assert abs(g["agent_steps_per_s"] - n_ag * g["env_steps_per_s"]) < 1e-3 * g["agent_steps_per_s"]
-        assert "scaling_efficiency_vs_n1" in g
+        # the denominator is the same global batch timed by rank 0 alone in the same run
+        assert g["n1_same_run"] and g["n1_env_steps_per_s"] > 0 and 0.1 < g["scaling_efficiency_vs_n1"] < 3.0
     # default backend (nccl = RCCL) with more ranks than GPUs: RCCL cannot form a communicator over duplicate devices, so
     # bench.py keeps the timing barrier on gloo without trying (decided from the device count, same on every rank)
     out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
