@@ -75,13 +75,21 @@ class EntityState(object):
 
 
 class AgentState(EntityState):
-    """Adds the communication utterance `c` (core.py:12-16).  All scenarios of
-    the reference set `silent=True`, so `c` is identically zero (core.py:281-282)."""
+    """Adds the communication utterance `c` (core.py:12-16): [B, dim_c], row `index` of `World.comm_c`.  All scenarios
+    of the reference set `silent=True`, so `c` is identically zero there (core.py:281-282); a non-silent agent's `c` is
+    what `World.step()` made of its `action.c` (core.py:284-286)."""
 
     @property
     def c(self):
         w = self._world
+        if w.comm_c is not None:
+            return w.comm_c[:, self._index]
         return torch.zeros((w.num_envs, w.dim_c), dtype=torch.float32, device=w.device)
+
+    @c.setter
+    def c(self, value):
+        w = self._world
+        w.ensure_comm()[0][:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
 
 class Action(object):
@@ -90,7 +98,19 @@ class Action(object):
     def __init__(self, world=None, index=None):
         self._world = world
         self._index = index
-        self.c = None
+
+    @property
+    def c(self):
+        """Communication action [B, dim_c] (row of `World.action_c`); None until somebody sets one."""
+        w = self._world
+        return None if w is None or w.action_c is None else w.action_c[:, self._index]
+
+    @c.setter
+    def c(self, value):
+        w = self._world
+        if w is None or value is None:
+            return
+        w.ensure_comm()[1][:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
     @property
     def u(self):
@@ -194,6 +214,9 @@ class World(object):
         self.landmark_pos = None
         self.obstacle_pos = None          # movable colliding landmarks (formation_hd_obs_env)
         self.obstacle_vel = None
+        self.comm_c = None                # AgentState.c of all agents [B, N, dim_c]; allocated with the first non-silent agent
+        self.action_c = None              # Action.c [B, N, dim_c]
+        self._props = None                # (signature, device table [N, 6]) of heterogeneous agents
         self.scenario = None
 
     # ---- reference-compatible views --------------------------------------
@@ -240,6 +263,36 @@ class World(object):
             l.i = N + i
             l.state = EntityState(self, "landmark", i) if i < L else EntityState(self, "obstacle", i - L)
 
+    def ensure_comm(self):
+        """(comm_c, action_c): the communication state / action tensors [B, N, dim_c], allocated on first use."""
+        if self.comm_c is None:
+            if self.dim_c != 2:
+                raise NotImplementedError("communication of non-silent agents is built for dim_c = 2 (every scenario "
+                                          "file of the reference), got %d" % self.dim_c)
+            f = dict(dtype=torch.float32, device=self.device)
+            self.comm_c = torch.zeros((self.num_envs, len(self.agents), self.dim_c), **f)
+            self.action_c = torch.zeros((self.num_envs, len(self.agents), self.dim_c), **f)
+        return self.comm_c, self.action_c
+
+    def any_non_silent(self):
+        return any(not a.silent for a in self.agents)
+
+    def agent_props(self):
+        """Device table float [N, 6] = (mass, size, accel, max_speed, u_noise, c_noise) per agent for
+        `FgParams.agent_props`, or None while all agents are alike (then the scalars of FgParams say it all).
+        accel / max_speed / u_noise / c_noise: 0 = None; c_noise < 0 marks a silent agent (`fg_update_comm`)."""
+        rows = [(float(a.mass), float(a.size), float(a.accel or 0.0), float(a.max_speed or 0.0), float(a.u_noise or 0.0),
+                 -1.0 if a.silent else float(a.c_noise or 0.0)) for a in self.agents]
+        alike = len({r[:5] for r in rows}) == 1
+        if alike and not self.any_non_silent():
+            return None
+        if alike and all(r[5] == rows[0][5] for r in rows) and rows[0][5] == 0.0:
+            return None                                   # everybody non-silent, noise-free: the library's default
+        sig = tuple(rows)
+        if self._props is None or self._props[0] != sig:
+            self._props = (sig, torch.tensor(rows, dtype=torch.float32, device=self.device), alike)
+        return self._props[1]
+
     def set_state(self, pos=None, vel=None):
         """Upload [B,N,2] positions / velocities (any array-like, or a tensor on any device) into the SoA tensors."""
         def as_dev(x):
@@ -261,22 +314,20 @@ class World(object):
     def native_params(self, sensitivity=5.0, collide_thresh=0.0, auto_reset=False, seed=0, rng_offset=0):
         """FgParams for the C ABI from this world's constants (uniform agents)."""
         a0 = self.agents[0]
-        sizes = {a.size for a in self.agents}
-        masses = {a.mass for a in self.agents}
-        if len(sizes) != 1 or len(masses) != 1:
-            raise NotImplementedError("kernels assume identical agent size and mass")
         for a in self.agents:
             if not a.movable or not a.collide or a.ghost:
                 raise NotImplementedError("immovable / non-colliding / ghost agents do not occur in the "
                                           "reference scenarios and are not built")
-        opts = {(a.max_speed, a.accel, a.u_noise) for a in self.agents}
-        if len(opts) != 1:
-            raise NotImplementedError("kernels assume identical max_speed / accel / u_noise for all agents")
+        # agents that differ in mass / size / accel / max_speed / u_noise (core.py:45-109): a per-agent table; the
+        # scalars below then only carry agent 0's contact distance (the scale of collide_thresh) and the sensitivity
+        # of agents without an accel of their own
+        props = self.agent_props()
+        hetero = props is not None and not self._props[2]
         if len(self.walls) > _native.MAX_WALLS:
             raise NotImplementedError("at most %d walls" % _native.MAX_WALLS)
         if any(not w.hard for w in self.walls):
             raise NotImplementedError("soft walls only matter for ghost entities, which are not built")
-        sens = a0.accel if a0.accel is not None else sensitivity     # environment.py:218-220
+        sens = a0.accel if (a0.accel is not None and not hetero) else sensitivity     # environment.py:218-220
         p = _native.FgParams(
             dt=self.dt, damping=self.damping, contact_force=self.contact_force,
             contact_margin=self.contact_margin, sensitivity=sens, mass=a0.mass,
@@ -288,6 +339,8 @@ class World(object):
         counter = self.rng_counter               # MultiAgentEnv.use_device_rng_counter
         if counter is not None:
             p.rng_offset_dev = counter.data_ptr()
+        if hetero:
+            p.agent_props = props.data_ptr()
         for k, w in enumerate(self.walls):
             p.walls[k] = _native.FgWall(vertical=0 if w.orient == "H" else 1, axis_pos=float(w.axis_pos),
                                         end0=float(w.endpoints[0]), end1=float(w.endpoints[1]),
@@ -297,9 +350,10 @@ class World(object):
     def params_signature(self):
         """Cheap tuple of everything `native_params` reads from the world and from agent 0:
         callers that cache an FgParams re-derive it when this changes."""
-        a0 = self.agents[0]
         return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
-                len(self.agents), a0.size, a0.initial_mass, a0.accel, a0.max_speed, a0.u_noise,
+                len(self.agents), tuple((a.size, a.initial_mass, a.accel, a.max_speed, a.u_noise, a.silent, a.c_noise)
+                                        for a in self.agents),
+                None if self.comm_c is None else self.comm_c.data_ptr(),
                 None if self.rng_counter is None else self.rng_counter.data_ptr(),
                 tuple((w.orient, float(w.axis_pos), float(w.endpoints[0]), float(w.endpoints[1]), float(w.width), w.hard)
                       for w in self.walls))
@@ -315,3 +369,21 @@ class World(object):
             p, self.num_envs, len(self.agents),
             self.pos_x.data_ptr(), self.pos_y.data_ptr(), self.vel_x.data_ptr(), self.vel_y.data_ptr(),
             self.action_u.data_ptr(), _native.current_stream(self.device)))
+        self.update_agent_state()
+        if self.scenario is not None and hasattr(self.scenario, "_cache"):
+            self.scenario._cache = None                   # per-agent callbacks must re-evaluate on the new state
+
+    def update_agent_state(self, seed=0):
+        """core.py:221-222, 279-286 for every agent: `state.c` = zeros for a silent agent, `action.c` (+ c_noise) for
+        the others - one launch (`fg_update_comm`); nothing to do while everybody is silent (`state.c` reads zeros)."""
+        if not self.any_non_silent():
+            if self.comm_c is not None:
+                self.comm_c.zero_()
+            return
+        comm, act = self.ensure_comm()
+        p = self.native_params(seed=seed, rng_offset=self.world_step)
+        props = self.agent_props()
+        if props is not None:
+            p.agent_props = props.data_ptr()              # the c_noise / silent column matters here even for alike agents
+        _native.check(_native.load().fg_update_comm(p, self.num_envs, len(self.agents), act.data_ptr(), comm.data_ptr(),
+                                                    _native.current_stream(self.device)))

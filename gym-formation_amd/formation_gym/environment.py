@@ -65,13 +65,16 @@ class MultiAgentEnv(object):
         obs_dim = self.scenario.obs_dim(world)
         share_obs_dim = 0
         for agent in self.agents:
-            if not agent.silent:
-                raise NotImplementedError("non-silent agents do not occur in the reference scenarios")
             if self.discrete_action_space:                        # :64-65
-                self.action_space.append(spaces.Discrete(world.dim_p * 2 + 1))
+                u_space = spaces.Discrete(world.dim_p * 2 + 1)
             else:
-                self.action_space.append(spaces.Box(low=-agent.u_range, high=+agent.u_range,
-                                                    shape=(world.dim_p,), dtype=np.float32))
+                u_space = spaces.Box(low=-agent.u_range, high=+agent.u_range, shape=(world.dim_p,), dtype=np.float32)
+            if not agent.silent:                                  # :72-84: a Tuple (physical, communication) action space
+                c_space = spaces.Discrete(world.dim_c) if self.discrete_action_space else \
+                    spaces.Box(low=0.0, high=1.0, shape=(world.dim_c,), dtype=np.float32)
+                self.action_space.append(spaces.Tuple([u_space, c_space]))
+            else:
+                self.action_space.append(u_space)
             share_obs_dim += obs_dim
             self.observation_space.append(spaces.Box(low=-np.inf, high=+np.inf,
                                                      shape=(obs_dim,), dtype=np.float32))
@@ -125,6 +128,12 @@ class MultiAgentEnv(object):
     def step(self, action_n):
         self.current_step += 1
         self.agents = self.world.policy_agents
+        if self.world.any_non_silent():
+            # The reference cannot step non-silent (movable) agents either: `_set_action` consumes the whole action for
+            # the physical part and then indexes the exhausted list for the communication part (environment.py:216-231;
+            # fixture hd_n5_comm records the IndexError).  Non-silent agents are driven through the World API instead:
+            # agent.action.u / agent.action.c, world.step(), scenario.observation / reward (core.py:206-225, 279-286).
+            raise IndexError("list index out of range")
         batched = torch.is_tensor(action_n)
         mode = self._action_mode()
         if mode:

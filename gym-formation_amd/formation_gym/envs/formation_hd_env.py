@@ -109,6 +109,8 @@ class Scenario(BaseScenario):
                                 auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
         p.obs_env_pitch = self.obs_env_pitch(obs, len(world.agents))
         p.env_index_base = int(getattr(self, "env_base", 0))
+        if world.any_non_silent():                        # :48-51 the communication block carries the others' state.c
+            p.comm_state = world.ensure_comm()[0].data_ptr()
         return p
 
     @staticmethod

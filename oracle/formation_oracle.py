@@ -159,40 +159,58 @@ def wall_force(pos, size, wall, P, dtype=np.float64):
     return np.where(beyond[..., None], dtype(0), f)
 
 
-def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None):
+def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None, mass=None, size=None):
     """World.step for agent-only colliders (core.py:206-322 with the early-outs
     of :292-297 applied: landmarks have collide=False, so only agent-agent
     pairs survive).  pos, vel, act: [B,N,2].  Returns new (pos, vel).
 
     environment.py:216-221  u = sensitivity * action (no clipping)
     core.py:235-236         F_i = mass * u_i   (accel None, no noise)
-    core.py:304-318         pair force on PRE-step positions, ratio m_b/m_a = 1
+    core.py:304-318         pair force on PRE-step positions, ratio m_b/m_a
     core.py:268-277         v = v*(1-damping) + F/m*dt ; p += v*dt
+    max_speed / accel: a scalar for every agent or one value per agent [N] (NaN = None for that agent);
+    mass / size: per-agent arrays [N] (core.py:68-75: Entity.initial_mass, Entity.size), default P.mass / P.agent_size.
     """
     pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
     act = np.asarray(act, dtype=dtype)
     B, N, _ = pos.shape
-    if accel is None:
-        F = dtype(P.mass) * (dtype(P.sensitivity) * act)
-    else:                                  # environment.py:219-220 and core.py:236 both use accel
-        F = dtype(P.mass * accel) * (dtype(accel) * act)
+    m = np.full(N, P.mass, dtype=dtype) if mass is None else np.asarray(mass, dtype=dtype)
+    sz = np.full(N, P.agent_size, dtype=dtype) if size is None else np.asarray(size, dtype=dtype)
+    acc = np.full(N, np.nan) if accel is None else np.broadcast_to(np.asarray(accel, dtype=np.float64), (N,))
+    has_acc = ~np.isnan(acc)
+    sens = np.where(has_acc, acc, P.sensitivity).astype(dtype)           # environment.py:218-220
+    gain = np.where(has_acc, m * np.where(has_acc, acc, 1.0), m).astype(dtype)   # core.py:236
+    F = gain[None, :, None] * (sens[None, :, None] * act)
     delta = pos[:, :, None, :] - pos[:, None, :, :]            # [B,i,j,2] = p_i - p_j
     dist = np.sqrt((delta ** 2).sum(-1))                       # [B,i,j]
-    pen = softplus_penetration(dist, dtype(P.dist_min), dtype(P.contact_margin))
+    dist_min = (sz[:, None] + sz[None, :]).astype(dtype)       # core.py:307 size_a + size_b
+    pen = softplus_penetration(dist, dist_min[None], dtype(P.contact_margin))
     with np.errstate(invalid="ignore", divide="ignore"):
         f = dtype(P.contact_force) * delta / dist[..., None] * pen[..., None]
+    ratio = (m[None, :] / m[:, None]).astype(dtype)            # core.py:314-317: agent i receives (m_j / m_i) f
+    f = ratio[None, :, :, None] * f
     eye = np.eye(N, dtype=bool)[None, :, :, None]
     f = np.where(eye, dtype(0), f)                             # core.py:296 same entity
     F = F + f.sum(2)
     for w in (walls or []):                                    # core.py:255-261
-        F = F + wall_force(pos, dtype(P.agent_size), w, P, dtype)
-    vel = vel * dtype(1 - P.damping) + (F / dtype(P.mass)) * dtype(P.dt)
+        F = F + wall_force(pos, sz[None, :], w, P, dtype)
+    vel = vel * dtype(1 - P.damping) + (F / m[None, :, None]) * dtype(P.dt)
     if max_speed is not None:                                  # core.py:271-276
+        ms = np.broadcast_to(np.asarray(max_speed, dtype=np.float64), (N,))[None, :, None]
         speed = np.sqrt((vel ** 2).sum(-1, keepdims=True))
         with np.errstate(invalid="ignore", divide="ignore"):
-            vel = np.where(speed > max_speed, vel / speed * dtype(max_speed), vel)
+            vel = np.where(speed > ms, vel / speed * ms.astype(dtype), vel)     # NaN (None) compares False
     pos = pos + vel * dtype(P.dt)
     return pos, vel
+
+
+def update_comm(action_c, silent=None, dtype=np.float64):
+    """World.update_agent_state without noise (core.py:279-286): state.c = action.c, zeros for a silent agent.
+    action_c [B,N,dim_c]; silent: bool [N] or None (nobody silent)."""
+    c = np.array(action_c, dtype=dtype)
+    if silent is not None:
+        c[:, np.asarray(silent, dtype=bool)] = 0
+    return c
 
 
 ACT_ONEHOT5, ACT_INDEX, ACT_ARGMAX = 1, 2, 3
@@ -219,9 +237,10 @@ def decode_actions(action, mode):
     raise ValueError("unknown action mode %r" % (mode,))
 
 
-def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64):
+def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64, comm=None):
     """formation_hd_env.py:52-59 for every agent: [v_i | p_j - p_i (j != i, index
-    order) | zeros 2(N-1) | ideal_shape.flatten() | ideal_vel] -> [B,N,6N]."""
+    order) | c_j (j != i; zeros for silent agents) 2(N-1) | ideal_shape.flatten() | ideal_vel] -> [B,N,6N].
+    comm [B,N,2] = AgentState.c of every agent (dim_c = 2), None = all silent."""
     pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
     B, N, _ = pos.shape
     obs = np.zeros((B, N, 6 * N), dtype=dtype)
@@ -229,12 +248,15 @@ def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64):
     rel = pos[:, None, :, :] - pos[:, :, None, :]              # [B,i,j,2] = p_j - p_i
     keep = ~np.eye(N, dtype=bool)
     obs[:, :, 2:2 * N] = rel[:, keep].reshape(B, N, 2 * (N - 1))
+    if comm is not None:                                       # :48-51 comm = append(other.state.c) for other != agent
+        c = np.broadcast_to(np.asarray(comm, dtype=dtype)[:, None, :, :], (B, N, N, 2))
+        obs[:, :, 2 * N:4 * N - 2] = c[:, keep].reshape(B, N, 2 * (N - 1))
     obs[:, :, 4 * N - 2:6 * N - 2] = np.asarray(ideal_shape, dtype=dtype).reshape(B, 1, 2 * N)
     obs[:, :, 6 * N - 2:] = np.asarray(ideal_vel, dtype=dtype)[:, None, :]
     return obs
 
 
-def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64):
+def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64, size=None):
     """formation_hd_env.py:61-75 for every agent + the integer by-products.
     Returns dict(indiv[B,N], shared[B], hd[B,2], hd_idx[B,4], near_lm[B,N],
     near_ag[B,N], cnt[B,N], gap_lm, gap_ag, cnt_margin)."""
@@ -248,7 +270,11 @@ def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64):
     H = np.maximum(h1, h2)                                     # :66
     velterm = np.sqrt(((iv - vel.mean(1)) ** 2).sum(-1))       # :68-69
     PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
-    thr = dtype(P.collide_thresh)
+    if size is None:
+        thr = dtype(P.collide_thresh)
+    else:                                                      # :119-121 per pair: (size_a + size_b) / 2, scaled like P's
+        sz = np.asarray(size, dtype=dtype)
+        thr = (dtype(P.collide_thresh / P.dist_min) * (sz[:, None] + sz[None, :]))[None]
     close = PD < thr                                           # :121 strict <
     close[:, np.arange(N), np.arange(N)] = False               # :73 agent != a
     cnt = close.sum(2)
@@ -277,10 +303,11 @@ def step_hd(state, act, P=None, dtype=np.float64, **world_options):
     113-142).  `state` = dict(pos, vel, ideal_shape, ideal_vel, step); returns
     (new_state, out) with out = dict(obs, reward[B,N,1], done[B,N], indiv, ...)."""
     P = P or HdParams()
+    comm = world_options.pop("comm", None)                     # AgentState.c [B,N,2] of non-silent agents
     pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype, **world_options)
     step = np.asarray(state["step"]) + 1                       # environment.py:114
-    out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype)
-    out["obs"] = observation_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], dtype)
+    out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype, size=world_options.get("size"))
+    out["obs"] = observation_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], dtype, comm=comm)
     N = pos.shape[1]
     out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]    # :136-138
     out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)      # :172-178

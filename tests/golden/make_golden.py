@@ -28,7 +28,7 @@ import warnings
 import numpy as np
 
 REF = os.environ.get("FG_REFERENCE", "/root/reference")
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get("FG_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))   # FG_GOLDEN_OUT: the drift test writes elsewhere
 
 GYM_SHIM = textwrap.dedent('''
     import numpy as np
@@ -140,6 +140,12 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
                 a.accel = options.get("accel")
             if options.get("walls"):
                 env.world.walls = [rcore.Wall(o, ax, ep, w) for (o, ax, ep, w) in WALLS]
+            het = options.get("hetero")                   # per-agent mass / size / accel / max_speed (core.py:45-109)
+            if het:
+                for a, m_, s_, ac_, ms_ in zip(env.world.agents, het["mass"], het["size"], het["accel"], het["max_speed"]):
+                    a.initial_mass = float(m_); a.size = float(s_)
+                    a.accel = None if np.isnan(ac_) else float(ac_)
+                    a.max_speed = None if np.isnan(ms_) else float(ms_)
             wc = options.get("world")                     # non-default World constants (core.py:119-139)
             if wc:
                 env.world.dt = wc["dt"]; env.world.damping = wc["damping"]
@@ -160,6 +166,9 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
         ivel.append(np.array(sc.ideal_vel, dtype=np.float64))
         obs0.append(np.array(o0, dtype=np.float64))
         thresh = (env.world.agents[0].size + env.world.agents[1].size) / 2
+        if options and options.get("hetero"):             # is_collision per pair (formation_hd_env.py:119-121)
+            sz_ = np.array([a.size for a in env.world.agents])
+            thresh = (sz_[:, None] + sz_[None, :]) / 2
         rec = {k: [] for k in out}
         for t in range(T):
             act_n = [acts[t, b, i].astype(np.float64).copy() for i in range(N)]
@@ -186,6 +195,60 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
         res["obs_t%d" % t] = np.array(lst)                     # [B,N,6N]
     if options and options.get("world"):
         res.update({"world_" + k: np.array(v) for k, v in options["world"].items()})
+    if options and options.get("hetero"):
+        res.update({"agent_" + k: np.array(v, dtype=np.float64) for k, v in options["hetero"].items()})
+    return res
+
+
+def hetero_options(N, seed):
+    """Per-agent properties no reference scenario sets: mass 0.5 ... 3, size 0.02 ... 0.09, a third of the agents with
+    their own accel, a third with a max_speed (NaN = None)."""
+    rs = np.random.RandomState(seed)
+    mass = rs.uniform(0.5, 3.0, N); size = rs.uniform(0.02, 0.09, N)
+    accel = np.where(rs.uniform(size=N) < 0.34, rs.uniform(2.0, 6.0, N), np.nan)
+    max_speed = np.where(rs.uniform(size=N) < 0.34, rs.uniform(0.2, 0.8, N), np.nan)
+    return dict(mass=mass, size=size, accel=accel, max_speed=max_speed)
+
+
+def comm_fixture(fg, N, T, seed, act_seed, crowd):
+    """Non-silent agents (core.py:279-286, formation_hd_env.py:48-51).  The reference's env.step cannot take them
+    (environment.py:231 indexes an exhausted action list -> IndexError, recorded below), so the World is driven the
+    way core.py's own API allows: action.u / action.c set per agent, world.step(), then the scenario callbacks."""
+    env = fg.make_env("formation_hd_env", False, N)
+    sc = _scenario_of(env)
+    world = env.world
+    silent = np.zeros(N, dtype=bool); silent[1] = True           # one agent stays silent: its c is zeros
+    for a, s_ in zip(world.agents, silent):
+        a.silent = bool(s_)
+    env.seed(seed)
+    env.reset()
+    for a in world.agents:
+        a.state.p_pos = a.state.p_pos * crowd
+    p0, v0 = _state(env)
+    try:
+        env.step([np.zeros(2) for _ in range(N)])
+        raised = "none"
+    except Exception as exc:                                      # noqa: BLE001
+        raised = type(exc).__name__ + ": " + str(exc)
+    for a, p_, v_ in zip(world.agents, p0, v0):                  # undo whatever the failed call did
+        a.state.p_pos = p_.copy(); a.state.p_vel = v_.copy()
+    rs = np.random.RandomState(act_seed)
+    acts = rs.uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    comm = rs.uniform(0, 1, (T, N, 2)).astype(np.float32)
+    rec = {k: [] for k in ("pos", "vel", "c", "obs", "indiv")}
+    for t in range(T):
+        for i, a in enumerate(world.agents):
+            a.action.u = 5.0 * acts[t, i].astype(np.float64)     # what _set_action does (environment.py:216-221)
+            a.action.c = comm[t, i].astype(np.float64)
+        world.step()
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["c"].append(np.array([a.state.c for a in world.agents], dtype=np.float64))
+        rec["obs"].append(np.array([sc.observation(a, world) for a in world.agents], dtype=np.float64))
+        rec["indiv"].append(np.array([sc.reward(a, world) for a in world.agents], dtype=np.float64))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, acts=acts, comm=comm, silent=silent, ideal_shape=np.array(sc.ideal_shape, dtype=np.float64),
+               ideal_vel=np.array(sc.ideal_vel, dtype=np.float64), seed=np.array(seed), env_step_raises=np.array(raised))
     return res
 
 
@@ -447,6 +510,13 @@ def main():
         world=dict(dt=0.05, damping=0.4, contact_force=60.0, contact_margin=4e-3, mass=2.5, size=0.08, world_length=7))))
     save("hd_n27_constants", lambda: rollout_hd(fg, 27, 2, 8, seed=26, act_seed=36, crowd=0.4, obs_at=[8], options=dict(
         world=dict(dt=0.2, damping=0.1, contact_force=150.0, contact_margin=2e-3, mass=0.5, size=0.05, world_length=5))))
+    # per-agent mass / size / accel / max_speed (force_ratio m_b / m_a of core.py:314-317, per-pair contact distances)
+    save("hd_n9_masses", lambda: rollout_hd(fg, 9, 3, 16, seed=93, act_seed=94, crowd=0.25, obs_at=[1, 16],
+                                            options=dict(hetero=hetero_options(9, 95))))
+    save("hd_n27_masses", lambda: rollout_hd(fg, 27, 2, 10, seed=96, act_seed=97, crowd=0.45, obs_at=[10],
+                                             options=dict(hetero=hetero_options(27, 98), walls=True)))
+    # non-silent agents: World.step + Scenario.observation with state.c in the communication block
+    save("hd_n5_comm", lambda: comm_fixture(fg, 5, 10, seed=99, act_seed=100, crowd=0.3))
     save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
     # config 1: basic_formation_env, N=3, incl. the done flip at step 50
     save("basic_n3", lambda: rollout_basic(fg, 3, 52, seed=1, act_seed=20))

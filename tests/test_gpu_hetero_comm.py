@@ -1,0 +1,195 @@
+"""GPU parity of the World features beyond the reference's own scenarios:
+agents of different mass / size / accel / max_speed (core.py:68-75, 97-99, 289-322) and non-silent agents
+(core.py:279-286, formation_hd_env.py:48-51).  Fixtures come from the real reference (tests/golden/make_golden.py),
+every fp32 bound is 1e-5 abs (shared reward: 2e-6 relative, H2)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import formation_oracle as O
+from tests.test_gpu_parity import ATOL, _load, _make, _np
+
+pytestmark = pytest.mark.gpu
+
+
+def _apply_hetero(env, g, walls=False):
+    from formation_gym.core import Wall
+    for a, m, s, ac, ms in zip(env.world.agents, g["agent_mass"], g["agent_size"], g["agent_accel"], g["agent_max_speed"]):
+        a.initial_mass = float(m); a.size = float(s)
+        a.accel = None if np.isnan(ac) else float(ac)
+        a.max_speed = None if np.isnan(ms) else float(ms)
+    if walls:
+        env.world.walls = [Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS]
+
+
+@pytest.mark.parametrize("name,walls", [("hd_n9_masses", False), ("hd_n27_masses", True)])
+def test_per_agent_mass_size_options_teacher_forced(golden, name, walls):
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    _apply_hetero(env, g, walls)
+    env.enable_assignments(True)
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    worst = {"pos": 0.0, "vel": 0.0, "indiv": 0.0, "obs": 0.0}
+    for t in range(T):
+        _load(env, prev_pos, prev_vel, g["ideal_shape"], g["ideal_vel"], np.full(B, t))
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
+        ok = g["cnt_margin"][t] > 1e-5
+        np.testing.assert_allclose(_np(info["individual_reward"])[ok], g["indiv"][t][ok], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(rew)[ok, :, 0], g["shared"][t][ok], rtol=2e-6, atol=ATOL)
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+        worst["pos"] = max(worst["pos"], np.abs(_np(pos) - g["pos"][t]).max())
+        worst["vel"] = max(worst["vel"], np.abs(_np(vel) - g["vel"][t]).max())
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    assert g["cnt"].sum() > 0
+    # a K-step launch with the same table runs step_kernel's K-loop: bit-identical to single steps
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    acts = torch.as_tensor(g["acts"][:4]).cuda().contiguous()
+    singles = []
+    for t in range(4):
+        o, r, d, _ = env.step(acts[t])
+        singles.append((o.clone(), r.clone()))
+    _load(env, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    o_seq, r_seq, _, _ = env.rollout(acts)
+    for t in range(4):
+        assert torch.equal(o_seq[t], singles[t][0]) and torch.equal(r_seq[t], singles[t][1])
+
+
+@pytest.mark.parametrize("N,B", [(3, 50), (12, 33), (27, 40), (70, 9), (81, 6), (200, 3)])
+def test_random_per_agent_tables_against_oracle(N, B):
+    """Randomised tables over specialised, run-time and whole-workgroup agent counts: one teacher-forced step vs the
+    fp64 oracle on the same fp32 inputs, crowded so that contacts and penalties occur."""
+    rs = np.random.RandomState(1000 + N)
+    env = _make(N, B)
+    mass = rs.uniform(0.4, 4.0, N); size = rs.uniform(0.01, 0.08, N)
+    accel = np.where(rs.uniform(size=N) < 0.5, rs.uniform(1.0, 7.0, N), np.nan)
+    vmax = np.where(rs.uniform(size=N) < 0.5, rs.uniform(0.1, 1.0, N), np.nan)
+    g = dict(agent_mass=mass, agent_size=size, agent_accel=accel, agent_max_speed=vmax)
+    _apply_hetero(env, g)
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    spread = 0.5 * np.sqrt(N / 27.0)
+    pos = f32(rs.uniform(-spread, spread, (B, N, 2))); vel = f32(rs.uniform(-0.5, 0.5, (B, N, 2)))
+    shape = rs.uniform(-1, 1, (B, N, 2)); shape = f32(shape - shape.mean(1, keepdims=True))
+    ivel = f32(rs.uniform(-1, 1, (B, 2)))
+    act = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+    _load(env, pos, vel, shape, ivel, np.zeros(B))
+    obs, rew, done, info = env.step(torch.as_tensor(act).cuda())
+    P = O.HdParams(); P.agent_size = float(np.float32(size[0]))          # the scale of collide_thresh is agent 0's
+    st = dict(pos=pos, vel=vel, ideal_shape=shape, ideal_vel=ivel, step=np.zeros(B, dtype=np.int32))
+    opts = dict(mass=f32(mass), size=f32(size), accel=np.where(np.isnan(accel), np.nan, f32(np.nan_to_num(accel))),
+                max_speed=np.where(np.isnan(vmax), np.nan, f32(np.nan_to_num(vmax))))
+    new, out = O.step_hd(st, act.astype(np.float64), **opts)
+    p_, v_ = env.world.get_state()
+    np.testing.assert_allclose(_np(p_), new["pos"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(v_), new["vel"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(obs), out["obs"], rtol=0, atol=ATOL)
+    ok = out["cnt_margin"] > 1e-5
+    assert ok.any() and out["cnt"].sum() > 0
+    np.testing.assert_allclose(_np(info["individual_reward"])[ok], out["indiv"][ok], rtol=0, atol=ATOL)
+
+
+def test_identical_table_rows_equal_the_scalar_description():
+    """A table whose rows all equal the scalars must give what the scalar path gives (same formula, 1e-6: the table path
+    sums the pair forces in a plain loop, the scalar one in the packed loops)."""
+    N, B = 27, 64
+    e1, e2 = _make(N, B), _make(N, B)
+    for e in (e1, e2):
+        e.seed(4); e.reset()
+        e.world.set_state(pos=e.world.get_state()[0] * 0.3)
+    p = e2.scenario.params(e2.world)
+    rows = torch.tensor([[1.0, 0.03, 0, 0, 0, -1.0]] * N, dtype=torch.float32, device="cuda")
+    act = torch.rand((B, N, 2), device="cuda") * 2 - 1
+    o1, r1, _, i1 = e1.step(act.clone())
+    from formation_gym import _native
+    p.agent_props = rows.data_ptr()
+    out = e2._out
+    _native.check(_native.load().fg_step_hd(
+        p, B, N, e2.world.pos_x.data_ptr(), e2.world.pos_y.data_ptr(), e2.world.vel_x.data_ptr(), e2.world.vel_y.data_ptr(),
+        act.data_ptr(), e2.scenario.ideal_shape.data_ptr(), e2.scenario.ideal_vel.data_ptr(), e2.world.step_count.data_ptr(),
+        out["obs"].data_ptr(), out["reward"].data_ptr(), out["indiv"].data_ptr(), out["done"].data_ptr(), None, None, None,
+        _native.current_stream(e2.world.device)))
+    torch.cuda.synchronize()
+    assert float((out["obs"] - o1).abs().max()) < 1e-6 and float((out["indiv"] - i1["individual_reward"]).abs().max()) < 1e-5
+    np.testing.assert_allclose(_np(e2.world.pos_x), _np(e1.world.pos_x), rtol=0, atol=1e-6)
+
+
+def test_non_silent_agents_through_the_world_api(golden):
+    """The fixture's path: agent.action.u / .c set per agent, world.step(), scenario.observation / reward per agent
+    (the reference's env.step raises IndexError for non-silent agents, and so does this one)."""
+    import formation_gym
+    g = golden("hd_n5_comm")
+    T, N = g["acts"].shape[:2]
+    env = formation_gym.make_env("formation_hd_env", False, N, device="cuda:0")
+    world, sc = env.world, env.scenario
+    for a, s in zip(world.agents, g["silent"]):
+        a.silent = bool(s)
+    env2 = formation_gym.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation)
+    assert [type(s).__name__ for s in env2.action_space] == ["Tuple" if not s else "Box" for s in g["silent"]]
+    with pytest.raises(IndexError, match="list index out of range"):
+        env2.step([np.zeros(2) for _ in range(N)])
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):
+        _load(env, prev_pos[None], prev_vel[None], g["ideal_shape"][None], g["ideal_vel"][None], np.zeros(1))   # teacher-forced
+        for i, a in enumerate(world.agents):
+            a.action.u = torch.as_tensor(g["acts"][t, i])[None]            # RAW action: the x5 of _set_action happens in-kernel
+            a.action.c = torch.as_tensor(g["comm"][t, i])[None]
+        world.step()
+        pos, vel = world.get_state()
+        np.testing.assert_allclose(_np(pos)[0], g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel)[0], g["vel"][t], rtol=0, atol=ATOL)
+        c = np.stack([_np(a.state.c)[0] for a in world.agents])
+        np.testing.assert_array_equal(c, g["c"][t].astype(np.float32).astype(np.float64))
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+        obs = np.stack([_np(sc.observation(a, world))[0] for a in world.agents])
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=0, atol=ATOL)
+        rew = np.array([float(sc.reward(a, world)[0]) for a in world.agents])
+        np.testing.assert_allclose(rew, g["indiv"][t], rtol=0, atol=ATOL)
+    assert (g["obs"][:, 0, 2 * N:4 * N - 2] != 0).any()
+
+
+@pytest.mark.parametrize("N,B", [(9, 130), (27, 70), (100, 5), (81, 40)])
+def test_comm_block_at_batch_sizes_and_launch_paths(N, B):
+    """fg_observe_hd / fg_step_hd with FgParams.comm_state over lane-group, whole-workgroup and split launches
+    vs the oracle's observation; c_noise draws are Gaussian with the requested scale."""
+    import formation_gym
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    env.seed(5); env.reset()
+    world, sc = env.world, env.scenario
+    silent = np.zeros(N, dtype=bool); silent[::4] = True
+    for a, s in zip(world.agents, silent):
+        a.silent = bool(s)
+    comm_c, action_c = world.ensure_comm()
+    action_c.copy_(torch.rand((B, N, 2), device="cuda"))
+    world.action_u.copy_(torch.rand((B, N, 2), device="cuda") * 2 - 1)
+    st0 = [t.clone() for t in world.get_state()]
+    world.step()
+    want_c = O.update_comm(_np(action_c), silent)
+    np.testing.assert_array_equal(_np(comm_c), want_c)
+    pos, vel = world.get_state()
+    out = dict(obs=torch.empty((B, N, 6 * N), device="cuda"), reward=torch.empty((B, N), device="cuda"))
+    sc.observe_batch(world, out)
+    want = O.observation_hd(_np(pos), _np(vel), _np(sc.ideal_shape), _np(sc.ideal_vel), comm=want_c)
+    np.testing.assert_allclose(_np(out["obs"]), want, rtol=0, atol=ATOL)
+    # the fused step with the communication block (fg_step_hd + comm_state; split launches at few envs)
+    act = torch.rand((B, N, 2), device="cuda") * 2 - 1
+    st = dict(pos=_np(pos), vel=_np(vel), ideal_shape=_np(sc.ideal_shape), ideal_vel=_np(sc.ideal_vel),
+              step=world.step_count.cpu().numpy())
+    sc.step_batch(world, act, env._out)
+    new, ref = O.step_hd(st, _np(act), comm=want_c)
+    np.testing.assert_allclose(_np(env._out["obs"]), ref["obs"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(env._out["indiv"]), ref["indiv"], rtol=0, atol=ATOL)
+    # noise: N(0, c_noise^2) around action.c for the non-silent agents, fresh every step
+    for a in world.agents:
+        a.c_noise = 0.25
+    world.step()
+    d1 = (_np(comm_c) - _np(action_c))[:, ~silent]
+    world.step()
+    d2 = (_np(comm_c) - _np(action_c))[:, ~silent]
+    tol = 4.5 * 0.25 / np.sqrt(d1.size)                      # 4.5 standard errors of the mean (std: / sqrt(2), well inside)
+    assert abs(d1.std() - 0.25) < tol and abs(d1.mean()) < tol and np.abs(d1 - d2).max() > 0.1
+    assert (_np(comm_c)[:, silent] == 0).all()

@@ -1,6 +1,8 @@
 """Pin the CPU oracle (oracle/formation_oracle.py) to the golden fixtures that
 tests/golden/make_golden.py captured from the real reference, plus scipy's
 published directed_hausdorff example.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -323,6 +325,82 @@ def test_non_default_world_constants_match_reference(golden, name):
         if (t + 1) in g["obs_steps"]:
             np.testing.assert_allclose(out["obs"], g["obs_t%d" % (t + 1)], rtol=0, atol=1e-10)
         prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+def hetero_opts(g, walls=False):
+    """World options of a `*_masses` fixture: per-agent mass / size / accel / max_speed (NaN = None)."""
+    o = dict(mass=g["agent_mass"], size=g["agent_size"], accel=g["agent_accel"], max_speed=g["agent_max_speed"])
+    if walls:
+        o["walls"] = O.GOLDEN_WALLS
+    return o
+
+
+@pytest.mark.parametrize("name,walls", [("hd_n9_masses", False), ("hd_n27_masses", True)])
+def test_per_agent_mass_size_and_options_match_reference(golden, name, walls):
+    """Agents of different mass, size, accel and max_speed (set on the reference's agents before the rollout):
+    force_ratio m_b / m_a (core.py:314-317), per-pair contact and penalty distances (core.py:307,
+    formation_hd_env.py:119-121), per-agent gains (core.py:236, environment.py:219-220) and speed clamps (:271-276)."""
+    g = golden(name)
+    B = g["pos0"].shape[0]
+    opts = hetero_opts(g, walls)
+    assert g["cnt"].sum() > 0 and np.ptp(g["agent_mass"]) > 1 and np.isnan(g["agent_accel"]).any() and (~np.isnan(g["agent_accel"])).any()
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(g["acts"].shape[0]):
+        st = dict(pos=prev_pos, vel=prev_vel, ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"],
+                  step=np.full(B, t, dtype=np.int32))
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64), **opts)
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(st["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["reward"][..., 0], g["shared"][t], rtol=1e-12, atol=1e-10)
+        np.testing.assert_array_equal(out["cnt"], g["cnt"][t])
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(out["obs"], g["obs_t%d" % (t + 1)], rtol=0, atol=1e-10)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+
+
+def test_non_silent_agents_match_reference(golden):
+    """World.update_agent_state (core.py:279-286) and the communication block of the observation
+    (formation_hd_env.py:48-51), driven through core.py's own API; the reference's env.step cannot take
+    non-silent agents at all (IndexError at environment.py:231), which the fixture records."""
+    g = golden("hd_n5_comm")
+    assert str(g["env_step_raises"]).startswith("IndexError")
+    pos, vel = g["pos0"][None], g["vel0"][None]
+    for t in range(g["acts"].shape[0]):
+        st = dict(pos=pos, vel=vel, ideal_shape=g["ideal_shape"][None], ideal_vel=g["ideal_vel"][None],
+                  step=np.zeros(1, dtype=np.int32))
+        c = O.update_comm(g["comm"][t][None], g["silent"])
+        np.testing.assert_array_equal(c[0], g["c"][t])
+        st, out = O.step_hd(st, g["acts"][t][None].astype(np.float64), comm=c)
+        np.testing.assert_allclose(st["pos"][0], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["obs"][0], g["obs"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"][0], g["indiv"][t], rtol=0, atol=1e-10)
+        pos, vel = st["pos"], st["vel"]
+    assert (g["obs"][:, 0, 2 * 5:4 * 5 - 2] != 0).any()
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("FG_REFERENCE", "/root/reference")),
+                    reason="the reference is only present in the build container")
+def test_committed_fixtures_equal_the_generator_output(tmp_path):
+    """Fixture / script drift guard: re-run tests/golden/make_golden.py against the real reference into a temp
+    directory and demand key-for-key, bit-for-bit equality with the committed .npz files."""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tests", "golden", "make_golden.py")], check=True, timeout=1500,
+                   env=dict(os.environ, FG_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1"), capture_output=True)
+    committed = sorted(os.path.basename(f) for f in glob.glob(os.path.join(root, "tests", "golden", "*.npz")))
+    made = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / "*.npz")))
+    assert committed == made
+    for name in committed:
+        with np.load(os.path.join(root, "tests", "golden", name)) as a, np.load(str(tmp_path / name)) as b:
+            assert sorted(a.files) == sorted(b.files), name
+            for k in a.files:
+                if a[k].dtype.kind in "US":
+                    assert str(a[k]) == str(b[k]), (name, k)
+                else:
+                    np.testing.assert_array_equal(a[k], b[k], err_msg="%s[%s]" % (name, k))
 
 
 ACT_MODES = [("act_onehot5_n3", O.ACT_ONEHOT5), ("act_index_n9", O.ACT_INDEX), ("act_argmax_n3", O.ACT_ARGMAX)]
