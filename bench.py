@@ -200,7 +200,7 @@ def main():
     ap.add_argument("--global-div", type=int, default=1,
                     help="test aid: run the GLOBAL-batch configs (BASELINE configs[3], [4]) with their batch sizes divided "
                          "by this, whatever the headline shape is (the lines are marked)")
-    ap.add_argument("--placement-candidates", type=int, default=4,
+    ap.add_argument("--placement-candidates", type=int, default=8,
                     help="observation buffers beyond the Infinity Cache: allocate up to this many candidates, time the launch "
                          "on each, keep the fastest (formation_gym/placement.py); 1 = no probe")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -320,7 +320,7 @@ def main():
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
         placed = {}
         if a.placement_candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
-            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
+            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.6 / gpu_share)
         out = env._out
         act_pool, launchers = None, []
         if not policy:
@@ -408,7 +408,7 @@ def main():
             if a.obs_every == 1:
                 # the observation buffer is PLACED: candidates timed with this env's own launch, the fastest kept
                 seq = env.alloc_rollout_buffers(chunk, obs_env_pitch=0 if pitch == 6 * N * N else pitch, policy=policy,
-                                                candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
+                                                candidates=a.placement_candidates, mem_fraction=0.6 / gpu_share)
                 placed["rollout"] = env.placement
             else:
                 obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)

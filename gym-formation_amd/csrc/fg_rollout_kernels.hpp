@@ -482,6 +482,12 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 
     const bool per_step = a.K == 1;
     const int total = per_step ? NG : a.K;
+#ifdef FG_WIDE_WRITER_PRIO
+    if (!producer) __builtin_amdgcn_s_setprio(FG_WIDE_WRITER_PRIO);
+#endif
+#ifdef FG_WIDE_PRODUCER_PRIO
+    if (producer) __builtin_amdgcn_s_setprio(FG_WIDE_PRODUCER_PRIO);
+#endif
     if (producer) { load_group(0); produce(0, 0); if (per_step) store_group(); }
     __syncthreads();
     for (int it = 0; it < total; ++it) {

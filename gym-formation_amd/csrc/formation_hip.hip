@@ -243,9 +243,18 @@ static int launch_wide_v(Args a, hipStream_t st) {
     if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+#ifndef FG_W81_E
+#define FG_W81_E 4            // envs (= producer waves) per workgroup of the 81-agent pipelined kernel
+#endif
+#ifndef FG_W81_TW
+#define FG_W81_TW 256         // writer threads of that kernel
+#endif
+#ifndef FG_W243_TW
+#define FG_W243_TW 256
+#endif
 template <bool POLICY = false>
 static int launch_wide(const Args& a, hipStream_t st) {
-    return a.N == 81 ? launch_wide_v<81, 2, 4, 256, POLICY>(a, st) : launch_wide_v<243, 4, 4, 256, POLICY>(a, st);
+    return a.N == 81 ? launch_wide_v<81, 2, FG_W81_E, FG_W81_TW, POLICY>(a, st) : launch_wide_v<243, 4, 4, FG_W243_TW, POLICY>(a, st);
 }
 
 // N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel

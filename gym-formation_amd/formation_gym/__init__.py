@@ -16,6 +16,7 @@ import importlib.util
 import os.path as osp
 
 from .environment import MultiAgentEnv
+from .scenario import BaseScenario
 from .policy_bfs import ezpolicy, get_action_BFS  # noqa: F401
 
 __all__ = ["make_env", "MultiAgentEnv", "ezpolicy", "get_action_BFS"]
@@ -36,7 +37,13 @@ def load_scenario(scenario_name):
     spec = importlib.util.spec_from_file_location("formation_gym_scenario_%d" % _counter[0], pathname)
     module = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(module)
-    return module.Scenario()
+    cls = module.Scenario
+    if getattr(cls, "step_batch", BaseScenario.step_batch) is BaseScenario.step_batch:
+        # a file written for the reference (make_world / reset_world / observation / reward per agent, scenario.py:4-12):
+        # physics on the GPU, its callbacks on the host - the slow path, see callback_scenario.py
+        from .callback_scenario import CallbackScenario
+        return CallbackScenario(cls)
+    return cls()
 
 
 def make_env(scenario_name='basic_formation_env', benchmark=False, num_agents=3,
@@ -51,4 +58,5 @@ def make_env(scenario_name='basic_formation_env', benchmark=False, num_agents=3,
     else:
         env = MultiAgentEnv(world, scenario.reset_world, scenario.reward, scenario.observation,
                             shared_viewer=True)
+    env.info = {"path": getattr(scenario, "PATH", "fused HIP launch per step (batched Scenario protocol)")}
     return env

@@ -30,10 +30,15 @@ class EntityState(object):
         self._world = world
         self._kind = kind
         self._index = index
+        # Not bound to a device World (an entity of a host-side world description, e.g. the worlds a reference-style
+        # Scenario file builds: formation_gym/callback_scenario.py): plain attributes, as in the reference (core.py:4-9)
+        self._host = {}
 
     @property
     def p_pos(self):
         w, i = self._world, self._index
+        if w is None:
+            return self._host.get("p_pos")
         if self._kind == "agent":
             return torch.stack((w.pos_x[:, i], w.pos_y[:, i]), dim=-1)
         if self._kind == "obstacle":
@@ -43,6 +48,9 @@ class EntityState(object):
     @p_pos.setter
     def p_pos(self, value):
         w, i = self._world, self._index
+        if w is None:
+            self._host["p_pos"] = value
+            return
         value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
         if self._kind == "agent":
             w.pos_x[:, i] = value[..., 0]
@@ -55,6 +63,8 @@ class EntityState(object):
     @property
     def p_vel(self):
         w, i = self._world, self._index
+        if w is None:
+            return self._host.get("p_vel")
         if self._kind == "agent":
             return torch.stack((w.vel_x[:, i], w.vel_y[:, i]), dim=-1)
         if self._kind == "obstacle":
@@ -64,6 +74,9 @@ class EntityState(object):
     @p_vel.setter
     def p_vel(self, value):
         w, i = self._world, self._index
+        if w is None:
+            self._host["p_vel"] = value
+            return
         value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
         if self._kind == "obstacle":
             w.obstacle_vel[:, i] = value
@@ -82,6 +95,8 @@ class AgentState(EntityState):
     @property
     def c(self):
         w = self._world
+        if w is None:
+            return self._host.get("c")
         if w.comm_c is not None:
             return w.comm_c[:, self._index]
         return torch.zeros((w.num_envs, w.dim_c), dtype=torch.float32, device=w.device)
@@ -89,6 +104,9 @@ class AgentState(EntityState):
     @c.setter
     def c(self, value):
         w = self._world
+        if w is None:
+            self._host["c"] = value
+            return
         w.ensure_comm()[0][:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
 
@@ -98,27 +116,38 @@ class Action(object):
     def __init__(self, world=None, index=None):
         self._world = world
         self._index = index
+        self._host = {}                   # an action of a host-side world description: plain attributes
 
     @property
     def c(self):
         """Communication action [B, dim_c] (row of `World.action_c`); None until somebody sets one."""
         w = self._world
-        return None if w is None or w.action_c is None else w.action_c[:, self._index]
+        if w is None:
+            return self._host.get("c")
+        return None if w.action_c is None else w.action_c[:, self._index]
 
     @c.setter
     def c(self, value):
         w = self._world
-        if w is None or value is None:
+        if w is None:
+            self._host["c"] = value
+            return
+        if value is None:
             return
         w.ensure_comm()[1][:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
     @property
     def u(self):
+        if self._world is None:
+            return self._host.get("u")
         return self._world.action_u[:, self._index]
 
     @u.setter
     def u(self, value):
         w = self._world
+        if w is None:
+            self._host["u"] = value
+            return
         w.action_u[:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
 
@@ -363,7 +392,7 @@ class World(object):
         contact force, integration - one HIP launch.  `action_u` holds the RAW
         action; environment.py:216-221's sensitivity scaling happens in-kernel."""
         self.world_step += 1
-        p = self.native_params(sensitivity=sensitivity)
+        p = self.native_params(sensitivity=sensitivity, rng_offset=self.world_step)   # motor noise: fresh draws every step
         lib = _native.load()
         _native.check(lib.fg_physics_step(
             p, self.num_envs, len(self.agents),

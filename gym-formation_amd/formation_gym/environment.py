@@ -302,7 +302,7 @@ class MultiAgentEnv(object):
         self._rng_offset, self.current_step, w.world_step = host
         sc._cache = None
 
-    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=4, mem_fraction=0.5):
+    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.6):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
         the bytes - PLACED: when it is larger than the Infinity Cache, up to `candidates` allocations are made, this
         env's own K-step launch is timed on each and the fastest is kept (formation_gym/placement.py; the rate of a
@@ -354,7 +354,7 @@ class MultiAgentEnv(object):
         self.placement = report
         return dict(small, obs=obs)
 
-    def place_step_buffers(self, candidates=4, mem_fraction=0.5):
+    def place_step_buffers(self, candidates=8, mem_fraction=0.6):
         """The same probe for the per-step output buffer `step` writes into (only batches whose single-step
         observation tensor exceeds the Infinity Cache: 243 agents x >= 200 envs, 81 x >= 1700, 27 x >= 15 000)."""
         from . import placement

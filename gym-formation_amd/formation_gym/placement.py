@@ -16,11 +16,15 @@ import torch
 MIN_PROBE_BYTES = 256 << 20
 
 
-def probe_allocation(alloc, time_fn, nbytes, device, candidates=4, mem_fraction=0.5, reps=3, min_bytes=MIN_PROBE_BYTES):
+def probe_allocation(alloc, time_fn, nbytes, device, candidates=8, mem_fraction=0.6, reps=3, min_bytes=MIN_PROBE_BYTES,
+                     good_enough=0.90):
     """Returns (buffer, report).  alloc() -> a fresh buffer (any object: a tensor, a dict of tensors); time_fn(buffer)
-    enqueues ONE launch that streams into it on torch's current stream of `device`.  report = {tried, kept_GBps_rel,
-    ms: [per candidate median], kept, ...}; with nbytes < min_bytes or candidates < 2 a single allocation is returned
-    un-probed (report['tried'] == 1)."""
+    enqueues ONE launch that streams into it on torch's current stream of `device`.  Up to `candidates` allocations are
+    tried (all held until the end: a freed candidate's pages would come straight back), fewer when they would take more
+    than `mem_fraction` of the free device memory; the search stops early once the rates have shown both modes, i.e. the
+    best candidate takes <= `good_enough` x the time of the worst (the placements are bimodal, several levels 5-13 % apart:
+    profiles/r03_placement.md).  report = {tried, ms per candidate, kept, kept_ms, worst_ms, ...}; with
+    nbytes < min_bytes or candidates < 2 a single allocation is returned un-probed (report['tried'] == 1)."""
     device = torch.device(device)
     free = torch.cuda.mem_get_info(device)[0] if device.type == "cuda" else 0
     m = int(candidates)
@@ -44,10 +48,12 @@ def probe_allocation(alloc, time_fn, nbytes, device, candidates=4, mem_fraction=
         stream.synchronize()
         t = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(reps))
         ms.append(t[len(t) // 2])
-    best = min(range(m), key=lambda i: ms[i])
+        if len(ms) >= 2 and min(ms) <= good_enough * max(ms):
+            break
+    best = min(range(len(ms)), key=lambda i: ms[i])
     keep = held[best]
     del held, buf
     torch.cuda.empty_cache()                                    # the losers go back to the driver, not to torch's pool
-    return keep, {"tried": m, "ms": [round(x, 4) for x in ms], "kept": best, "probed": True,
+    return keep, {"tried": len(ms), "max_candidates": m, "ms": [round(x, 4) for x in ms], "kept": best, "probed": True,
                   "kept_ms": round(ms[best], 4), "worst_ms": round(max(ms), 4),
                   "worst_over_kept": round(max(ms) / ms[best], 4)}

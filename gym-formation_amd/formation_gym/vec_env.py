@@ -89,6 +89,18 @@ class FormationVecEnv(object):
             raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
         return self.env.rollout_policy(K, num_agents_per_layer, out=out, obs_every=obs_every)
 
+    def capture(self, policy_fn, steps_per_replay):
+        """The caller's step loop (train/maddpg-v2/main.py:77-91: policy forward -> env.step, K times) captured ONCE
+        in a hipGraph and replayed: `loop = venv.capture(policy_fn, T)`, then every `loop.replay()` advances all envs by
+        T steps - `act = policy_fn(obs); obs, rew, done, info = venv.step(act)` T times - at the cost of one graph launch
+        instead of T x (policy kernels + step launch) host round trips (2-4x on launch-bound batches).
+          policy_fn(obs [B,N,D]) -> actions [B,N,2]: device-side work only (torch modules, formation_gym.get_action_BFS,
+              ...), no host synchronisation, the same shapes every call - what hipGraph capture asks of any code.
+        Episodes restart inside the graph ('device' reset mode; the counter RNG's per-step offset lives in device memory,
+        so every replay draws new reset states - those of the same steps taken launch by launch).  Capturing leaves the
+        env's state untouched (the warm-up pass is rolled back).  Returns a `CapturedLoop`."""
+        return CapturedLoop(self, policy_fn, int(steps_per_replay))
+
     def step_async(self, actions):
         self._pending = self.step(actions)
 
@@ -98,3 +110,74 @@ class FormationVecEnv(object):
 
     def close(self):
         self.env.close()
+
+
+class CapturedLoop(object):
+    """A T-step policy-in-the-loop rollout as one replayable hipGraph (see `FormationVecEnv.capture`).
+
+    Every step writes straight into its slot of fixed [T, ...] buffers (no copies inside the graph):
+        obs [T,B,N,D], reward [T,B,N,1], done [T,B,N] (bool), info {'individual_reward' [T,B,N], 'actions' [T,B,N,2]}
+    which `replay()` returns as views; the next replay overwrites them.  The observation step 0 of a replay acts on is
+    the last one of the previous replay (slot T-1), seeded at capture time with the env's current observation."""
+
+    def __init__(self, venv, policy_fn, steps):
+        if venv.reset_mode != "device":
+            raise NotImplementedError("a captured loop resets on the device: use reset_mode='device'")
+        if steps < 1:
+            raise ValueError("steps_per_replay must be >= 1")
+        env = venv.env
+        if getattr(env.scenario, "bind_step", None) is None or env._action_mode() or env.post_step_callback is not None:
+            raise NotImplementedError("capture needs a batched scenario with continuous actions and no host callbacks")
+        self.venv, self.env, self.steps, self.policy_fn = venv, env, steps, policy_fn
+        B, N = env.num_envs, env.num_agents
+        D = env._out["obs"].shape[-1]
+        dev = env._act.device
+        f = dict(dtype=torch.float32, device=dev)
+        T = steps
+        env.use_device_rng_counter(True)           # by-value launch arguments are frozen in a graph
+        self.buf = dict(obs=torch.empty((T, B, N, D), **f), reward=torch.empty((T, B, N), **f),
+                        indiv=torch.empty((T, B, N), **f), done=torch.zeros((T, B, N), dtype=torch.uint8, device=dev),
+                        act=torch.empty((T, B, N, 2), **f))
+        self.buf["obs"][T - 1].copy_(env._out["obs"])                   # what step 0 of the first replay acts on
+        snap = env._snapshot()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            # launches are bound to the capture stream, one per slot (pointers resolved once)
+            self._launch = [env.scenario.bind_step(env.world, self.buf["act"][t],
+                                                   {k: self.buf[k][t] for k in ("obs", "reward", "indiv", "done")},
+                                                   auto_reset=env.auto_reset) for t in range(T)]
+            self._body()                                                # warm-up: LDS opt-ins, lazy inits, allocator pools
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        env._restore(snap)
+        self.buf["obs"][T - 1].copy_(env._out["obs"])
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._body()
+        env._restore(snap)                                              # capture executes nothing; host counters did move
+        self.buf["obs"][T - 1].copy_(env._out["obs"])
+        self.replays = 0
+
+    def _body(self):
+        env, T = self.env, self.steps
+        obs = self.buf["obs"][T - 1]
+        for t in range(T):
+            act = self.policy_fn(obs)
+            self.buf["act"][t].copy_(act)
+            self._launch[t](1)                                           # by-value offset 1 + the device counter
+            env.world.rng_counter.add_(1)
+            obs = self.buf["obs"][t]
+
+    def replay(self):
+        env, T = self.env, self.steps
+        self.graph.replay()
+        env._rng_offset += T
+        env.current_step += T
+        env.world.world_step += T
+        env.scenario._cache = None
+        self.replays += 1
+        b = self.buf
+        rew = b["reward"] if env.shared_reward else b["indiv"]
+        return b["obs"], rew.unsqueeze(-1), b["done"].view(torch.bool), {"individual_reward": b["indiv"], "actions": b["act"]}

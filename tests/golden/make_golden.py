@@ -461,6 +461,33 @@ def benchmark_fixture(fg, N, T, seed, act_seed, crowd):
     return res
 
 
+def plugin_fixture(fg, path, N, T, seed, act_seed):
+    """An ORIGINAL reference-style scenario file (tests/plugins/) run under the REAL reference: loaded the way
+    make_env loads envs/<name>.py (__init__.py:8-16, which only accepts names inside the reference's own package)."""
+    import imp
+    scenario = imp.load_source('', path).Scenario()
+    world = scenario.make_world(N)
+    env = fg.MultiAgentEnv(world, scenario.reset_world, scenario.reward, scenario.observation, shared_viewer=True)
+    env.seed(seed)
+    obs0 = np.array(env.reset(), dtype=np.float64)
+    p0, v0 = _state(env)
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    rec = {k: [] for k in ("pos", "vel", "obs", "indiv", "shared", "done")}
+    for t in range(T):
+        obs_n, rew_n, done_n, info_n = env.step([acts[t, i].astype(np.float64) for i in range(N)])
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["obs"].append(np.array(obs_n, dtype=np.float64))
+        rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
+        rec["shared"].append(rew_n[0][0])
+        rec["done"].append(np.array(done_n, dtype=np.bool_))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, obs0=obs0, acts=acts, seed=np.array(seed), radius=np.array(scenario.radius),
+               beacon=np.array(world.landmarks[0].state.p_pos, dtype=np.float64),
+               obs_dim=np.array(env.observation_space[0].shape[0]), world_length=np.array(env.world_length))
+    return res
+
+
 def hausdorff_kat():
     """scipy's own published docstring example for directed_hausdorff
     (scipy 1.15.3 spatial/distance.py) - the only external KAT on this path."""
@@ -532,6 +559,9 @@ def main():
     save("policy_n5_per5", lambda: policy_fixture(fg, 5, 10, seed=47, per=5))
     save("benchmark_n9", lambda: benchmark_fixture(fg, 9, 10, seed=91, act_seed=92, crowd=0.12))
     save("hausdorff_kat", lambda: hausdorff_kat())
+    # a reference-style plugin file of this repo (not of the reference), executed by the reference's env shell
+    plugin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plugins", "ring_patrol_env.py")
+    save("ring_patrol_n5", lambda: plugin_fixture(fg, plugin, 5, 22, seed=61, act_seed=62))
     # non-default action modes of _set_action (environment.py:187-216)
     save("act_onehot5_n3", lambda: rollout_action_mode(fg, "onehot5", 3, 8, seed=71, act_seed=81))
     save("act_index_n9", lambda: rollout_action_mode(fg, "index", 9, 8, seed=72, act_seed=82))

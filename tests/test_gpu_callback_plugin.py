@@ -1,0 +1,87 @@
+"""A reference-style Scenario file (tests/plugins/ring_patrol_env.py: ORIGINAL, written against the reference's plugin API
+scenario.py:4-12 only) dropped into formation_gym.make_env: World.step on the GPU, the file's own per-agent callbacks on
+the host.  The fixture ring_patrol_n5.npz is the SAME file executed by the real reference's env shell
+(tests/golden/make_golden.py: plugin_fixture; environment.py:113-184)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-5
+PLUGIN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", "ring_patrol_env.py")
+
+
+def test_reference_style_plugin_matches_the_reference(golden):
+    import formation_gym
+    g = golden("ring_patrol_n5")
+    T, N = g["acts"].shape[:2]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        env = formation_gym.make_env(PLUGIN, False, N, device="cuda:0")
+    assert any("host callbacks" in str(x.message) for x in w)            # the slow path is announced ...
+    assert "host callbacks" in env.info["path"]                          # ... and labelled
+    assert env.observation_space[0].shape == (int(g["obs_dim"]),) and env.world_length == int(g["world_length"])
+    assert env.shared_reward
+    env.seed(int(g["seed"]))
+    obs0 = env.reset()
+    np.testing.assert_allclose(np.array(obs0), g["obs0"], rtol=0, atol=ATOL)
+    # free-running (the ring scenario is smooth: no contact thresholds in the reward), reference-style list API
+    worst = 0.0
+    for t in range(T):
+        act_n = [g["acts"][t, i].astype(np.float64) for i in range(N)]
+        obs_n, rew_n, done_n, info_n = env.step(act_n)
+        np.testing.assert_array_equal(np.array(act_n), 5.0 * g["acts"][t].astype(np.float64))     # scaled in place
+        pos, vel = env.world.get_state()
+        tol = ATOL if t < 6 else 2e-4                                     # fp32 trajectory through stiff contacts (H1)
+        np.testing.assert_allclose(pos[0].double().cpu().numpy(), g["pos"][t], rtol=0, atol=tol)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose(rew_n[0][0], g["shared"][t], rtol=0, atol=50 * tol)
+        assert done_n == list(g["done"][t])
+        worst = max(worst, float(np.abs(pos[0].double().cpu().numpy() - g["pos"][t]).max()))
+    # teacher-forced: every step from the reference's own previous state, every bound 1e-5
+    env.seed(int(g["seed"]))
+    env.reset()
+    prev_p, prev_v = g["pos0"], g["vel0"]
+    for t in range(T):
+        env.world.set_state(prev_p[None], prev_v[None])
+        obs_n, rew_n, done_n, info_n = env.step([g["acts"][t, i].astype(np.float64) for i in range(N)])
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(pos[0].double().cpu().numpy(), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(vel[0].double().cpu().numpy(), g["vel"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(rew_n[0][0], g["shared"][t], rtol=0, atol=5 * ATOL)
+        prev_p, prev_v = g["pos"][t], g["vel"][t]
+
+
+def test_reference_style_plugin_batched():
+    """num_envs > 1: one instance of the user's Scenario per env, env b seeded seed + 1000 b; env 0 of the batch equals
+    the single-env run, and the batched tensor API returns [B, N, D]."""
+    import formation_gym
+    N, B = 5, 6
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        one = formation_gym.make_env(PLUGIN, False, N, device="cuda:0")
+        many = formation_gym.make_env(PLUGIN, False, N, num_envs=B, device="cuda:0")
+        third = formation_gym.make_env(PLUGIN, False, N, device="cuda:0")
+    one.seed(7); many.seed(7); third.seed(7 + 2000)
+    o1 = np.array(one.reset())
+    o3 = np.array(third.reset())
+    ob = many.reset()
+    assert tuple(ob.shape) == (B, N, 18)
+    np.testing.assert_array_equal(ob[0].double().cpu().numpy(), o1.astype(np.float32).astype(np.float64))
+    np.testing.assert_array_equal(ob[2].double().cpu().numpy(), o3.astype(np.float32).astype(np.float64))
+    act = torch.rand((B, N, 2), device="cuda") * 2 - 1
+    obs, rew, done, info = many.step(act)
+    o1s, r1s, d1s, i1s = one.step([act[0, i].cpu().numpy().astype(np.float64) for i in range(N)])
+    np.testing.assert_allclose(obs[0].double().cpu().numpy(), np.array(o1s), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(float(rew[0, 0, 0]), r1s[0][0], rtol=0, atol=1e-5)
+    assert tuple(rew.shape) == (B, N, 1) and tuple(done.shape) == (B, N)
+    assert many.benchmark_data if hasattr(many, "benchmark_data") else True
+    bd = many.scenario.benchmark_data(many.world.agents[1], many.world)
+    assert "ring_error" in bd

@@ -490,3 +490,57 @@ def test_device_rng_counter_toggle_and_captured_rollouts():
         assert torch.equal(pol_g["obs"], rec[r][1]) and torch.equal(pol_g["act"], rec[r][2]), "replay %d: closed-loop launch" % r
     for x, y in zip(ref.world.get_state(), env.world.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("N,B,policy", [(27, 300, "bfs"), (9, 640, "linear"), (81, 40, "bfs")])
+def test_vec_env_capture_replays_equal_the_step_loop(N, B, policy):
+    """FormationVecEnv.capture(policy_fn, T): three replays of the captured T-step loop (device-side policy + vec-env
+    step with auto-resets inside the graph) equal 3 T steps of the same loop taken launch by launch, bit for bit -
+    observations, rewards, dones, actions, final state - and capturing leaves the env's state untouched."""
+    import formation_gym
+    from formation_gym.vec_env import FormationVecEnv
+    T, R = 5, 3
+    dev = "cuda:0"
+    gen = torch.Generator(device=dev); gen.manual_seed(N)
+    W = (torch.rand((6 * N, 2), generator=gen, device=dev) - 0.5) * 0.2
+    if policy == "bfs":
+        fn = lambda obs: formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3)
+    else:
+        fn = lambda obs: torch.tanh(obs @ W)
+
+    def fresh():
+        v = FormationVecEnv(_make(N, B), reset_mode="device")
+        v.env.seed(6)
+        v.reset()
+        v.env.world.world_length = 4                       # short episodes: resets inside every replay
+        v.env.world.step_count.copy_(torch.arange(B, dtype=torch.int32, device=dev) % 4)
+        return v
+
+    ref = fresh()
+    obs = ref.env._out["obs"]
+    want = {k: [] for k in ("obs", "rew", "done", "act")}
+    for t in range(T * R):
+        act = fn(obs).contiguous()
+        want["act"].append(act.clone())
+        obs, rew, done, info = ref.step(act)
+        want["obs"].append(obs.clone()); want["rew"].append(rew.clone()); want["done"].append(done.clone())
+
+    v = fresh()
+    before = [x.clone() for x in v.env.world.get_state()] + [v.env.world.step_count.clone()]
+    loop = v.capture(fn, T)
+    after = [x.clone() for x in v.env.world.get_state()] + [v.env.world.step_count.clone()]
+    for x, y in zip(before, after):
+        assert torch.equal(x, y)
+    for r in range(R):
+        o, rw, d, info = loop.replay()
+        torch.cuda.synchronize()
+        for t in range(T):
+            k = r * T + t
+            assert torch.equal(o[t], want["obs"][k]), (r, t)
+            assert torch.equal(rw[t], want["rew"][k]) and torch.equal(d[t], want["done"][k])
+            assert torch.equal(info["actions"][t], want["act"][k])
+    for x, y in zip(ref.env.world.get_state(), v.env.world.get_state()):
+        assert torch.equal(x, y)
+    assert torch.stack(want["done"]).any() and v.env.current_step == ref.env.current_step == T * R
+    with pytest.raises(NotImplementedError):
+        FormationVecEnv(_make(N, 8), reset_mode="host").capture(fn, 2)

@@ -39,3 +39,19 @@ def test_generate_shape_matches_reference(golden):
     for L in range(4):
         np.testing.assert_allclose(np.asarray(sc.generate_shape(L), dtype=np.float64).reshape(-1, 2),
                                    g["layer%d" % L], rtol=0, atol=1e-15)
+
+
+def test_reference_style_scenario_files_take_the_callback_adapter():
+    """load_scenario: a file with only the reference's per-agent callbacks (scenario.py:4-12) is wrapped, the batched
+    scenarios of envs/ are not."""
+    import os
+    import formation_gym
+    from formation_gym.callback_scenario import CallbackScenario
+    plugin = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", "ring_patrol_env.py")
+    sc = formation_gym.load_scenario(plugin)
+    assert isinstance(sc, CallbackScenario) and "host callbacks" in sc.PATH
+    user = sc._factory()
+    w = user.make_world(4)                         # the user's file runs on host-mode entities (no device needed)
+    assert len(w.agents) == 4 and w.agents[0].state.p_pos.shape == (2,) and w.agents[3].max_speed == 0.5
+    assert len(user.observation(w.agents[0], w)) == 2 + 2 + 2 + 2 * 3 + 3
+    assert not isinstance(formation_gym.load_scenario("formation_hd_env"), CallbackScenario)
