@@ -100,15 +100,31 @@ def _cpu_model():
         return "unknown"
 
 
+def usable_cores():
+    """CPU cores this process can actually keep busy: the affinity mask, cut down to the cgroup's CPU quota
+    (a GPU box hands a 16-core share of a 256-thread host to each lease: cpu.max = '1600000 100000')."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()])):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(n_agents, budget_s=12.0):
     """The oracle's per-env port (same loop structure as the reference) on the host
     cores: one env per process, bounded sample.  Reported baseline only."""
     import multiprocessing as mp
     host_cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))                  # the cores this process may actually use
-    except AttributeError:
-        cores = host_cores
+    cores = usable_cores()                                    # affinity mask and cgroup CPU quota of this process
     probe = _cpu_port_worker((n_agents, 2, 12345))          # seconds for 2 steps, 1 core
     per_step = max(probe / 2, 1e-4)
     steps = int(max(3, min(400, budget_s / per_step)))

@@ -71,16 +71,26 @@ __global__ __launch_bounds__(256) void update_comm_kernel(const FgParams p, int 
 //   double = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two 32-bit outputs; U(-1,1) = -1 + 2 d.
 // mt_state: uint32 [B][626] = key[624], pos, unused.
 // ---------------------------------------------------------------------------
+// Which envs reset: those whose mask byte is set (mask != NULL), every env (mask NULL, world_length <= 0), or - the
+// vec-env worker's rule, decided on the device without a mask upload or a host read-back - those whose episode is over,
+// step[b] >= world_length (mask NULL, world_length > 0; env_wrappers.py:14-18).  With `obs` the workgroup also writes the
+// RESET observation of its env (formation_hd_env.py:52-59 on the fresh state: what the worker returns), the same bits
+// fg_observe_hd gives, so that a vec-env step needs no second pass over the whole batch.
 __global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8_t* __restrict__ mask,
                                                        uint32_t* __restrict__ mt_state,
                                                        float* px, float* py, float* vx, float* vy,
-                                                       float* shape, float* ivel, float* lm_pos, int32_t* step) {
+                                                       float* shape, float* ivel, float* lm_pos, int32_t* step,
+                                                       int world_length, float* obs, long long obs_pitch2) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (b >= B || (mask && !mask[b])) return;
+    if (!mask && world_length > 0 && step[b] < world_length) return;
     uint32_t* const mt = lds_u32;                      // [624]
     uint32_t* const outs = lds_u32 + 624;              // [8N + 4] tempered outputs
     double* const dsum = reinterpret_cast<double*>(lds_u32 + 624 + ((8 * N + 4 + 1) & ~1));   // [2] mean of raw
+    float2* const P = reinterpret_cast<float2*>(dsum + 2);   // [N] fresh positions, [N] ideal shape, [1] ideal velocity
+    float2* const S = P + N;
+    float2* const IV = S + N;
     uint32_t* const gstate = mt_state + (size_t)b * 626;
     for (int q = tid; q < 624; q += 256) mt[q] = gstate[q];
     int pos = (int)gstate[624];
@@ -135,18 +145,42 @@ __global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8
     __syncthreads();
     for (int i = tid; i < N; i += 256) {
         const size_t o = (size_t)b * N + i;
-        px[o] = (float)draw(2 * i); py[o] = (float)draw(2 * i + 1);
+        const float2 pp = make_float2((float)draw(2 * i), (float)draw(2 * i + 1));
+        px[o] = pp.x; py[o] = pp.y;
         vx[o] = 0.f; vy[o] = 0.f;
         const double rx = draw(2 * N + 2 * i), ry = draw(2 * N + 2 * i + 1);
-        shape[2 * o] = (float)(rx - dsum[0]); shape[2 * o + 1] = (float)(ry - dsum[1]);
+        const float2 ss = make_float2((float)(rx - dsum[0]), (float)(ry - dsum[1]));
+        shape[2 * o] = ss.x; shape[2 * o + 1] = ss.y;
         if (lm_pos) { lm_pos[2 * o] = (float)rx; lm_pos[2 * o + 1] = (float)ry; }
+        P[i] = pp; S[i] = ss;
     }
     if (tid == 0) {
-        ivel[2 * b] = (float)draw(4 * N); ivel[2 * b + 1] = (float)draw(4 * N + 1);
+        const float2 iv = make_float2((float)draw(4 * N), (float)draw(4 * N + 1));
+        ivel[2 * b] = iv.x; ivel[2 * b + 1] = iv.y;
+        IV[0] = iv;
         if (step) step[b] = 0;
         gstate[624] = (uint32_t)pos;
     }
     for (int q = tid; q < 624; q += 256) gstate[q] = mt[q];
+    if (obs) {                                         // the reset observation: [0 | p_j - p_i (j != i) | 0 .. | shape | ideal_vel]
+        __syncthreads();
+        float2* const out = reinterpret_cast<float2*>(obs) + (size_t)b * (size_t)obs_pitch2;
+        const unsigned n3 = 3u * (unsigned)N, total = n3 * (unsigned)N;
+        for (unsigned q = tid; q < total; q += 256) {
+            const unsigned row = q / n3, u = q - row * n3;
+            float2 val = make_float2(0.f, 0.f);
+            if (u >= 1u && u < (unsigned)N) {
+                const unsigned j = u - 1u, idx = j + (j >= row ? 1u : 0u);
+                const float2 a2 = P[idx], c2 = P[row];
+                val = make_float2(a2.x - c2.x, a2.y - c2.y);
+            } else if (u >= 2u * N - 1u && u < n3 - 1u) {
+                val = S[u - (2u * N - 1u)];
+            } else if (u == n3 - 1u) {
+                val = IV[0];
+            }
+            out[q] = val;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

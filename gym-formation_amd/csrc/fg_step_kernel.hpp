@@ -53,7 +53,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     // pair loops of 17..32 agents: 7 iterations (14 partners) per unrolled block, so that a block's LDS reads are in flight
     // together - only two of a SIMD's waves own agents in this geometry, little else hides the round trips
     // (27 x 4096: 15.6 -> 15.3 us, profiles/r02_step/step27_micro.txt)
-    constexpr int UNR = (NC > 16 && NC <= 32) ? 7 : 2;
+    constexpr int UNR = (NC > 16 && NC <= 32) ? 7 : (T >= 1024 ? 1 : 2);   // 1024 threads: 128 VGPRs per lane, no room to unroll
     real2* const A = env_tables(smem, e < E ? e : 0, N);
     real2* const V = A + 3 * N;
     real2* const NV = A + 4 * N;             // -velocity, read by the row writer
@@ -284,7 +284,9 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                     unsigned q = head + 2u * (q_lo + tid);
                     unsigned rp = q / n3;
                     unsigned u = q - rp * n3;
-#pragma unroll 2
+                    // 1024-thread workgroups have 128 VGPRs per lane: two units in flight there spilled (IDX / OPTS instantiations)
+                    constexpr int FLAT_UNR = (T >= 1024) ? 1 : 2;
+#pragma unroll FLAT_UNR
                     for (unsigned q2 = q_lo + tid; q2 < q_hi; q2 += T) {
                         unsigned u1 = u + 1u, rp1 = rp;
                         if (u1 == n3) { u1 = 0u; rp1 += 1u; }

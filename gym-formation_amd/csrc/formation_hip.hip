@@ -545,21 +545,43 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     return FG_OK;
 }
 
-int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
-                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                   float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
+static int launch_mt_reset(int B, int N, const uint8_t* mask, uint32_t* mt_state,
+                           float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                           float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step,
+                           int world_length, float* obs, long long obs_env_pitch, void* stream) {
     const DeviceGuard device_guard(stream, pos_x);
     if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 2 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
     if (!mt_state || !pos_x || !pos_y || !vel_x || !vel_y || !ideal_shape || !ideal_vel)
         return fail(FG_ERR_BAD_ARG, "fg_reset_hd_mt: a required pointer is NULL%s");
-    const int lds = (624 + ((8 * N + 4 + 1) & ~1)) * (int)sizeof(uint32_t) + 2 * (int)sizeof(double);
+    const long long nenv = 6LL * N * N;
+    const long long pitch = obs_env_pitch ? obs_env_pitch : nenv;
+    if (obs && (pitch < nenv || (pitch & 1))) return fail(FG_ERR_BAD_ARG, "obs_env_pitch must be 0 or an even number of floats >= 6 N^2%s");
+    if ((uintptr_t)obs & 7u) return fail(FG_ERR_ALIGNMENT, "obs must be 8-byte aligned%s");
+    const int lds = (624 + ((8 * N + 4 + 1) & ~1)) * (int)sizeof(uint32_t) + 2 * (int)sizeof(double) +
+                    (2 * N + 1) * (int)sizeof(float2);
     hipLaunchKernelGGL(mt_reset_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, B, N, mask, mt_state,
-                       pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step);
+                       pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step, world_length, obs, pitch / 2);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "mt reset launch failed: %s", hipGetErrorString(err));
     return FG_OK;
+}
+
+int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
+                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                   float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream) {
+    return launch_mt_reset(B, N, mask, mt_state, pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step,
+                           0, nullptr, 0, stream);
+}
+
+int fg_reset_hd_mt_done(int B, int N, int world_length, uint32_t* mt_state,
+                        float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                        float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step,
+                        float* obs, int64_t obs_env_pitch, void* stream) {
+    if (world_length <= 0 || !step) return fail(FG_ERR_BAD_ARG, "fg_reset_hd_mt_done: world_length > 0 and step required%s");
+    return launch_mt_reset(B, N, nullptr, mt_state, pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step,
+                           world_length, obs, (long long)obs_env_pitch, stream);
 }
 
 int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, float* comm_state, void* stream) {

@@ -101,6 +101,7 @@ SIGNATURES = {
     "fg_rollout_hd": (_I, [_PP, _I, _I, _I] + [_P] * 12 + [_I, _P]),
     "fg_reset_hd": (_I, [_PP, _I, _I] + [_P] * 9),
     "fg_reset_hd_mt": (_I, [_I, _I] + [_P] * 11),
+    "fg_reset_hd_mt_done": (_I, [_I, _I, _I] + [_P] * 10 + [ctypes.c_int64, _P]),
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),

@@ -296,6 +296,20 @@ class Scenario(BaseScenario):
             world.step_count.data_ptr(), _native.current_stream(world.device)))
         self._cache = None
 
+    def reset_mt_done(self, world, obs=None):
+        """The vec-env worker's `if all(done): ob = env.reset()` (env_wrappers.py:14-18) for every env at once, decided on
+        the device (`fg_reset_hd_mt_done`): envs whose step counter has reached world_length restart from their own
+        MT19937 streams and, with `obs` [B, N, 6N], get their reset observation written over the step's."""
+        if getattr(self, "_mt_state", None) is None or self._mt_state.shape[0] != world.num_envs:
+            self.upload_mt_streams(world)
+        _native.check(_native.load().fg_reset_hd_mt_done(
+            world.num_envs, len(world.agents), int(world.world_length), self._mt_state.data_ptr(),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.landmark_pos.data_ptr(),
+            world.step_count.data_ptr(), _native.ptr(obs), self.obs_env_pitch(obs, len(world.agents)),
+            _native.current_stream(world.device)))
+        self._cache = None
+
     def reset_device(self, world, mask=None, rng_offset=0):
         """Throughput-mode reset on the GPU (counter RNG, distributional parity only)."""
         lib = _native.load()

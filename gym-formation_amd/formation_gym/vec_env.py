@@ -52,16 +52,14 @@ class FormationVecEnv(object):
             if self._host_steps is None:
                 self._host_steps = self.env.world.step_count.cpu().numpy().astype("int64") - 1
             self._host_steps += 1
-            finished = self._host_steps >= self.env.world_length
+            finished = self._host_steps >= int(self.env.world.world_length)
             if finished.any():
-                sc, world = self.env.scenario, self.env.world
-                mask = torch.as_tensor(finished.astype("uint8")).to(world.device, non_blocking=True)
-                # the reset and the observation launch below write state and observations only: reward / done / info
-                # keep their pre-reset values (as in 'device' mode they are views of buffers the next step overwrites)
-                sc.reset_mt(world, mask)
-                sc.observe_batch(world, {"obs": self.env._out["obs"]})
+                # ONE launch, decided on the device (step counter >= world_length): the finished envs restart from their
+                # own MT19937 streams and their reset observation replaces the step's; no mask upload, no second pass over
+                # the batch.  reward / done / info keep their pre-reset values.  The host mirror of the (deterministic)
+                # step counters only serves to skip the launch on steps in which nobody finishes.
+                self.env.scenario.reset_mt_done(self.env.world, self.env._out["obs"])
                 self._host_steps[finished] = 0
-                self._keep = mask
             return self.env._out["obs"], rew, done, info
         if self.reset_mode == "host":
             mask = done.all(dim=1)

@@ -228,6 +228,16 @@ int fg_reset_hd_mt(int B, int N, const uint8_t* mask, uint32_t* mt_state,
                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                    float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step, void* stream);
 
+/* The vec-env worker's reset (train/maddpg-v2/utils/env_wrappers.py:14-18: `if all(done): ob = env.reset()`) decided ON
+ * THE DEVICE: every env whose episode is over (step[b] >= world_length) is re-initialised from its own MT19937 stream as
+ * fg_reset_hd_mt does, and - if obs is not NULL - its block of the observation tensor [B][N][6N] (env blocks
+ * obs_env_pitch floats apart, 0 = contiguous) is overwritten with the RESET observation (formation_hd_env.py:52-59 on the
+ * fresh state, the bits fg_observe_hd gives).  No mask upload, no host read-back, one launch. */
+int fg_reset_hd_mt_done(int B, int N, int world_length, uint32_t* mt_state,
+                        float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                        float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step,
+                        float* obs, int64_t obs_env_pitch, void* stream);
+
 /* World.update_agent_state (core.py:279-286) for all B x N agents: state.c = action.c + c_noise * N(0,1) for a
  * non-silent agent, zeros for a silent one (agent_props[i][5] < 0; without a table every agent is non-silent and
  * noise-free).  dim_c = 2.  action_c, comm_state float [B][N][2]; the noise comes from the device counter RNG

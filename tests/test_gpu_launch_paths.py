@@ -544,3 +544,58 @@ def test_vec_env_capture_replays_equal_the_step_loop(N, B, policy):
     assert torch.stack(want["done"]).any() and v.env.current_step == ref.env.current_step == T * R
     with pytest.raises(NotImplementedError):
         FormationVecEnv(_make(N, 8), reset_mode="host").capture(fn, 2)
+
+
+@pytest.mark.parametrize("N,B_split", [(81, 1), (100, 96), (243, 96), (243, 1), (81, 128)])
+def test_split_step_with_index_outputs_world_options_and_padded_pitch(N, B_split):
+    """The split single step: landmark-index outputs, World options (walls + max_speed: the OPTS instantiation),
+    a padded observation pitch and auto-reset at the reset step, each against the same envs inside a batch large enough to
+    take the single fused launch - bit for bit."""
+    from formation_gym.core import Wall
+    B = 140
+    step0 = np.where(np.arange(B) % 2 == 0, 99, 7)
+    pitch = -(-6 * N * N // 32) * 32 + 32
+
+    def build(nenv, opts):
+        e = _make(N, nenv)
+        e.scenario.seed(8)
+        if opts:
+            for a in e.world.agents:
+                a.max_speed = 0.7
+            e.world.walls = [Wall("V", -0.8, (-1.0, 1.0), 0.1), Wall("H", 0.7, (-0.5, 0.5), 0.2)]
+        e.auto_reset = True
+        e.enable_assignments(True)
+        return e
+
+    for opts in (False, True):
+        big = build(B, opts)
+        big.scenario.reset_device(big.world, rng_offset=777)
+        big.world.pos_x.mul_(0.4); big.world.pos_y.mul_(0.4)
+        big.world.step_count.copy_(torch.as_tensor(step0, dtype=torch.int32))
+        small = build(B_split, opts)
+        pos, vel = big.world.get_state()
+        small.world.set_state(pos[:B_split], vel[:B_split])
+        small.scenario.ideal_shape.copy_(big.scenario.ideal_shape[:B_split]); small.scenario.ideal_vel.copy_(big.scenario.ideal_vel[:B_split])
+        small.world.step_count.copy_(big.world.step_count[:B_split])
+        outs = []
+        for e, n in ((big, B), (small, B_split)):
+            f = dict(dtype=torch.float32, device="cuda")
+            raw = torch.full((n, pitch), -7.0, **f)
+            out = dict(obs=raw[:, :6 * N * N].view(n, N, 6 * N), reward=torch.empty((n, N), **f), indiv=torch.empty((n, N), **f),
+                       done=torch.zeros((n, N), dtype=torch.uint8, device="cuda"),
+                       near_lm=torch.zeros((n, N), dtype=torch.int32, device="cuda"),
+                       near_ag=torch.zeros((n, N), dtype=torch.int32, device="cuda"),
+                       hd_idx=torch.zeros((n, 4), dtype=torch.int32, device="cuda"))
+            outs.append((out, raw))
+        gen = torch.Generator(device="cuda"); gen.manual_seed(N + B_split)
+        for t in range(2):
+            act = torch.rand((B, N, 2), generator=gen, device="cuda") * 2 - 1
+            big.scenario.step_batch(big.world, act, outs[0][0], auto_reset=True, rng_offset=5 + t)
+            small.scenario.step_batch(small.world, act[:B_split].contiguous(), outs[1][0], auto_reset=True, rng_offset=5 + t)
+            for k in outs[0][0]:
+                assert torch.equal(outs[0][0][k][:B_split], outs[1][0][k]), (opts, t, k)
+            assert bool((outs[1][1][:, 6 * N * N:] == -7.0).all())            # the pad between env blocks is untouched
+            assert bool(outs[1][0]["done"].any()) == (t == 0)
+        for x, y in zip(big.world.get_state(), small.world.get_state()):
+            assert torch.equal(x[:B_split], y)
+        assert torch.equal(big.scenario.ideal_shape[:B_split], small.scenario.ideal_shape)

@@ -936,6 +936,36 @@ def test_vec_env_device_mt_matches_host_reset_mode():
         assert torch.equal(envs[0][0].world.step_count, envs[1][0].world.step_count)
 
 
+@pytest.mark.parametrize("N,B,L", [(27, 130, 4), (81, 12, 3), (10, 70, 5), (243, 3, 2)])
+def test_vec_env_device_mt_single_launch_reset_at_other_sizes(N, B, L):
+    """fg_reset_hd_mt_done (reset decided on the device + reset observation in the same launch) against the 'host' reset
+    mode over several short episodes at mixed phases: observations, rewards, dones, final state and the MT19937 streams'
+    continuation agree bit for bit."""
+    from formation_gym.vec_env import FormationVecEnv
+    envs = []
+    phase = (np.arange(B) * 3) % L
+    for mode in ("device_mt", "host"):
+        e = _make(N, B)
+        e.seed(33)
+        v = FormationVecEnv(e, reset_mode=mode)
+        v.reset()
+        e.world.world_length = L
+        e.world.step_count.copy_(torch.as_tensor(phase.astype(np.int32)))
+        if mode == "device_mt":
+            v._host_steps = phase.astype(np.int64).copy()
+        envs.append((e, v))
+    rs = np.random.RandomState(6)
+    for t in range(3 * L + 1):
+        act = torch.as_tensor(rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)).cuda()
+        outs = [v.step(act) for (_, v) in envs]
+        for k in range(3):
+            assert torch.equal(outs[0][k], outs[1][k]), (t, k)
+    for x, y in zip(envs[0][0].world.get_state(), envs[1][0].world.get_state()):
+        assert torch.equal(x, y)
+    assert torch.equal(envs[0][0].world.step_count, envs[1][0].world.step_count)
+    assert torch.equal(envs[0][0].scenario.ideal_shape, envs[1][0].scenario.ideal_shape)
+
+
 def test_episode_statistics_match_oracle_over_100_steps():
     """Chaotic fp32 trajectories cannot match fp64 pointwise over an episode, but nothing may
     drift systematically: over 1024 envs x 100 steps the per-step batch means of reward, speed
