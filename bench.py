@@ -329,14 +329,15 @@ def main():
         env.auto_reset = not a.no_auto_reset                     # vec-env semantics: episodes restart on device
         env.world.step_count.zero_()
 
-        # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB
+        # steps per rollout launch, bounded so that the [K,B,N,6N] rollout buffer stays under 48 GB (fewer steps per launch
+        # cost more than a better placement gains: 243 x 8192 at 2 steps per launch 2.01 ms/step, at 4 1.83)
         # (ranks that SHARE a GPU - a rehearsal of N ranks on one device - share its memory too)
         chunk = max(1, min(chunk_req, int(48e9 / gpu_share // max(1, B * N * 6 * N * 4)) or 1))
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
         placed = {}
         if a.placement_candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
-            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.6 / gpu_share)
+            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.7 / gpu_share)
         out = env._out
         act_pool, launchers = None, []
         if not policy:
@@ -354,7 +355,8 @@ def main():
                 lo_ = t % P
                 if lo_ + k > P:
                     k = P - lo_
-                env.rollout(act_pool[lo_:lo_ + k], out={k2: v[:k // (a.obs_every if k2 == "obs" else 1)] for k2, v in seq.items()},
+                env.rollout(act_pool[lo_:lo_ + k], out={k2: v[:k // (a.obs_every if k2 == "obs" else 1)] for k2, v in seq.items()
+                                                        if torch.is_tensor(v)},
                             obs_every=a.obs_every)
                 t += k
 
@@ -362,7 +364,7 @@ def main():
             t = start
             while t < start + n:
                 k = min(chunk, start + n - t)
-                env.rollout_policy(k, 3, out={k2: v[:k] for k2, v in seq.items()})
+                env.rollout_policy(k, 3, out={k2: v[:k] for k2, v in seq.items() if torch.is_tensor(v)})
                 t += k
 
         def run_policy_steps(n, start):
@@ -424,7 +426,7 @@ def main():
             if a.obs_every == 1:
                 # the observation buffer is PLACED: candidates timed with this env's own launch, the fastest kept
                 seq = env.alloc_rollout_buffers(chunk, obs_env_pitch=0 if pitch == 6 * N * N else pitch, policy=policy,
-                                                candidates=a.placement_candidates, mem_fraction=0.6 / gpu_share)
+                                                candidates=a.placement_candidates, mem_fraction=0.7 / gpu_share)
                 placed["rollout"] = env.placement
             else:
                 obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)
@@ -456,8 +458,26 @@ def main():
             if other == "rollout":
                 r["extra"]["chunk"] = chunk
             if policy:
+                # the same launch-by-launch loop captured once in a hipGraph and replayed (FormationVecEnv.capture): what a
+                # trainer-shaped loop (policy forward -> env.step, train/maddpg-v2/main.py:77-91) gets without writing
+                # capture code; 20 steps per replay, device auto-reset inside the graph
+                from formation_gym.vec_env import FormationVecEnv
+                env.auto_reset = False                         # FormationVecEnv switches it on again ('device' mode)
+                venv = FormationVecEnv(env, reset_mode="device")
+                env.scenario.observe_batch(env.world, {"obs": out["obs"], "reward": out["reward"]})
+                loop = venv.capture(lambda o, out=None: formation_gym.get_action_BFS(formation_gym.ezpolicy, o, 3, out=out), 20)
+                dg, _, _ = timed(lambda n_, s_: [loop.replay() for _ in range(max(1, n_ // 20))], 20 * max(1, other_steps // 20),
+                                 20)
+                mg = median(dg)
+                gsteps = 20 * max(1, other_steps // 20)
+                r["extra"]["graph_replay"] = {
+                    "what": "FormationVecEnv.capture(get_action_BFS(ezpolicy), 20): the launch-by-launch loop (fg_policy_bfs + "
+                            "fg_step_hd per step) as one replayed hipGraph of 20 steps",
+                    "ms_per_step": round(mg / gsteps, 5),
+                    "env_steps_per_s": round(world_size * B * gsteps / (mg * 1e-3), 1)}
+                del loop, venv
                 # the demo loop one step at a time in ONE launch per step: fg_rollout_hd_policy with K = 1
-                one = {k2: v[:1] for k2, v in seq.items()}
+                one = {k2: v[:1] for k2, v in seq.items() if torch.is_tensor(v)}
                 d3, _, _ = timed(lambda n_, s_: [env.rollout_policy(1, 3, out=one) for _ in range(n_)], other_steps, min(warmup, 40))
                 m3 = median(d3)
                 r["extra"]["fused_single_step_launch"] = {

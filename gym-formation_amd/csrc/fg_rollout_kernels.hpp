@@ -8,6 +8,10 @@
 #include "fg_obs_writers.hpp"
 #include "fg_policy_kernels.hpp"
 
+#ifndef FG_WIDE_SPLIT_ROWS
+#define FG_WIDE_SPLIT_ROWS 0
+#endif
+
 namespace fg {
 
 // ---------------------------------------------------------------------------
@@ -505,9 +509,18 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
+#if FG_WIDE_SPLIT_ROWS
+                // every env by ALL writer waves (contiguous row ranges), env after env: the waves of a workgroup finish a step
+                // together and write one compact window
+                for (int ee = 0; ee < El; ++ee)
+                    write_obs_rows<NC, NWW, 1>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N + (size_t)ee * (roll_block_floats(N) / 2),
+                                               roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                               reinterpret_cast<float2*>(a.obs) + unit0 + (size_t)ee * (size_t)a.obs_pitch, (size_t)a.obs_pitch, 1, 3);
+#else
                 write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, (tid - TP) >> 6,
                                            reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
+#endif
             }
         }
         __syncthreads();

@@ -29,6 +29,7 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <vector>
 #include "fg_common.hpp"
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
@@ -335,6 +336,89 @@ using namespace fg;
 extern "C" {
 
 int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+// ---- placed device memory: address space backed by separately created chunks (HIP virtual memory management) ----
+namespace {
+struct Arena {
+    int dev = 0;
+    size_t chunk = 0, n = 0;
+    char* base = nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> handle;
+    std::vector<char> live;
+    void drop(size_t i) {
+        if (!live[i]) return;
+        (void)hipMemUnmap(base + i * chunk, chunk);
+        (void)hipMemRelease(handle[i]);
+        live[i] = 0;
+    }
+};
+}  // namespace
+
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out) {
+    if (!arena || !base || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena, base and bytes > 0 required%s");
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    hipError_t err = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (err != hipSuccess || gran == 0) return fail(FG_ERR_HIP, "hipMemGetAllocationGranularity failed: %s", hipGetErrorString(err));
+    size_t chunk = chunk_bytes ? (size_t)chunk_bytes : ((size_t)1 << 30);
+    chunk = (chunk + gran - 1) / gran * gran;
+    Arena* a = new Arena();
+    a->dev = device; a->chunk = chunk; a->n = ((size_t)bytes + chunk - 1) / chunk;
+    void* va = nullptr;
+    err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
+    if (err != hipSuccess) { delete a; return fail(FG_ERR_HIP, "hipMemAddressReserve failed: %s", hipGetErrorString(err)); }
+    a->base = (char*)va;
+    a->handle.resize(a->n); a->live.assign(a->n, 0);
+    for (size_t i = 0; i < a->n && err == hipSuccess; ++i) {
+        err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
+        if (err != hipSuccess) break;
+        err = hipMemMap(a->base + i * chunk, chunk, 0, a->handle[i], 0);
+        if (err != hipSuccess) { (void)hipMemRelease(a->handle[i]); break; }
+        a->live[i] = 1;
+    }
+    if (err == hipSuccess) {
+        hipMemAccessDesc desc;
+        memset(&desc, 0, sizeof(desc));
+        desc.location.type = hipMemLocationTypeDevice;
+        desc.location.id = device;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        err = hipMemSetAccess(a->base, a->n * chunk, &desc, 1);
+    }
+    if (err != hipSuccess) {
+        const int rc = fail(FG_ERR_HIP, "fg_arena_create: %s", hipGetErrorString(err));
+        (void)hipGetLastError();
+        for (size_t i = 0; i < a->n; ++i) a->drop(i);
+        (void)hipMemAddressFree(a->base, a->n * chunk);
+        delete a;
+        return rc;
+    }
+    *arena = a; *base = a->base;
+    if (chunk_out) *chunk_out = chunk;
+    return FG_OK;
+}
+
+int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes) {
+    Arena* a = (Arena*)arena;
+    if (!a) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: arena is NULL%s");
+    if (offset + bytes > a->n * a->chunk) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: range beyond the arena%s");
+    const size_t first = (size_t)(offset / a->chunk), last = bytes ? (size_t)((offset + bytes - 1) / a->chunk) : first;
+    for (size_t i = 0; i < a->n; ++i)
+        if (bytes == 0 || i < first || i > last) a->drop(i);
+    return FG_OK;
+}
+
+int fg_arena_destroy(void* arena) {
+    Arena* a = (Arena*)arena;
+    if (!a) return FG_OK;
+    for (size_t i = 0; i < a->n; ++i) a->drop(i);
+    (void)hipMemAddressFree(a->base, a->n * a->chunk);
+    delete a;
+    return FG_OK;
+}
 
 const char* fg_last_error(void) { return g_err; }
 

@@ -93,6 +93,9 @@ _PP = ctypes.POINTER(FgParams)
 SIGNATURES = {
     "fg_abi_version": (_I, []),
     "fg_last_error": (ctypes.c_char_p, []),
+    "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
+    "fg_arena_keep": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64]),
+    "fg_arena_destroy": (_I, [_P]),
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "fg_step_hd_bytes": (ctypes.c_int64, [_I]),
     "fg_step_hd": (_I, [_PP, _I, _I] + [_P] * 16),

@@ -102,6 +102,7 @@ class MultiAgentEnv(object):
         self._launchers = {}              # pre-bound step launches, see _bound_step
         self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
         self.placement = None             # report of the last buffer placement probe (alloc_rollout_buffers)
+        self._arenas = []                 # placement.Arena objects behind placed buffers (kept alive with the env)
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -302,13 +303,15 @@ class MultiAgentEnv(object):
         self._rng_offset, self.current_step, w.world_step = host
         sc._cache = None
 
-    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.6):
+    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.7):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
-        the bytes - PLACED: when it is larger than the Infinity Cache, up to `candidates` allocations are made, this
-        env's own K-step launch is timed on each and the fastest is kept (formation_gym/placement.py; the rate of a
-        launch depends on the allocation it streams into by up to 15 %).  The env's state is restored afterwards.
-        `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report is left in
-        `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`."""
+        the bytes - PLACED: when it is larger than the Infinity Cache, this env's own K-step launch is timed on windows
+        of an arena of physical chunks and the fastest window is kept, the rest released (formation_gym/placement.py: the
+        rate of a launch depends on where in HBM its buffer lies, by up to 15 %); where the arena cannot be made, on up
+        to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state is restored
+        afterwards.  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report is left in
+        `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`; it (and the env) keeps the arena
+        behind the observation tensor alive (`out['arena']`)."""
         from . import placement
         K, obs_every = int(K), int(obs_every)
         B, N = self.num_envs, self.num_agents
@@ -324,8 +327,11 @@ class MultiAgentEnv(object):
         if policy:
             small["act"] = torch.empty((K, B, N, 2), **f)
 
+        def shaped(flat):
+            return flat.view(slots, B, pitch)[:, :, :N * D].view(slots, B, N, D)
+
         def alloc():
-            return torch.empty((slots, B, pitch), **f)[:, :, :N * D].view(slots, B, N, D)
+            return shaped(torch.empty(slots * B * pitch, **f))
 
         nbytes = slots * B * pitch * 4
         if slots == 0 or nbytes < placement.MIN_PROBE_BYTES or candidates < 2:
@@ -340,22 +346,32 @@ class MultiAgentEnv(object):
                 self.rollout_policy(K, 3, out=out, obs_every=obs_every)
             else:
                 self.rollout(acts, out=out, obs_every=obs_every)
+            self._roll_launchers.clear()               # one binding per candidate window: do not let them pile up
 
-        obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
+        arena = None
+        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, mem_fraction=mem_fraction)
+        if placed is not None:
+            flat, report, arena = placed
+            obs = shaped(flat)
+            self._arenas.append(arena)
+        else:
+            obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
         self._roll_launchers.clear()                   # bindings made on the candidates keep them alive: drop them,
         torch.cuda.empty_cache()                       # then hand the losers back to the driver
         self._restore(snap)
         report["buffer_MB"] = round(nbytes / 1e6, 1)
-        if report.get("probed"):
-            alg = _native.step_hd_bytes(N) * B * K if hasattr(_native, "step_hd_bytes") and D == 6 * N else None
-            if alg:
-                report["kept_GBps"] = round(alg / (report["kept_ms"] * 1e-3) / 1e9, 1)
-                report["worst_GBps"] = round(alg / (report["worst_ms"] * 1e-3) / 1e9, 1)
+        if report.get("probed") and D == 6 * N:
+            alg = _native.step_hd_bytes(N) * B * K
+            report["kept_GBps"] = round(alg / (report["kept_ms"] * 1e-3) / 1e9, 1)
+            report["worst_GBps"] = round(alg / (report["worst_ms"] * 1e-3) / 1e9, 1)
         self.placement = report
-        return dict(small, obs=obs)
+        out = dict(small, obs=obs)
+        if arena is not None:
+            out["arena"] = arena
+        return out
 
-    def place_step_buffers(self, candidates=8, mem_fraction=0.6):
-        """The same probe for the per-step output buffer `step` writes into (only batches whose single-step
+    def place_step_buffers(self, candidates=8, mem_fraction=0.7):
+        """The same placement for the per-step output buffer `step` writes into (only batches whose single-step
         observation tensor exceeds the Infinity Cache: 243 agents x >= 200 envs, 81 x >= 1700, 27 x >= 15 000)."""
         from . import placement
         B, N = self.num_envs, self.num_agents
@@ -385,7 +401,13 @@ class MultiAgentEnv(object):
         def time_fn(flat):
             self.scenario.step_batch(self.world, act, views(flat), auto_reset=self.auto_reset, rng_offset=1)
 
-        flat, report = placement.probe_allocation(alloc, time_fn, nflat * 4, dev, candidates=candidates, mem_fraction=mem_fraction)
+        placed = placement.probe_arena(nflat, time_fn, dev, mem_fraction=mem_fraction)
+        if placed is not None:
+            flat, report, arena = placed
+            flat.zero_()
+            self._arenas.append(arena)
+        else:
+            flat, report = placement.probe_allocation(alloc, time_fn, nflat * 4, dev, candidates=candidates, mem_fraction=mem_fraction)
         self._flat, self._out = flat, views(flat)
         self._launchers.clear()
         self._restore(snap)

@@ -310,6 +310,26 @@ class Scenario(BaseScenario):
             _native.current_stream(world.device)))
         self._cache = None
 
+    def bind_reset_mt_done(self, world, obs=None):
+        """`reset_mt_done` with every pointer resolved once: returns `launch()`, one ctypes call per vec-env step."""
+        if getattr(self, "_mt_state", None) is None or self._mt_state.shape[0] != world.num_envs:
+            self.upload_mt_streams(world)
+        fn = _native.load().fg_reset_hd_mt_done
+        args = (world.num_envs, len(world.agents), int(world.world_length), self._mt_state.data_ptr(),
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.landmark_pos.data_ptr(),
+                world.step_count.data_ptr(), _native.ptr(obs), self.obs_env_pitch(obs, len(world.agents)),
+                _native.current_stream(world.device))
+        keep = (self._mt_state, obs)
+
+        def launch():
+            rc = fn(*args)
+            if rc:
+                _native.check(rc)
+            self._cache = None
+            return keep
+        return launch
+
     def reset_device(self, world, mask=None, rng_offset=0):
         """Throughput-mode reset on the GPU (counter RNG, distributional parity only)."""
         lib = _native.load()

@@ -59,17 +59,18 @@ def ezpolicy(obs):
     return act.numpy() if as_numpy else act
 
 
-def get_action_BFS(policy, obs, num_agents_per_layer):
+def get_action_BFS(policy, obs, num_agents_per_layer, out=None):
     """Hierarchical expansion of `policy` over a `num_agents_per_layer`-ary tree.
 
     obs: list of N observation vectors (reference style, returns a list of N
     arrays of shape (2,)) or a tensor [B, N, 6N] (returns a tensor [B, N, 2]).
-    `policy` must be batched when a tensor is given (`ezpolicy` is)."""
+    `policy` must be batched when a tensor is given (`ezpolicy` is).
+    out (batched extension): a float32 tensor [B, N, 2] to receive the actions."""
     per = int(num_agents_per_layer)
     ref_style = not torch.is_tensor(obs)
     if (not ref_style and policy is ezpolicy and obs.is_cuda and obs.dtype == torch.float32 and obs.dim() == 3
             and 2 <= per <= 8 and obs.shape[1] >= 3):
-        return bfs_actions(obs, per)               # anything else (float64, wider hierarchies): the tensor path below
+        return bfs_actions(obs, per, out=out)      # anything else (float64, wider hierarchies): the tensor path below
     o = torch.as_tensor(np.asarray(obs, dtype=np.float64))[None] if ref_style else obs
     B, N, D = o.shape
     layers = math.log(N) / math.log(per)
@@ -103,6 +104,9 @@ def get_action_BFS(policy, obs, num_agents_per_layer):
         sub_vel = torch.as_tensor(sub_vel).reshape(B, groups, per, 1, 2)
         tgt_vel = sub_vel.expand(B, groups, per, n_sub, 2).reshape(B, N, 2)
     act = tgt_vel
+    if out is not None:
+        out.copy_(act)
+        act = out
     if ref_style:
         a = act[0].numpy()
         return [a[i] for i in range(N)]

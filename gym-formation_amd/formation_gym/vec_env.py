@@ -29,6 +29,7 @@ class FormationVecEnv(object):
         env.auto_reset = reset_mode == "device"
         self.ts = torch.zeros(self.num_envs, dtype=torch.int64)
         self._host_steps = None
+        self._mt_launch = None
 
     def get_spaces(self):
         return self.observation_space, self.action_space
@@ -58,7 +59,10 @@ class FormationVecEnv(object):
                 # own MT19937 streams and their reset observation replaces the step's; no mask upload, no second pass over
                 # the batch.  reward / done / info keep their pre-reset values.  The host mirror of the (deterministic)
                 # step counters only serves to skip the launch on steps in which nobody finishes.
-                self.env.scenario.reset_mt_done(self.env.world, self.env._out["obs"])
+                if self._mt_launch is None or self._mt_launch[0] != self.env._out["obs"].data_ptr():
+                    self._mt_launch = (self.env._out["obs"].data_ptr(),
+                                       self.env.scenario.bind_reset_mt_done(self.env.world, self.env._out["obs"]))
+                self._mt_launch[1]()
                 self._host_steps[finished] = 0
             return self.env._out["obs"], rew, done, info
         if self.reset_mode == "host":
@@ -93,7 +97,8 @@ class FormationVecEnv(object):
         T steps - `act = policy_fn(obs); obs, rew, done, info = venv.step(act)` T times - at the cost of one graph launch
         instead of T x (policy kernels + step launch) host round trips (2-4x on launch-bound batches).
           policy_fn(obs [B,N,D]) -> actions [B,N,2]: device-side work only (torch modules, formation_gym.get_action_BFS,
-              ...), no host synchronisation, the same shapes every call - what hipGraph capture asks of any code.
+              ...), no host synchronisation, the same shapes every call - what hipGraph capture asks of any code.  If it
+              has an `out` parameter it is called as policy_fn(obs, out=slot) and may write the actions there directly.
         Episodes restart inside the graph ('device' reset mode; the counter RNG's per-step offset lives in device memory,
         so every replay draws new reset states - those of the same steps taken launch by launch).  Capturing leaves the
         env's state untouched (the warm-up pass is rolled back).  Returns a `CapturedLoop`."""
@@ -127,6 +132,11 @@ class CapturedLoop(object):
         if getattr(env.scenario, "bind_step", None) is None or env._action_mode() or env.post_step_callback is not None:
             raise NotImplementedError("capture needs a batched scenario with continuous actions and no host callbacks")
         self.venv, self.env, self.steps, self.policy_fn = venv, env, steps, policy_fn
+        try:                                       # policy_fn(obs, out=slot): an optional `out` saves a copy per step
+            import inspect
+            self._takes_out = "out" in inspect.signature(policy_fn).parameters
+        except (TypeError, ValueError):
+            self._takes_out = False
         B, N = env.num_envs, env.num_agents
         D = env._out["obs"].shape[-1]
         dev = env._act.device
@@ -162,11 +172,16 @@ class CapturedLoop(object):
         env, T = self.env, self.steps
         obs = self.buf["obs"][T - 1]
         for t in range(T):
-            act = self.policy_fn(obs)
-            self.buf["act"][t].copy_(act)
-            self._launch[t](1)                                           # by-value offset 1 + the device counter
-            env.world.rng_counter.add_(1)
+            slot = self.buf["act"][t]
+            if self._takes_out:                                          # the policy writes its actions straight into the slot
+                act = self.policy_fn(obs, out=slot)
+                if act is not None and act.data_ptr() != slot.data_ptr():
+                    slot.copy_(act)
+            else:
+                slot.copy_(self.policy_fn(obs))
+            self._launch[t](1 + t)                                       # by-value offset of step t + the device counter,
             obs = self.buf["obs"][t]
+        env.world.rng_counter.add_(T)                                    # which advances once per replay
 
     def replay(self):
         env, T = self.env, self.steps

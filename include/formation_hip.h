@@ -163,6 +163,22 @@ typedef struct FgScenario {
     float penalty;
 } FgScenario;
 
+/* Placed device memory ------------------------------------------------------
+ * The rate at which the rollout kernels stream observations depends on WHERE in HBM the buffer lies: windows of one and
+ * the same large allocation run the same launch at 5.2 or 6.0 TB/s, in regions a few GB wide (profiles/r03_place/).  An
+ * arena is address space backed by separately created physical chunks (HIP virtual memory management), so that a caller
+ * can time its launch on windows of the arena, keep the chunks of the best window and hand all others back:
+ *   fg_arena_create   reserves ceil(bytes / chunk) * chunk bytes of address space on `device` (chunk_bytes is rounded up to
+ *                     the allocation granularity; 0 = 1 GiB), backs every chunk with device memory, read-write for that
+ *                     device; *base = start of the range, *arena = handle
+ *   fg_arena_keep     releases every chunk that does not intersect [offset, offset + bytes): their addresses become invalid,
+ *                     the kept chunks stay where they are (call only when no launch is using the arena)
+ *   fg_arena_destroy  releases everything and frees the address range
+ * These three are the only entry points that allocate; they enqueue nothing and take no stream. */
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out);
+int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes);
+int fg_arena_destroy(void* arena);
+
 /* library / diagnostics --------------------------------------------------- */
 int fg_abi_version(void);
 const char* fg_last_error(void);

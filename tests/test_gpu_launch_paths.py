@@ -492,7 +492,7 @@ def test_device_rng_counter_toggle_and_captured_rollouts():
         assert torch.equal(x, y)
 
 
-@pytest.mark.parametrize("N,B,policy", [(27, 300, "bfs"), (9, 640, "linear"), (81, 40, "bfs")])
+@pytest.mark.parametrize("N,B,policy", [(27, 300, "bfs"), (9, 640, "linear"), (81, 40, "bfs_out")])
 def test_vec_env_capture_replays_equal_the_step_loop(N, B, policy):
     """FormationVecEnv.capture(policy_fn, T): three replays of the captured T-step loop (device-side policy + vec-env
     step with auto-resets inside the graph) equal 3 T steps of the same loop taken launch by launch, bit for bit -
@@ -505,6 +505,8 @@ def test_vec_env_capture_replays_equal_the_step_loop(N, B, policy):
     W = (torch.rand((6 * N, 2), generator=gen, device=dev) - 0.5) * 0.2
     if policy == "bfs":
         fn = lambda obs: formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3)
+    elif policy == "bfs_out":                              # a policy that writes into the slot it is given
+        fn = lambda obs, out=None: formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3, out=out)
     else:
         fn = lambda obs: torch.tanh(obs @ W)
 
