@@ -396,7 +396,7 @@ def main():
             t1 = cal[1].elapsed_time(cal[4]) / 3.0
             if not solo[0]:
                 t1 = sharding.max_over_ranks(t1, red_dev, sync_group)   # same value on every rank
-            R = int(min(4000, max(1, -(-a.min_timed_ms // max(t1, 1e-3)))))
+            R = int(min(4000, max(1, -(-1.25 * a.min_timed_ms // max(t1, 1e-3)))))   # 25 % margin: the calibration blocks run cold-ish
             # the timed series: R consecutive blocks of exactly n steps, each delimited by HIP events on the launch
             # stream, the series bracketed by barrier + device synchronize.  The stream never idles between blocks
             # (the host queues ahead), which is how a rollout loop runs; a block that started on an idle GPU would

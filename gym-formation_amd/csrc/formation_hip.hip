@@ -663,6 +663,7 @@ int fg_reset_hd_mt_done(int B, int N, int world_length, uint32_t* mt_state,
                         float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                         float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step,
                         float* obs, int64_t obs_env_pitch, void* stream) {
+    if (B == 0) return FG_OK;
     if (world_length <= 0 || !step) return fail(FG_ERR_BAD_ARG, "fg_reset_hd_mt_done: world_length > 0 and step required%s");
     return launch_mt_reset(B, N, nullptr, mt_state, pos_x, pos_y, vel_x, vel_y, ideal_shape, ideal_vel, landmark_pos, step,
                            world_length, obs, (long long)obs_env_pitch, stream);

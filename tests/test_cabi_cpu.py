@@ -121,6 +121,28 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_decode_actions(_native.FG_ACT_INDEX, -3, p, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ARGMAX, 12, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
+    # ABI 6: per-agent table / communication state pointers are checked for alignment, the landmark-scenario entry
+    # points refuse them instead of ignoring them
+    assert lib.fg_step_hd(_params(agent_props=p + 2), 4, 9, *ok_ptrs) == _native.FG_ERR_ALIGNMENT
+    assert lib.fg_step_hd(_params(comm_state=p + 4), 4, 9, *ok_ptrs) == _native.FG_ERR_ALIGNMENT
+    assert lib.fg_step_hd(_params(dist_min=0.0), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_basic(_params(agent_props=p), 4, 3, 3, 1, *([p] * 13)) == _native.FG_ERR_BAD_ARG
+    assert b"formation_hd_env entry points only" in lib.fg_last_error()
+    assert lib.fg_update_comm(P, 0, 9, None, None, None) == _native.FG_OK
+    assert lib.fg_update_comm(P, 4, 9, None, p, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_update_comm(P, 4, 9, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
+    assert lib.fg_update_comm(P, 4, 5000, p, p, None) == _native.FG_ERR_UNSUPPORTED_N
+    # device-decided MT19937 reset: needs the step counters and an episode length
+    assert lib.fg_reset_hd_mt_done(0, 9, 100, *([None] * 10), 0, None) == _native.FG_OK
+    assert lib.fg_reset_hd_mt_done(4, 9, 0, *([p] * 10), 0, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_reset_hd_mt_done(4, 9, 100, *([p] * 9), p, 7, None) == _native.FG_ERR_BAD_ARG        # odd / short env pitch
+    assert lib.fg_reset_hd_mt_done(4, 9, 100, *([p] * 9), p + 4, 0, None) == _native.FG_ERR_ALIGNMENT
+    # arenas: argument checks (creating one needs a device)
+    h, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert lib.fg_arena_create(0, 0, 0, ctypes.byref(h), ctypes.byref(b), None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_create(0, 1 << 20, 0, None, ctypes.byref(b), None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_keep(None, 0, 16) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_destroy(None) == _native.FG_OK
     # fg_policy_bfs: N must be per_layer^L, 2 <= per_layer <= 8
     assert lib.fg_policy_bfs(0, 9, 3, None, 0, None, None) == _native.FG_OK
     assert lib.fg_policy_bfs(4, 10, 3, p, 0, p, None) == _native.FG_ERR_UNSUPPORTED_N
