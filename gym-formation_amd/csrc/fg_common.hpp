@@ -75,6 +75,7 @@ struct KParams {
     const uint64_t* rng_offset_dev;
     const double* agent_props;
     const double* comm_state;
+    int32_t obs_placed, reserved0;
 };
 #else
 typedef FgParams KParams;

@@ -274,6 +274,12 @@ static int launch_roll_v(const Args& a, hipStream_t st) {
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+#ifndef FG_R27_TW
+#define FG_R27_TW 256          // writer threads of the 27-agent rollout kernel
+#endif
+#ifndef FG_R27_WR
+#define FG_R27_WR 10           // its writer: 1 + rows per LDS tile, 0 = register-cached rows
+#endif
 template <bool POLICY = false>
 static int launch_roll(const Args& a, hipStream_t st) {
     // Defaults from the MI355X sweeps (profiles/README.md).  27 agents: 16 envs per workgroup = 8 producer + 4
@@ -283,9 +289,19 @@ static int launch_roll(const Args& a, hipStream_t st) {
     if (a.N == 27) {
         // HBM-streaming form of the tile writer (line ownership + paced stores, fg_obs_writers.hpp): batches of a few
         // workgroup generations whose rollout buffer does not fit the 256 MiB Infinity Cache; else the plain form
-        const bool stream = a.B < 16384 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
-        return stream ? launch_roll_v<27, 32, 512, 256, 16, 10, POLICY, true>(a, st)   // (8 paced writer waves: 13.2-14.4 vs 12.75 us/step)
-                      : launch_roll_v<27, 32, 512, 256, 16, 10, POLICY, false>(a, st);
+        const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+        bool stream = a.B < 16384 && hbm;
+#ifdef FG_R27_FORCE_STREAM
+        stream = FG_R27_FORCE_STREAM != 0;
+#endif
+        // A buffer composed of chunks spread over the device's memory (FgParams.obs_placed) takes the stream of 8 paced
+        // writer waves: 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384
+        // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
+        // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation keeps 4: its controller tables do not fit beside 16 tiles.
+        if (!POLICY && a.p.obs_placed && hbm)
+            return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
+        return stream ? launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, (FG_R27_WR > 0)>(a, st)
+                      : launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, false>(a, st);
     }
     if (a.N == 9) {
         if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10, POLICY>(a, st);
@@ -345,13 +361,16 @@ struct Arena {
     char* base = nullptr;
     std::vector<hipMemGenericAllocationHandle_t> handle;
     std::vector<char> live;
+    struct View { char* base; std::vector<uint32_t> chunks; };
+    std::vector<View> views;                            // extra mappings of some chunks (fg_arena_view)
     void drop(size_t i) {
         if (!live[i]) return;
-        (void)hipMemUnmap(base + i * chunk, chunk);
+        if (live[i] == 1) (void)hipMemUnmap(base + i * chunk, chunk);       // 2: the original mapping is gone already
         (void)hipMemRelease(handle[i]);
         live[i] = 0;
     }
 };
+typedef Arena::View ArenaView;
 }  // namespace
 
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out) {
@@ -405,15 +424,86 @@ int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes) {
     Arena* a = (Arena*)arena;
     if (!a) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: arena is NULL%s");
     if (offset + bytes > a->n * a->chunk) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: range beyond the arena%s");
+    for (auto& v : a->views) {                                  // views of chunks that may go away: unmapped first
+        for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
+        (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
+    }
+    a->views.clear();
     const size_t first = (size_t)(offset / a->chunk), last = bytes ? (size_t)((offset + bytes - 1) / a->chunk) : first;
     for (size_t i = 0; i < a->n; ++i)
         if (bytes == 0 || i < first || i > last) a->drop(i);
     return FG_OK;
 }
 
+// A second view of some of the arena's chunks, in the caller's order, at fresh contiguous addresses (the chunks stay
+// mapped where they were as well).  Views live until the arena is destroyed.
+int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void** base) {
+    Arena* a = (Arena*)arena;
+    if (!a || !chunk_index || !base || count == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_view: arena, indices and base required%s");
+    for (uint32_t j = 0; j < count; ++j)
+        if (chunk_index[j] >= a->n || a->live[chunk_index[j]] != 1) return fail(FG_ERR_BAD_ARG, "fg_arena_view: chunk index out of range or released%s");
+    void* va = nullptr;
+    hipError_t err = hipMemAddressReserve(&va, (size_t)count * a->chunk, 0, nullptr, 0);
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "hipMemAddressReserve failed: %s", hipGetErrorString(err));
+    uint32_t done = 0;
+    for (; done < count && err == hipSuccess; ++done)
+        err = hipMemMap((char*)va + (size_t)done * a->chunk, a->chunk, 0, a->handle[chunk_index[done]], 0);
+    if (err == hipSuccess) {
+        hipMemAccessDesc desc;
+        memset(&desc, 0, sizeof(desc));
+        desc.location.type = hipMemLocationTypeDevice;
+        desc.location.id = a->dev;
+        desc.flags = hipMemAccessFlagsProtReadWrite;
+        err = hipMemSetAccess(va, (size_t)count * a->chunk, &desc, 1);
+    }
+    if (err != hipSuccess) {
+        const int rc = fail(FG_ERR_HIP, "fg_arena_view: %s", hipGetErrorString(err));
+        (void)hipGetLastError();
+        for (uint32_t j = 0; j + 1 < done + 1 && j < count; ++j) (void)hipMemUnmap((char*)va + (size_t)j * a->chunk, a->chunk);
+        (void)hipMemAddressFree(va, (size_t)count * a->chunk);
+        return rc;
+    }
+    a->views.push_back(ArenaView{(char*)va, std::vector<uint32_t>(chunk_index, chunk_index + count)});
+    *base = va;
+    return FG_OK;
+}
+
+// Keep exactly the chunks of one view, mapped where that view has them; every other chunk goes back to the driver and the
+// arena's original address range and its other views become invalid.
+int fg_arena_keep_view(void* arena, void* view_base) {
+    Arena* a = (Arena*)arena;
+    if (!a || !view_base) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_view: arena and view required%s");
+    size_t which = a->views.size();
+    for (size_t v = 0; v < a->views.size(); ++v)
+        if (a->views[v].base == (char*)view_base) which = v;
+    if (which == a->views.size()) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_view: not a view of this arena%s");
+    std::vector<char> wanted(a->n, 0);
+    for (uint32_t c : a->views[which].chunks) wanted[c] = 1;
+    for (size_t v = 0; v < a->views.size(); ++v) {
+        if (v == which) continue;
+        ArenaView& o = a->views[v];
+        for (size_t j = 0; j < o.chunks.size(); ++j) (void)hipMemUnmap(o.base + j * a->chunk, a->chunk);
+        (void)hipMemAddressFree(o.base, o.chunks.size() * a->chunk);
+    }
+    ArenaView kept = a->views[which];
+    a->views.clear();
+    a->views.push_back(kept);
+    for (size_t i = 0; i < a->n; ++i) {
+        if (!a->live[i]) continue;
+        (void)hipMemUnmap(a->base + i * a->chunk, a->chunk);          // the original mapping goes in any case
+        if (!wanted[i]) (void)hipMemRelease(a->handle[i]);
+        a->live[i] = wanted[i] ? 2 : 0;                               // 2: alive through the kept view only
+    }
+    return FG_OK;
+}
+
 int fg_arena_destroy(void* arena) {
     Arena* a = (Arena*)arena;
     if (!a) return FG_OK;
+    for (auto& v : a->views) {
+        for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
+        (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
+    }
     for (size_t i = 0; i < a->n; ++i) a->drop(i);
     (void)hipMemAddressFree(a->base, a->n * a->chunk);
     delete a;

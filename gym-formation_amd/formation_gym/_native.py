@@ -56,6 +56,8 @@ class FgParams(ctypes.Structure):
         ("rng_offset_dev", ctypes.c_void_p),
         ("agent_props", ctypes.c_void_p),       # device float [N][AGENT_PROPS] or NULL (uniform agents)
         ("comm_state", ctypes.c_void_p),        # device float [B][N][2] or NULL (silent agents)
+        ("obs_placed", ctypes.c_int32),         # 1: the observation buffer was composed with fg_arena_* (placement.py)
+        ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -94,6 +96,8 @@ SIGNATURES = {
     "fg_abi_version": (_I, []),
     "fg_last_error": (ctypes.c_char_p, []),
     "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
+    "fg_arena_view": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
+    "fg_arena_keep_view": (_I, [_P, _P]),
     "fg_arena_keep": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64]),
     "fg_arena_destroy": (_I, [_P]),
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),

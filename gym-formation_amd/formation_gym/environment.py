@@ -305,10 +305,10 @@ class MultiAgentEnv(object):
 
     def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.7):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
-        the bytes - PLACED: when it is larger than the Infinity Cache, this env's own K-step launch is timed on windows
-        of an arena of physical chunks and the fastest window is kept, the rest released (formation_gym/placement.py: the
-        rate of a launch depends on where in HBM its buffer lies, by up to 15 %); where the arena cannot be made, on up
-        to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state is restored
+        the bytes - PLACED: when it is larger than the Infinity Cache, candidate buffers are composed of physical chunks
+        spread over the device's free memory, this env's own K-step launch is timed on `candidates` of them and the
+        fastest is kept, every other chunk released (formation_gym/placement.py: the rate of a launch depends on where
+        in HBM its buffer lies, by 15-25 %); where the arena cannot be made, on up to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state is restored
         afterwards.  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report is left in
         `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`; it (and the env) keeps the arena
         behind the observation tensor alive (`out['arena']`)."""
@@ -349,7 +349,7 @@ class MultiAgentEnv(object):
             self._roll_launchers.clear()               # one binding per candidate window: do not let them pile up
 
         arena = None
-        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, mem_fraction=mem_fraction)
+        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, trials=candidates, mem_fraction=mem_fraction)
         if placed is not None:
             flat, report, arena = placed
             obs = shaped(flat)
@@ -401,7 +401,7 @@ class MultiAgentEnv(object):
         def time_fn(flat):
             self.scenario.step_batch(self.world, act, views(flat), auto_reset=self.auto_reset, rng_offset=1)
 
-        placed = placement.probe_arena(nflat, time_fn, dev, mem_fraction=mem_fraction)
+        placed = placement.probe_arena(nflat, time_fn, dev, trials=candidates, mem_fraction=mem_fraction)
         if placed is not None:
             flat, report, arena = placed
             flat.zero_()

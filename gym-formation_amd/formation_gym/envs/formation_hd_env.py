@@ -10,7 +10,7 @@ the env shell's done (environment.py:172-178) runs inside the fused HIP kernel
 import numpy as np
 import torch
 
-from formation_gym import _native
+from formation_gym import _native, placement
 from formation_gym.core import World, Agent, Landmark
 from formation_gym.scenario import BaseScenario
 
@@ -111,6 +111,8 @@ class Scenario(BaseScenario):
         p.env_index_base = int(getattr(self, "env_base", 0))
         if world.any_non_silent():                        # :48-51 the communication block carries the others' state.c
             p.comm_state = world.ensure_comm()[0].data_ptr()
+        if obs is not None and obs.numel() and placement.is_placed(obs.data_ptr()):
+            p.obs_placed = 1                              # a buffer of chunks spread over the device memory: more writer waves pay
         return p
 
     @staticmethod

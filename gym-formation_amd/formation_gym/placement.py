@@ -1,16 +1,18 @@
 """Placement of large observation buffers in HBM.
 
 A K-step rollout streams its observations ([K, B, N, 6N] floats, 99 % of the bytes of the path) into one big buffer.  On
-MI355X the rate of one and the same launch depends on WHERE that buffer lies: windows of one large allocation run it at
-5.2 ... 6.1 TB/s, in a pattern a few GB wide that follows the physical memory behind the addresses (profiles/r03_place/:
-the same virtual addresses are fast in one process and slow in the next; single 1 GiB chunks all run alike, so it is the
-combination a multi-GB buffer lands on; byte offsets below ~50 MB change nothing; a physically contiguous allocation is
-the worst case, profiles/r02_place/).  Nothing inside a kernel reaches that, so the host places the buffer:
+MI355X the rate of one and the same launch depends on WHERE that buffer lies in physical memory (profiles/r03_place/):
+windows of one large allocation run it at 5.0 ... 6.0 TB/s; the same virtual addresses are fast in one process and slow
+in the next; single 1 GiB chunks all run alike, so it is the combination a multi-GB buffer lands on - and the rule behind
+it is SPREAD: a buffer whose chunks are scattered over 160 GB of the device's memory runs at 6.1-6.5 TB/s where
+neighbouring chunks give 5.0-5.4 (a 46 GB buffer with its own chunks merely shuffled: 6.8 instead of 6.1; a physically
+contiguous allocation is the worst case, 2.0-2.6 TB/s, profiles/r02_place/).  Nothing inside a kernel reaches that, so
+the host places the buffer:
 
   `probe_arena`       address space backed by separately created physical chunks (`fg_arena_*`: HIP virtual memory
-                      management); the caller's own launch is timed on windows of the arena at a stride of a quarter
-                      window, then around the best one at a finer stride; the best window's chunks are kept where they
-                      are, all others go back to the driver.  Nothing is wasted once the probe is over.
+                      management), as large as the free memory allows; candidate buffers are composed of chunks SPREAD
+                      over the whole arena (one per stratum, shuffled) and timed with the caller's own launch; the best
+                      candidate's chunks are kept, all others go back to the driver.  Nothing is wasted afterwards.
   `probe_allocation`  the fallback where the arena cannot be made: a few whole allocations held side by side, the
                       fastest kept (coarser: an allocation is one sample of the pattern).
 
@@ -73,6 +75,27 @@ def probe_allocation(alloc, time_fn, nbytes, device, candidates=8, mem_fraction=
                   "worst_over_kept": round(max(ms) / ms[best], 4)}
 
 
+_live_arenas = []          # weak references to the arenas of this process: `is_placed` answers from them
+
+
+def is_placed(address):
+    """Does this device address lie in a buffer composed by `probe_arena` (chunks spread over the device's memory)?
+    The scenario shells pass the answer to the library as `FgParams.obs_placed`."""
+    address = int(address)
+    alive = []
+    hit = False
+    for ref in _live_arenas:
+        arena = ref()
+        if arena is None or arena._handle is None:
+            continue
+        alive.append(ref)
+        lo, hi = arena.kept_range
+        if lo <= address < hi:
+            hit = True
+    _live_arenas[:] = alive
+    return hit
+
+
 class _Raw(object):
     """A device address range as something torch.as_tensor understands."""
 
@@ -81,8 +104,8 @@ class _Raw(object):
 
 
 class Arena(object):
-    """Address space backed by separately created physical chunks (C ABI `fg_arena_create / _keep / _destroy`).  The
-    tensors made by `floats()` are views of it: keep the Arena alive as long as they are in use."""
+    """Address space backed by separately created physical chunks (C ABI `fg_arena_*`).  The tensors made by `floats()`
+    are views of it: keep the Arena alive as long as they are in use."""
 
     def __init__(self, nbytes, device, chunk_bytes=0):
         self.device = torch.device(device)
@@ -92,9 +115,23 @@ class Arena(object):
                                                      ctypes.byref(base), ctypes.byref(chunk)))
         self._handle, self.base, self.chunk = handle, int(base.value), int(chunk.value)
         self.chunks = -(-int(nbytes) // self.chunk)
+        self.kept_range = (0, 0)          # address range of the spread buffer kept in the end (see is_placed)
+        import weakref
+        _live_arenas.append(weakref.ref(self))
 
-    def floats(self, byte_offset, nfloats):
-        return torch.as_tensor(_Raw(self.base + int(byte_offset), nfloats), device=self.device)
+    def floats(self, address, nfloats):
+        """A flat float32 tensor over `nfloats` floats at a device address inside the arena (or one of its views)."""
+        return torch.as_tensor(_Raw(int(address), nfloats), device=self.device)
+
+    def view(self, chunk_index):
+        """The given chunks (any order) mapped once more at fresh contiguous addresses; returns the base address."""
+        arr = (ctypes.c_uint32 * len(chunk_index))(*[int(c) for c in chunk_index])
+        base = ctypes.c_void_p()
+        _native.check(_native.load().fg_arena_view(self._handle, arr, len(chunk_index), ctypes.byref(base)))
+        return int(base.value)
+
+    def keep_view(self, view_base):
+        _native.check(_native.load().fg_arena_keep_view(self._handle, ctypes.c_void_p(int(view_base))))
 
     def keep(self, byte_offset, nbytes):
         _native.check(_native.load().fg_arena_keep(self._handle, int(byte_offset), int(nbytes)))
@@ -112,48 +149,64 @@ class Arena(object):
             pass
 
 
-def probe_arena(nfloats, time_fn, device, factor=8.0, mem_fraction=0.7, reps=3, min_bytes=MIN_PROBE_BYTES):
-    """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor is a view of the arena, which the caller
-    keeps alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back
-    to `probe_allocation`).  time_fn(flat_tensor) enqueues ONE launch that streams into the candidate window."""
+def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_bytes=192 << 30, reps=3,
+                min_bytes=MIN_PROBE_BYTES, seed=0):
+    """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor lives in the arena, which the caller keeps
+    alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back to
+    `probe_allocation`).  time_fn(flat_tensor) enqueues ONE launch that streams into the candidate buffer.
+
+    Candidates: the first window of the arena as it was created (what a plain allocation gives) and `trials` selections of
+    chunks SPREAD over the whole arena - one chunk per stratum, in shuffled order (profiles/r03_place/: the wider a
+    buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the slow case).
+    The best candidate's chunks are kept, every other chunk goes back to the driver."""
+    import random
     device = torch.device(device)
     nbytes = int(nfloats) * 4
     if device.type != "cuda" or nbytes < min_bytes:
         return None
     free = torch.cuda.mem_get_info(device)[0]
-    chunk = (1 << 30) if nbytes >= (4 << 30) else (256 << 20) if nbytes >= (1 << 30) else (64 << 20)
-    total = int(min(factor * nbytes, mem_fraction * free))
+    chunk = 32 << 20
+    while chunk < (1 << 30) and nbytes // chunk > 32:            # 16 ... 32 chunks per buffer, 32 MiB ... 1 GiB each
+        chunk <<= 1
+    total = int(min(max_arena_bytes, mem_fraction * free))
+    if total < 2 * nbytes:
+        total = int(min(0.9 * free, 1.5 * nbytes))                # a huge buffer: at least some room to shuffle in
     if total < nbytes + 2 * chunk:
         return None
     try:
         arena = Arena(total, device, chunk)
     except _native.FormationHipError:
         return None
-    chunk = arena.chunk
-    W = -(-nbytes // chunk)                                      # chunks per window
-    last = arena.chunks - W
+    chunk, n = arena.chunk, arena.chunks
+    W = -(-nbytes // chunk)                                      # chunks per buffer
     stream = torch.cuda.current_stream(device)
-    seen = {}
-
-    def rate(k):
-        if k not in seen:
-            seen[k] = _time_launch(time_fn, arena.floats(k * chunk, nfloats), stream, reps)
-        return seen[k]
-
-    coarse = max(1, W // 4)
-    for k in range(0, last + 1, coarse):
-        rate(k)
-    best = min(seen, key=seen.get)
-    fine = max(1, coarse // 4)
-    for k in range(max(0, best - coarse + fine), min(last, best + coarse - fine) + 1, fine):   # around the best window
-        rate(k)
-    best = min(seen, key=seen.get)
-    ms = [seen[k] for k in sorted(seen)]
+    rnd = random.Random(seed)
+    cands = [("as created", arena.base, None)]
+    for _ in range(int(trials)):
+        idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
+        while len(idx) < W:                                       # strata narrower than a chunk can collide
+            c = rnd.randrange(n)
+            if c not in idx:
+                idx.append(c)
+        rnd.shuffle(idx)
+        cands.append(("spread", arena.view(idx), idx))
+    ms = []
+    for _, addr, idx in cands:                                  # a spread candidate is timed as what it will be: "placed"
+        arena.kept_range = (addr, addr + W * chunk) if idx is not None else (0, 0)
+        ms.append(_time_launch(time_fn, arena.floats(addr, nfloats), stream, reps))
+    arena.kept_range = (0, 0)
+    best = min(range(len(ms)), key=lambda i: ms[i])
     stream.synchronize()
-    arena.keep(best * chunk, nbytes)
-    flat = arena.floats(best * chunk, nfloats)
-    report = {"method": "arena windows", "probed": True, "tried": len(seen), "arena_GB": round(arena.chunks * chunk / 1e9, 1),
-              "chunk_MiB": chunk >> 20, "window_chunks": W, "kept_window": best, "kept_ms": round(seen[best], 4),
-              "worst_ms": round(max(ms), 4), "median_ms": round(sorted(ms)[len(ms) // 2], 4),
-              "worst_over_kept": round(max(ms) / seen[best], 4)}
+    if cands[best][2] is None:
+        arena.keep(0, nbytes)
+    else:
+        arena.keep_view(cands[best][1])
+        arena.kept_range = (cands[best][1], cands[best][1] + W * chunk)
+    flat = arena.floats(cands[best][1], nfloats)
+    spread = sorted(ms[1:])
+    report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
+              "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
+              "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
+              "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
+              "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4)}
     return flat, report, arena

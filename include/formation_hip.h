@@ -135,6 +135,11 @@ typedef struct FgParams {
                                 into the communication block of the observation, row i = c_j for j != i in index order
                                 (formation_hd_env.py:48-51,59); NULL = zeros, the silent agents of every reference
                                 scenario (core.py:281-282).  Honoured by fg_step_hd, fg_observe_hd, fg_rollout_hd. */
+    int32_t obs_placed;        /* hint: 1 = the observation buffer of this launch was composed with fg_arena_* of chunks spread
+                                over the device's memory.  Such a buffer takes the store stream of MORE writer
+                                waves: the 27-agent rollout then runs 8 paced writer waves per workgroup (11.7 us/step at
+                                27 x 4096) where 4 are best on an ordinary allocation (12.9 there, 13.2-14.4 with 8).  0 = unknown */
+    int32_t reserved0;
 } FgParams;
 #define FG_AGENT_PROPS 6
 
@@ -164,18 +169,24 @@ typedef struct FgScenario {
 } FgScenario;
 
 /* Placed device memory ------------------------------------------------------
- * The rate at which the rollout kernels stream observations depends on WHERE in HBM the buffer lies: windows of one and
- * the same large allocation run the same launch at 5.2 or 6.0 TB/s, in regions a few GB wide (profiles/r03_place/).  An
- * arena is address space backed by separately created physical chunks (HIP virtual memory management), so that a caller
- * can time its launch on windows of the arena, keep the chunks of the best window and hand all others back:
- *   fg_arena_create   reserves ceil(bytes / chunk) * chunk bytes of address space on `device` (chunk_bytes is rounded up to
- *                     the allocation granularity; 0 = 1 GiB), backs every chunk with device memory, read-write for that
- *                     device; *base = start of the range, *arena = handle
- *   fg_arena_keep     releases every chunk that does not intersect [offset, offset + bytes): their addresses become invalid,
- *                     the kept chunks stay where they are (call only when no launch is using the arena)
- *   fg_arena_destroy  releases everything and frees the address range
- * These three are the only entry points that allocate; they enqueue nothing and take no stream. */
+ * The rate at which the rollout kernels stream observations depends on WHERE in HBM the buffer lies: a multi-GB buffer on
+ * physically neighbouring memory runs the same launch at 5.0-5.4 TB/s, one whose chunks are spread over the device's
+ * memory at 6.2-6.8 TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  An arena is address space
+ * backed by separately created physical chunks (HIP virtual memory management), from which a caller composes buffers:
+ *   fg_arena_create     reserves ceil(bytes / chunk) * chunk bytes of address space on `device` (chunk_bytes is rounded up
+ *                       to the allocation granularity; 0 = 1 GiB), backs every chunk with device memory, read-write for that
+ *                       device; *base = start of the range, *arena = handle, *chunk_out = the chunk size used
+ *   fg_arena_view       maps `count` of the chunks (indices into the original range, any order) once more at fresh contiguous
+ *                       addresses *base: a candidate buffer made of exactly those chunks
+ *   fg_arena_keep_view  keeps the chunks of one view, mapped where that view has them, and hands every other chunk back to
+ *                       the driver; the original range and all other views become invalid
+ *   fg_arena_keep       the same for a window [offset, offset + bytes) of the original range (all views become invalid)
+ *   fg_arena_destroy    releases everything and frees the address ranges
+ * Call keep / destroy only when no launch is using the arena.  These are the only entry points that allocate; they
+ * enqueue nothing and take no stream. */
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out);
+int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
+int fg_arena_keep_view(void* arena, void* view_base);
 int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes);
 int fg_arena_destroy(void* arena);
 

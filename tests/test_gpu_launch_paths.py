@@ -601,3 +601,44 @@ def test_split_step_with_index_outputs_world_options_and_padded_pitch(N, B_split
         for x, y in zip(big.world.get_state(), small.world.get_state()):
             assert torch.equal(x[:B_split], y)
         assert torch.equal(big.scenario.ideal_shape[:B_split], small.scenario.ideal_shape)
+
+
+@pytest.mark.parametrize("N,B,K", [(27, 4096, 8), (27, 4099, 7), (81, 1024, 4), (243, 512, 2)])
+def test_placed_rollout_buffers_equal_step_calls(N, B, K):
+    """env.alloc_rollout_buffers: the observation buffer composed of physical chunks spread over the device memory
+    (fg_arena_*, formation_gym/placement.py).  A rollout into it - at 27 agents the instantiation with 8 paced writer waves
+    that FgParams.obs_placed selects - equals K step calls bit for bit; the probe leaves the env's state untouched."""
+    from formation_gym import placement
+    rs = np.random.RandomState(N + K)
+    step0 = np.where(np.arange(B) % 3 == 0, 100 - 1 - (np.arange(B) // 3) % K, rs.randint(0, 100 - K, B))
+    a, b = _pair(N, B, seed=4, crowd=0.45, step0=step0)
+    before = [x.clone() for x in b.world.get_state()] + [b.world.step_count.clone(), b.scenario.ideal_shape.clone()]
+    out = b.alloc_rollout_buffers(K)
+    after = [x.clone() for x in b.world.get_state()] + [b.world.step_count.clone(), b.scenario.ideal_shape.clone()]
+    for x, y in zip(before, after):
+        assert torch.equal(x, y)
+    rep = b.placement
+    assert rep["probed"] and rep["tried"] >= 2 and rep["kept_ms"] <= rep["worst_ms"]
+    if rep["kept"] == "spread":
+        assert placement.is_placed(out["obs"].data_ptr()) and b.scenario.params(b.world, obs=out["obs"]).obs_placed == 1
+    assert not placement.is_placed(a._out["obs"].data_ptr())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(N)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    for rep_ in range(2):                                   # two launches into the same placed buffer
+        obs, rew, done, info = b.rollout(acts, out=out)
+        for k in range(K):
+            o, r, d, i = a.step(acts[k])
+            assert torch.equal(o, obs[k]), "observations differ at step %d" % k
+            assert torch.equal(r, rew[k]) and torch.equal(d, done[k])
+            assert torch.equal(i["individual_reward"], info["individual_reward"][k])
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    # the single-step buffer, placed
+    if N >= 81:
+        rep2 = b.place_step_buffers()
+        assert rep2["probed"]
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") * 2 - 1
+        o1, r1, d1, _ = a.step(act)
+        o2, r2, d2, _ = b.step(act)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    del out, obs
