@@ -636,7 +636,7 @@ def test_placed_rollout_buffers_equal_step_calls(N, B, K):
     # the single-step buffer, placed
     if N >= 81:
         rep2 = b.place_step_buffers()
-        assert rep2["probed"]
+        assert rep2["probed"] == (B * N * 6 * N * 4 >= placement.MIN_PROBE_BYTES)      # 81 x 1024: 161 MB, cache-resident
         act = torch.rand((B, N, 2), generator=gen, device="cuda") * 2 - 1
         o1, r1, d1, _ = a.step(act)
         o2, r2, d2, _ = b.step(act)
