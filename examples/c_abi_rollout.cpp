@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "formation_hip.h"
@@ -83,6 +84,54 @@ int main(int argc, char** argv) {
         printf("%-28s %d agents x %d envs: %8.3f us/step  %.3e env-steps/s  %6.0f GB/s algorithmic\n",
                rollout ? "fg_rollout_hd (20 per launch)" : "fg_step_hd (1 per launch)", N, B, ms * 1e3 / n,
                (double)B * n / (ms * 1e-3), bytes_step * n / (ms * 1e-3) / 1e9);
+    }
+
+    // The same rollout into a PLACED observation buffer: address space backed by separately created
+    // physical chunks, the buffer composed of chunks spread over the whole arena in shuffled order, everything else
+    // handed back.  (formation_gym/placement.py additionally times several such selections and keeps the best.)
+    {
+        size_t free_b = 0, total_b = 0;
+        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t need = (uint64_t)K * B * obs_env * sizeof(float);
+        uint64_t chunk = 32ull << 20;
+        while (chunk < (1ull << 30) && need / chunk > 16) chunk <<= 1;
+        uint64_t arena_bytes = (uint64_t)(0.6 * (double)free_b);
+        if (arena_bytes > (192ull << 30)) arena_bytes = 192ull << 30;
+        void *arena = nullptr, *base = nullptr, *placed = nullptr;
+        if (need >= (256ull << 20) && arena_bytes >= 2 * need &&
+            fg_arena_create(0, arena_bytes, chunk, &arena, &base, &chunk) == FG_OK) {
+            const uint32_t n = (uint32_t)((arena_bytes + chunk - 1) / chunk), W = (uint32_t)((need + chunk - 1) / chunk);
+            std::vector<uint32_t> idx(W);
+            for (uint32_t j = 0; j < W; ++j) idx[j] = (uint32_t)(((uint64_t)j * n + n / 2) / W);   // one chunk per stratum
+            for (uint32_t j = W - 1; j > 0; --j) { lcg = lcg * 1664525u + 1013904223u; std::swap(idx[j], idx[(lcg >> 8) % (j + 1)]); }
+            FG_CHECK(fg_arena_view(arena, idx.data(), W, &placed));
+            FG_CHECK(fg_arena_keep_view(arena, placed));
+            float* obs_placed = static_cast<float*>(placed);
+            FgParams Q = P;
+            Q.obs_placed = 1;
+            auto run_placed = [&](int n_steps) -> int {
+                for (int t = 0; t < n_steps; t += K) {
+                    Q.rng_offset = (uint64_t)t + 1;
+                    FG_CHECK(fg_rollout_hd(&Q, B, N, K, px, py, vx, vy, act, shape, ivel, step, obs_placed, rew, ind, done, 1, st));
+                }
+                return 0;
+            };
+            const int n_steps = (steps / K) * K;
+            if (int rc = run_placed(2 * K)) return rc;
+            HIP_OK(hipEventRecord(e0, st));
+            if (int rc = run_placed(n_steps)) return rc;
+            HIP_OK(hipEventRecord(e1, st));
+            HIP_OK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+            printf("%-28s %d agents x %d envs: %8.3f us/step  %.3e env-steps/s  %6.0f GB/s algorithmic  (%u chunks of %llu MiB out of %u)\n",
+                   "fg_rollout_hd, placed buffer", N, B, ms * 1e3 / n_steps, (double)B * n_steps / (ms * 1e-3),
+                   bytes_step * n_steps / (ms * 1e-3) / 1e9, W, (unsigned long long)(chunk >> 20), n);
+            HIP_OK(hipStreamSynchronize(st));
+            FG_CHECK(fg_arena_destroy(arena));
+        } else {
+            printf("placed-buffer run skipped (buffer below the Infinity Cache size, or no room for an arena)\n");
+        }
     }
 
     // sanity on the last observation of env 0: finite, relative positions antisymmetric, zero block zero

@@ -160,14 +160,16 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the slow case).
     The best candidate's chunks are kept, every other chunk goes back to the driver."""
     import random
+    import time
+    t_start = time.perf_counter()
     device = torch.device(device)
     nbytes = int(nfloats) * 4
     if device.type != "cuda" or nbytes < min_bytes:
         return None
     free = torch.cuda.mem_get_info(device)[0]
     chunk = 32 << 20
-    while chunk < (1 << 30) and nbytes // chunk > 32:            # 16 ... 32 chunks per buffer, 32 MiB ... 1 GiB each
-        chunk <<= 1
+    while chunk < (1 << 30) and nbytes // chunk > 16:            # 8 ... 16 chunks per buffer, 32 MiB ... 1 GiB each (the chunk
+        chunk <<= 1                                              # size itself does not matter: profiles/r03_place/spread_*)
     total = int(min(max_arena_bytes, mem_fraction * free))
     if total < 2 * nbytes:
         total = int(min(0.9 * free, 1.5 * nbytes))                # a huge buffer: at least some room to shuffle in
@@ -208,5 +210,6 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
               "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
               "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
-              "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4)}
+              "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
+              "probe_seconds": round(time.perf_counter() - t_start, 2)}
     return flat, report, arena
