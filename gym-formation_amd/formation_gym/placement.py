@@ -150,15 +150,19 @@ class Arena(object):
 
 
 def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_bytes=192 << 30, reps=3,
-                min_bytes=MIN_PROBE_BYTES, seed=0):
+                min_bytes=MIN_PROBE_BYTES, seed=0, budget_s=1.0):
     """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor lives in the arena, which the caller keeps
     alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back to
     `probe_allocation`).  time_fn(flat_tensor) enqueues ONE launch that streams into the candidate buffer.
 
-    Candidates: the first window of the arena as it was created (what a plain allocation gives) and `trials` selections of
-    chunks SPREAD over the whole arena - one chunk per stratum, in shuffled order (profiles/r03_place/: the wider a
-    buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the slow case).
-    The best candidate's chunks are kept, every other chunk goes back to the driver."""
+    Candidates: the first window of the arena as it was created (what a plain allocation gives) and selections of chunks
+    SPREAD over the whole arena - one chunk per stratum, strata in shuffled or golden-stride order (profiles/r03_place/:
+    the wider a buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the
+    slow case).  At least `trials` selections are timed, more while the launches timed so far took less than half of
+    `budget_s` (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ by 1 %); the
+    rest of the budget goes to a local search that swaps single chunks of the best selection for unused ones.  The best
+    candidate's chunks are kept, every other chunk goes back to the driver."""
+    import math
     import random
     import time
     t_start = time.perf_counter()
@@ -183,21 +187,62 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     W = -(-nbytes // chunk)                                      # chunks per buffer
     stream = torch.cuda.current_stream(device)
     rnd = random.Random(seed)
-    cands = [("as created", arena.base, None)]
-    for _ in range(int(trials)):
+    cands, ms = [], []                                           # (kind, address, chunk indices or None), median ms
+
+    def timed(addr, idx, r):                                     # a spread candidate is timed as what it will be: "placed"
+        arena.kept_range = (addr, addr + W * chunk) if idx is not None else (0, 0)
+        return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
+
+    def add(kind, idx):
+        addr = arena.base if idx is None else arena.view(idx)
+        cands.append((kind, addr, idx))
+        ms.append(timed(addr, idx, reps))
+        return ms[-1]
+
+    def spread_selection(t):
         idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
         while len(idx) < W:                                       # strata narrower than a chunk can collide
             c = rnd.randrange(n)
             if c not in idx:
                 idx.append(c)
-        rnd.shuffle(idx)
-        cands.append(("spread", arena.view(idx), idx))
-    ms = []
-    for _, addr, idx in cands:                                  # a spread candidate is timed as what it will be: "placed"
-        arena.kept_range = (addr, addr + W * chunk) if idx is not None else (0, 0)
-        ms.append(_time_launch(time_fn, arena.floats(addr, nfloats), stream, reps))
-    arena.kept_range = (0, 0)
+        idx.sort()
+        if t % 2 == 0:
+            rnd.shuffle(idx)                                      # strata in random order
+            return "spread, shuffled", idx
+        # strata in a golden-ratio stride order: consecutive chunks of the buffer (the slabs of consecutive steps) always
+        # come from far-apart parts of the arena, and so do chunks two and three apart
+        g = max(1, int(round(W * 0.6180339887)))
+        while math.gcd(g, W) != 1:
+            g += 1
+        off = rnd.randrange(W)
+        return "spread, golden stride", [idx[(off + k * g) % W] for k in range(W)]
+
+    t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
+    while time.perf_counter() - t_warm < 0.05:                   # probe measured 5-8 % slow
+        timed(arena.base, None, 2)
+    add("as created", None)
+    t_search = time.perf_counter()
+    t = 0
+    while t < int(trials) or (t < 4 * int(trials) and time.perf_counter() - t_search < 0.5 * budget_s):
+        add(*spread_selection(t))
+        t += 1
     best = min(range(len(ms)), key=lambda i: ms[i])
+    swaps = 0
+    while cands[best][2] is not None and n > W and time.perf_counter() - t_search < budget_s and swaps < 64:
+        idx = list(cands[best][2])                               # local search: one chunk of the best selection swapped
+        c = rnd.randrange(n)
+        if c in idx:
+            continue
+        idx[rnd.randrange(W)] = c
+        swaps += 1
+        if add("spread, local search", idx) < 0.995 * ms[best]:
+            best = len(ms) - 1
+    finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
+    final = {i: timed(cands[i][1], cands[i][2], 2 * reps + 1) for i in finalists}
+    for i, v in final.items():
+        ms[i] = v
+    arena.kept_range = (0, 0)
+    best = min(final, key=final.get)
     stream.synchronize()
     if cands[best][2] is None:
         arena.keep(0, nbytes)
@@ -205,11 +250,12 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
         arena.keep_view(cands[best][1])
         arena.kept_range = (cands[best][1], cands[best][1] + W * chunk)
     flat = arena.floats(cands[best][1], nfloats)
-    spread = sorted(ms[1:])
+    spread = sorted(m for c, m in zip(cands, ms) if c[2] is not None)
     report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
               "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
               "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
+              "local_search_swaps": swaps,
               "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
               "probe_seconds": round(time.perf_counter() - t_start, 2)}
     return flat, report, arena
