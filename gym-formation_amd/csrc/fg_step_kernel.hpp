@@ -7,6 +7,10 @@
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
 
+#ifndef FG_STEP_WIDE_PACE
+#define FG_STEP_WIDE_PACE 1     // s_sleep after every row of the rows writer in single-step launches above 64 agents
+#endif
+
 namespace fg {
 
 // ---------------------------------------------------------------------------
@@ -234,10 +238,10 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             // ---- phase 5: observations --------------------------------------
             if (want_obs && !FLAT) {
                 if constexpr (NC > 0)
-                    write_obs_rows<NC, T / 64, E, (NC > 64 ? 1 : 0)>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
+                    write_obs_rows<NC, T / 64, E, (NC > 64 ? FG_STEP_WIDE_PACE : 0)>(env_tables(smem, 0, N), env_block_floats(NC) / 2, tid >> 6,
                                                   reinterpret_cast<real2*>(a.obs) +
                                                   ((size_t)slot * pre_B + b0) * (size_t)a.obs_pitch, (size_t)a.obs_pitch, El, 3,
-                                                  part, split > 1 ? split : 1);
+                                                  part, split > 1 ? split : 1, !a.p.obs_placed);
             } else if (want_obs) {
                 const unsigned n3 = 3u * N;                // (x,y) units per row
                 const unsigned nenv = n3 * N;              // units per env = N rows

@@ -274,6 +274,9 @@ static int launch_roll_v(const Args& a, hipStream_t st) {
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+#ifndef FG_R27_POLICY_ROWS512
+#define FG_R27_POLICY_ROWS512 1    // closed loop into a placed buffer: 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
+#endif
 #ifndef FG_R27_TW
 #define FG_R27_TW 256          // writer threads of the 27-agent rollout kernel
 #endif
@@ -300,6 +303,10 @@ static int launch_roll(const Args& a, hipStream_t st) {
         // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation keeps 4: its controller tables do not fit beside 16 tiles.
         if (!POLICY && a.p.obs_placed && hbm)
             return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
+#if FG_R27_POLICY_ROWS512
+        if (POLICY && a.p.obs_placed && hbm)                       // closed loop: 8 writer waves with the rows writer (no tiles in LDS)
+            return launch_roll_v<27, 32, 512, 512, 16, 0, POLICY, false>(a, st);
+#endif
         return stream ? launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, (FG_R27_WR > 0)>(a, st)
                       : launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, false>(a, st);
     }

@@ -642,3 +642,26 @@ def test_placed_rollout_buffers_equal_step_calls(N, B, K):
         o2, r2, d2, _ = b.step(act)
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
     del out, obs
+
+
+def test_placed_closed_loop_rollout_equals_policy_and_step_calls():
+    """env.rollout_policy into placed buffers (27 agents: the closed-loop instantiation with 8 writer waves and the rows
+    writer that FgParams.obs_placed selects) == K x (get_action_BFS on the last observation, step), bit for bit."""
+    import formation_gym
+    N, B, K = 27, 4096, 8
+    step0 = (np.arange(B) * 5) % 100
+    a, b = _pair(N, B, seed=9, crowd=0.6, step0=step0)
+    out = b.alloc_rollout_buffers(K, policy=True)
+    assert b.placement["probed"]
+    for e in (a, b):
+        e.scenario.observe_batch(e.world, {"obs": e._out["obs"], "reward": e._out["reward"]})
+    obs, rew, done, info = b.rollout_policy(K, 3, out=out)
+    o = a._out["obs"]
+    for k in range(K):
+        act = formation_gym.get_action_BFS(formation_gym.ezpolicy, o, 3)
+        assert torch.equal(act, info["actions"][k]), k
+        o, r, d, i = a.step(act)
+        assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k])
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    assert bool(done.any())
