@@ -380,6 +380,17 @@ struct Arena {
 typedef Arena::View ArenaView;
 }  // namespace
 
+// Before any chunk is unmapped or released the whole device is drained: work on ANY stream may still be using the
+// addresses that are about to go away (a fault on an unmapped address takes the process down).
+static void drain_device(int dev) {
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) (void)hipSetDevice(dev);
+    (void)hipDeviceSynchronize();
+    if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+}
+
+
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out) {
     if (!arena || !base || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena, base and bytes > 0 required%s");
     hipMemAllocationProp prop;
@@ -431,6 +442,7 @@ int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes) {
     Arena* a = (Arena*)arena;
     if (!a) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: arena is NULL%s");
     if (offset + bytes > a->n * a->chunk) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: range beyond the arena%s");
+    drain_device(a->dev);
     for (auto& v : a->views) {                                  // views of chunks that may go away: unmapped first
         for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
         (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
@@ -480,6 +492,7 @@ int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void
 int fg_arena_keep_view(void* arena, void* view_base) {
     Arena* a = (Arena*)arena;
     if (!a || !view_base) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_view: arena and view required%s");
+    drain_device(a->dev);
     size_t which = a->views.size();
     for (size_t v = 0; v < a->views.size(); ++v)
         if (a->views[v].base == (char*)view_base) which = v;
@@ -507,6 +520,7 @@ int fg_arena_keep_view(void* arena, void* view_base) {
 int fg_arena_destroy(void* arena) {
     Arena* a = (Arena*)arena;
     if (!a) return FG_OK;
+    drain_device(a->dev);
     for (auto& v : a->views) {
         for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
         (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
@@ -890,7 +904,7 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
 }
 
 int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream) {
-    const DeviceGuard device_guard(stream, obs);
+    const DeviceGuard device_guard(stream, act);    // the actions (obs may live in an fg_arena, whose pointers carry no device attribute on every runtime)
     if (B == 0) return FG_OK;
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");

@@ -177,6 +177,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     total = int(min(max_arena_bytes, mem_fraction * free))
     if total < 2 * nbytes:
         total = int(min(0.9 * free, 1.5 * nbytes))                # a huge buffer: at least some room to shuffle in
+    while chunk < (1 << 30) and total // chunk > 2048:           # at most ~2000 chunks per arena (driver calls, page tables)
+        chunk <<= 1
     if total < nbytes + 2 * chunk:
         return None
     try:
