@@ -158,10 +158,10 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     Candidates: the first window of the arena as it was created (what a plain allocation gives) and selections of chunks
     SPREAD over the whole arena - one chunk per stratum, strata in shuffled or golden-stride order (profiles/r03_place/:
     the wider a buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the
-    slow case).  At least `trials` selections are timed, more while the launches timed so far took less than half of
-    `budget_s` (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ by 1 %); the
-    rest of the budget goes to a local search that swaps single chunks of the best selection for unused ones.  The best
-    candidate's chunks are kept, every other chunk goes back to the driver."""
+    slow case).  At least `trials` selections are timed, up to four times as many when `budget_s` affords them (a 0.25 ms
+    launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ by 1 %); all candidate mappings are
+    made before the first launch.  The three fastest are timed once more; the best candidate's chunks are kept, every
+    other chunk goes back to the driver."""
     import math
     import random
     import time
@@ -222,23 +222,17 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
     while time.perf_counter() - t_warm < 0.05:                   # probe measured 5-8 % slow
         timed(arena.base, None, 2)
-    add("as created", None)
-    t_search = time.perf_counter()
-    t = 0
-    while t < int(trials) or (t < 4 * int(trials) and time.perf_counter() - t_search < 0.5 * budget_s):
-        add(*spread_selection(t))
-        t += 1
-    best = min(range(len(ms)), key=lambda i: ms[i])
-    swaps = 0
-    while cands[best][2] is not None and n > W and time.perf_counter() - t_search < budget_s and swaps < 64:
-        idx = list(cands[best][2])                               # local search: one chunk of the best selection swapped
-        c = rnd.randrange(n)
-        if c in idx:
-            continue
-        idx[rnd.randrange(W)] = c
-        swaps += 1
-        if add("spread, local search", idx) < 0.995 * ms[best]:
-            best = len(ms) - 1
+    t_one = add("as created", None) * 1e-3                       # seconds per launch
+    # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
+    # and its selections differ by 1 %).  ALL candidate mappings are made before the first of them is timed: no page-table
+    # work between launches.
+    count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps + 1) * t_one + 2e-3))))
+    planned = [spread_selection(t) for t in range(count)]
+    views = [(kind, arena.view(idx), idx) for kind, idx in planned]
+    torch.cuda.synchronize(device)
+    for kind, addr, idx in views:
+        cands.append((kind, addr, idx))
+        ms.append(timed(addr, idx, reps))
     finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
     final = {i: timed(cands[i][1], cands[i][2], 2 * reps + 1) for i in finalists}
     for i, v in final.items():
@@ -257,7 +251,6 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
               "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
               "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
-              "local_search_swaps": swaps,
               "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
               "probe_seconds": round(time.perf_counter() - t_start, 2)}
     return flat, report, arena
