@@ -87,8 +87,8 @@ int main(int argc, char** argv) {
     }
 
     // The same rollout into a PLACED observation buffer: address space backed by separately created
-    // physical chunks, the buffer composed of chunks spread over the whole arena in shuffled order, everything else
-    // handed back.  (formation_gym/placement.py additionally times several such selections and keeps the best.)
+    // physical chunks, the buffer composed of chunks spread over the whole arena in shuffled order (fg_arena_map),
+    // everything else handed back (fg_arena_trim).  (formation_gym/placement.py additionally times several such selections and keeps the best.)
     {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
@@ -97,15 +97,16 @@ int main(int argc, char** argv) {
         while (chunk < (1ull << 30) && need / chunk > 16) chunk <<= 1;
         uint64_t arena_bytes = (uint64_t)(0.6 * (double)free_b);
         if (arena_bytes > (192ull << 30)) arena_bytes = 192ull << 30;
-        void *arena = nullptr, *base = nullptr, *placed = nullptr;
+        void *arena = nullptr, *placed = nullptr;
+        uint32_t n = 0;
         if (need >= (256ull << 20) && arena_bytes >= 2 * need &&
-            fg_arena_create(0, arena_bytes, chunk, &arena, &base, &chunk) == FG_OK) {
-            const uint32_t n = (uint32_t)((arena_bytes + chunk - 1) / chunk), W = (uint32_t)((need + chunk - 1) / chunk);
+            fg_arena_create(0, arena_bytes, chunk, &arena, &chunk, &n) == FG_OK) {
+            const uint32_t W = (uint32_t)((need + chunk - 1) / chunk);
             std::vector<uint32_t> idx(W);
             for (uint32_t j = 0; j < W; ++j) idx[j] = (uint32_t)(((uint64_t)j * n + n / 2) / W);   // one chunk per stratum
             for (uint32_t j = W - 1; j > 0; --j) { lcg = lcg * 1664525u + 1013904223u; std::swap(idx[j], idx[(lcg >> 8) % (j + 1)]); }
-            FG_CHECK(fg_arena_view(arena, idx.data(), W, &placed));
-            FG_CHECK(fg_arena_keep_view(arena, placed));
+            FG_CHECK(fg_arena_map(arena, idx.data(), W, &placed));
+            FG_CHECK(fg_arena_trim(arena));                               // every other chunk back to the driver
             float* obs_placed = static_cast<float*>(placed);
             FgParams Q = P;
             Q.obs_placed = 1;

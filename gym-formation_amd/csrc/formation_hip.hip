@@ -360,28 +360,23 @@ extern "C" {
 
 int fg_abi_version(void) { return FG_ABI_VERSION; }
 
-// ---- placed device memory: address space backed by separately created chunks (HIP virtual memory management) ----
+// ---- placed device memory: separately created physical chunks, mapped into fresh address ranges (HIP virtual memory
+// management).  Discipline: a chunk is mapped at ONE address at a time (no aliases), and the device is drained before any
+// mapping goes away.
 namespace {
 struct Arena {
     int dev = 0;
     size_t chunk = 0, n = 0;
-    char* base = nullptr;
     std::vector<hipMemGenericAllocationHandle_t> handle;
-    std::vector<char> live;
-    struct View { char* base; std::vector<uint32_t> chunks; };
-    std::vector<View> views;                            // extra mappings of some chunks (fg_arena_view)
-    void drop(size_t i) {
-        if (!live[i]) return;
-        if (live[i] == 1) (void)hipMemUnmap(base + i * chunk, chunk);       // 2: the original mapping is gone already
-        (void)hipMemRelease(handle[i]);
-        live[i] = 0;
-    }
+    std::vector<char> live;                             // handle exists
+    std::vector<int> mapped_in;                         // index of the mapping that holds the chunk, -1 = unmapped
+    struct Mapping { char* base; std::vector<uint32_t> chunks; };
+    std::vector<Mapping> maps;                          // slots; base == nullptr: free slot
 };
-typedef Arena::View ArenaView;
 }  // namespace
 
 // Before any chunk is unmapped or released the whole device is drained: work on ANY stream may still be using the
-// addresses that are about to go away (a fault on an unmapped address takes the process down).
+// addresses that are about to go away.
 static void drain_device(int dev) {
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
@@ -390,9 +385,19 @@ static void drain_device(int dev) {
     if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
 }
 
+static void arena_unmap_slot(Arena* a, size_t slot) {
+    Arena::Mapping& m = a->maps[slot];
+    if (!m.base) return;
+    for (size_t j = 0; j < m.chunks.size(); ++j) {
+        (void)hipMemUnmap(m.base + j * a->chunk, a->chunk);
+        a->mapped_in[m.chunks[j]] = -1;
+    }
+    (void)hipMemAddressFree(m.base, m.chunks.size() * a->chunk);
+    m.base = nullptr; m.chunks.clear();
+}
 
-int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out) {
-    if (!arena || !base || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena, base and bytes > 0 required%s");
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out) {
+    if (!arena || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena and bytes > 0 required%s");
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned;
@@ -405,68 +410,43 @@ int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** are
     chunk = (chunk + gran - 1) / gran * gran;
     Arena* a = new Arena();
     a->dev = device; a->chunk = chunk; a->n = ((size_t)bytes + chunk - 1) / chunk;
-    void* va = nullptr;
-    err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
-    if (err != hipSuccess) { delete a; return fail(FG_ERR_HIP, "hipMemAddressReserve failed: %s", hipGetErrorString(err)); }
-    a->base = (char*)va;
-    a->handle.resize(a->n); a->live.assign(a->n, 0);
-    for (size_t i = 0; i < a->n && err == hipSuccess; ++i) {
+    a->handle.resize(a->n); a->live.assign(a->n, 0); a->mapped_in.assign(a->n, -1);
+    for (size_t i = 0; i < a->n; ++i) {
         err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
         if (err != hipSuccess) break;
-        err = hipMemMap(a->base + i * chunk, chunk, 0, a->handle[i], 0);
-        if (err != hipSuccess) { (void)hipMemRelease(a->handle[i]); break; }
         a->live[i] = 1;
-    }
-    if (err == hipSuccess) {
-        hipMemAccessDesc desc;
-        memset(&desc, 0, sizeof(desc));
-        desc.location.type = hipMemLocationTypeDevice;
-        desc.location.id = device;
-        desc.flags = hipMemAccessFlagsProtReadWrite;
-        err = hipMemSetAccess(a->base, a->n * chunk, &desc, 1);
     }
     if (err != hipSuccess) {
         const int rc = fail(FG_ERR_HIP, "fg_arena_create: %s", hipGetErrorString(err));
         (void)hipGetLastError();
-        for (size_t i = 0; i < a->n; ++i) a->drop(i);
-        (void)hipMemAddressFree(a->base, a->n * chunk);
+        for (size_t i = 0; i < a->n; ++i) if (a->live[i]) (void)hipMemRelease(a->handle[i]);
         delete a;
         return rc;
     }
-    *arena = a; *base = a->base;
+    *arena = a;
     if (chunk_out) *chunk_out = chunk;
+    if (chunks_out) *chunks_out = (uint32_t)a->n;
     return FG_OK;
 }
 
-int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes) {
+int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base) {
     Arena* a = (Arena*)arena;
-    if (!a) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: arena is NULL%s");
-    if (offset + bytes > a->n * a->chunk) return fail(FG_ERR_BAD_ARG, "fg_arena_keep: range beyond the arena%s");
-    drain_device(a->dev);
-    for (auto& v : a->views) {                                  // views of chunks that may go away: unmapped first
-        for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
-        (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
+    if (!a || !chunk_index || !base || count == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_map: arena, indices and base required%s");
+    std::vector<char> seen(a->n, 0);
+    for (uint32_t j = 0; j < count; ++j) {
+        const uint32_t c = chunk_index[j];
+        if (c >= a->n || !a->live[c]) return fail(FG_ERR_BAD_ARG, "fg_arena_map: chunk index out of range or released%s");
+        if (a->mapped_in[c] >= 0 || seen[c]) return fail(FG_ERR_BAD_ARG, "fg_arena_map: a chunk is mapped at one address at a time%s");
+        seen[c] = 1;
     }
-    a->views.clear();
-    const size_t first = (size_t)(offset / a->chunk), last = bytes ? (size_t)((offset + bytes - 1) / a->chunk) : first;
-    for (size_t i = 0; i < a->n; ++i)
-        if (bytes == 0 || i < first || i > last) a->drop(i);
-    return FG_OK;
-}
-
-// A second view of some of the arena's chunks, in the caller's order, at fresh contiguous addresses (the chunks stay
-// mapped where they were as well).  Views live until the arena is destroyed.
-int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void** base) {
-    Arena* a = (Arena*)arena;
-    if (!a || !chunk_index || !base || count == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_view: arena, indices and base required%s");
-    for (uint32_t j = 0; j < count; ++j)
-        if (chunk_index[j] >= a->n || a->live[chunk_index[j]] != 1) return fail(FG_ERR_BAD_ARG, "fg_arena_view: chunk index out of range or released%s");
     void* va = nullptr;
     hipError_t err = hipMemAddressReserve(&va, (size_t)count * a->chunk, 0, nullptr, 0);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "hipMemAddressReserve failed: %s", hipGetErrorString(err));
     uint32_t done = 0;
-    for (; done < count && err == hipSuccess; ++done)
+    for (; done < count; ++done) {
         err = hipMemMap((char*)va + (size_t)done * a->chunk, a->chunk, 0, a->handle[chunk_index[done]], 0);
+        if (err != hipSuccess) break;
+    }
     if (err == hipSuccess) {
         hipMemAccessDesc desc;
         memset(&desc, 0, sizeof(desc));
@@ -476,44 +456,40 @@ int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void
         err = hipMemSetAccess(va, (size_t)count * a->chunk, &desc, 1);
     }
     if (err != hipSuccess) {
-        const int rc = fail(FG_ERR_HIP, "fg_arena_view: %s", hipGetErrorString(err));
+        const int rc = fail(FG_ERR_HIP, "fg_arena_map: %s", hipGetErrorString(err));
         (void)hipGetLastError();
-        for (uint32_t j = 0; j + 1 < done + 1 && j < count; ++j) (void)hipMemUnmap((char*)va + (size_t)j * a->chunk, a->chunk);
+        for (uint32_t j = 0; j < done; ++j) (void)hipMemUnmap((char*)va + (size_t)j * a->chunk, a->chunk);
         (void)hipMemAddressFree(va, (size_t)count * a->chunk);
         return rc;
     }
-    a->views.push_back(ArenaView{(char*)va, std::vector<uint32_t>(chunk_index, chunk_index + count)});
+    size_t slot = a->maps.size();
+    for (size_t k = 0; k < a->maps.size(); ++k) if (!a->maps[k].base) { slot = k; break; }
+    if (slot == a->maps.size()) a->maps.push_back(Arena::Mapping{nullptr, {}});
+    a->maps[slot].base = (char*)va;
+    a->maps[slot].chunks.assign(chunk_index, chunk_index + count);
+    for (uint32_t j = 0; j < count; ++j) a->mapped_in[chunk_index[j]] = (int)slot;
+    drain_device(a->dev);                               // the page-table work is complete before the caller launches into it
     *base = va;
     return FG_OK;
 }
 
-// Keep exactly the chunks of one view, mapped where that view has them; every other chunk goes back to the driver and the
-// arena's original address range and its other views become invalid.
-int fg_arena_keep_view(void* arena, void* view_base) {
+int fg_arena_unmap(void* arena, void* base) {
     Arena* a = (Arena*)arena;
-    if (!a || !view_base) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_view: arena and view required%s");
-    drain_device(a->dev);
-    size_t which = a->views.size();
-    for (size_t v = 0; v < a->views.size(); ++v)
-        if (a->views[v].base == (char*)view_base) which = v;
-    if (which == a->views.size()) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_view: not a view of this arena%s");
-    std::vector<char> wanted(a->n, 0);
-    for (uint32_t c : a->views[which].chunks) wanted[c] = 1;
-    for (size_t v = 0; v < a->views.size(); ++v) {
-        if (v == which) continue;
-        ArenaView& o = a->views[v];
-        for (size_t j = 0; j < o.chunks.size(); ++j) (void)hipMemUnmap(o.base + j * a->chunk, a->chunk);
-        (void)hipMemAddressFree(o.base, o.chunks.size() * a->chunk);
-    }
-    ArenaView kept = a->views[which];
-    a->views.clear();
-    a->views.push_back(kept);
-    for (size_t i = 0; i < a->n; ++i) {
-        if (!a->live[i]) continue;
-        (void)hipMemUnmap(a->base + i * a->chunk, a->chunk);          // the original mapping goes in any case
-        if (!wanted[i]) (void)hipMemRelease(a->handle[i]);
-        a->live[i] = wanted[i] ? 2 : 0;                               // 2: alive through the kept view only
-    }
+    if (!a || !base) return fail(FG_ERR_BAD_ARG, "fg_arena_unmap: arena and base required%s");
+    for (size_t k = 0; k < a->maps.size(); ++k)
+        if (a->maps[k].base == (char*)base) {
+            drain_device(a->dev);
+            arena_unmap_slot(a, k);
+            return FG_OK;
+        }
+    return fail(FG_ERR_BAD_ARG, "fg_arena_unmap: not a mapping of this arena%s");
+}
+
+int fg_arena_trim(void* arena) {
+    Arena* a = (Arena*)arena;
+    if (!a) return fail(FG_ERR_BAD_ARG, "fg_arena_trim: arena is NULL%s");
+    for (size_t i = 0; i < a->n; ++i)
+        if (a->live[i] && a->mapped_in[i] < 0) { (void)hipMemRelease(a->handle[i]); a->live[i] = 0; }
     return FG_OK;
 }
 
@@ -521,12 +497,8 @@ int fg_arena_destroy(void* arena) {
     Arena* a = (Arena*)arena;
     if (!a) return FG_OK;
     drain_device(a->dev);
-    for (auto& v : a->views) {
-        for (size_t j = 0; j < v.chunks.size(); ++j) (void)hipMemUnmap(v.base + j * a->chunk, a->chunk);
-        (void)hipMemAddressFree(v.base, v.chunks.size() * a->chunk);
-    }
-    for (size_t i = 0; i < a->n; ++i) a->drop(i);
-    (void)hipMemAddressFree(a->base, a->n * a->chunk);
+    for (size_t k = 0; k < a->maps.size(); ++k) arena_unmap_slot(a, k);
+    for (size_t i = 0; i < a->n; ++i) if (a->live[i]) (void)hipMemRelease(a->handle[i]);
     delete a;
     return FG_OK;
 }

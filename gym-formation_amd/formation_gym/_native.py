@@ -95,10 +95,11 @@ _PP = ctypes.POINTER(FgParams)
 SIGNATURES = {
     "fg_abi_version": (_I, []),
     "fg_last_error": (ctypes.c_char_p, []),
-    "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64)]),
-    "fg_arena_view": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
-    "fg_arena_keep_view": (_I, [_P, _P]),
-    "fg_arena_keep": (_I, [_P, ctypes.c_uint64, ctypes.c_uint64]),
+    "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64),
+                             ctypes.POINTER(ctypes.c_uint32)]),
+    "fg_arena_map": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
+    "fg_arena_unmap": (_I, [_P, _P]),
+    "fg_arena_trim": (_I, [_P]),
     "fg_arena_destroy": (_I, [_P]),
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "fg_step_hd_bytes": (ctypes.c_int64, [_I]),

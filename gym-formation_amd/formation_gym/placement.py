@@ -104,37 +104,38 @@ class _Raw(object):
 
 
 class Arena(object):
-    """Address space backed by separately created physical chunks (C ABI `fg_arena_*`).  The tensors made by `floats()`
-    are views of it: keep the Arena alive as long as they are in use."""
+    """A set of separately created physical chunks (C ABI `fg_arena_*`) from which buffers are composed: `map(indices)`
+    gives a device address range made of exactly those chunks; a chunk is mapped at one address at a time.  Tensors made
+    by `floats()` are views of a mapping: keep the Arena alive as long as they are in use."""
 
     def __init__(self, nbytes, device, chunk_bytes=0):
         self.device = torch.device(device)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        handle, base, chunk = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+        handle, chunk, count = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
         _native.check(_native.load().fg_arena_create(int(index), int(nbytes), int(chunk_bytes), ctypes.byref(handle),
-                                                     ctypes.byref(base), ctypes.byref(chunk)))
-        self._handle, self.base, self.chunk = handle, int(base.value), int(chunk.value)
-        self.chunks = -(-int(nbytes) // self.chunk)
+                                                     ctypes.byref(chunk), ctypes.byref(count)))
+        self._handle, self.chunk, self.chunks = handle, int(chunk.value), int(count.value)
         self.kept_range = (0, 0)          # address range of the spread buffer kept in the end (see is_placed)
         import weakref
         _live_arenas.append(weakref.ref(self))
 
     def floats(self, address, nfloats):
-        """A flat float32 tensor over `nfloats` floats at a device address inside the arena (or one of its views)."""
+        """A flat float32 tensor over `nfloats` floats at a device address inside one of the arena's mappings."""
         return torch.as_tensor(_Raw(int(address), nfloats), device=self.device)
 
-    def view(self, chunk_index):
-        """The given chunks (any order) mapped once more at fresh contiguous addresses; returns the base address."""
+    def map(self, chunk_index):
+        """The given chunks (any order) mapped at fresh contiguous addresses; returns the base address."""
         arr = (ctypes.c_uint32 * len(chunk_index))(*[int(c) for c in chunk_index])
         base = ctypes.c_void_p()
-        _native.check(_native.load().fg_arena_view(self._handle, arr, len(chunk_index), ctypes.byref(base)))
+        _native.check(_native.load().fg_arena_map(self._handle, arr, len(chunk_index), ctypes.byref(base)))
         return int(base.value)
 
-    def keep_view(self, view_base):
-        _native.check(_native.load().fg_arena_keep_view(self._handle, ctypes.c_void_p(int(view_base))))
+    def unmap(self, base):
+        _native.check(_native.load().fg_arena_unmap(self._handle, ctypes.c_void_p(int(base))))
 
-    def keep(self, byte_offset, nbytes):
-        _native.check(_native.load().fg_arena_keep(self._handle, int(byte_offset), int(nbytes)))
+    def trim(self):
+        """Hand every chunk that is not mapped right now back to the driver."""
+        _native.check(_native.load().fg_arena_trim(self._handle))
 
     def close(self):
         if self._handle is not None:
@@ -155,13 +156,13 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back to
     `probe_allocation`).  time_fn(flat_tensor) enqueues ONE launch that streams into the candidate buffer.
 
-    Candidates: the first window of the arena as it was created (what a plain allocation gives) and selections of chunks
-    SPREAD over the whole arena - one chunk per stratum, strata in shuffled or golden-stride order (profiles/r03_place/:
-    the wider a buffer's chunks are spread over the device's memory, the faster the launch; neighbouring memory is the
-    slow case).  At least `trials` selections are timed, up to four times as many when `budget_s` affords them (a 0.25 ms
-    launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ by 1 %); all candidate mappings are
-    made before the first launch.  The three fastest are timed once more; the best candidate's chunks are kept, every
-    other chunk goes back to the driver."""
+    Candidates: the arena's first chunks in the order they were created (what a plain allocation gives) and selections of
+    chunks SPREAD over the whole arena - one chunk per stratum, strata in shuffled or golden-stride order
+    (profiles/r03_place/: the wider a buffer's chunks are spread over the device's memory, the faster the launch;
+    neighbouring memory is the slow case).  At least `trials` selections are timed, up to four times as many when
+    `budget_s` affords them (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ
+    by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
+    once more, the winner is mapped for good and every other chunk goes back to the driver."""
     import math
     import random
     import time
@@ -189,17 +190,16 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     W = -(-nbytes // chunk)                                      # chunks per buffer
     stream = torch.cuda.current_stream(device)
     rnd = random.Random(seed)
-    cands, ms = [], []                                           # (kind, address, chunk indices or None), median ms
 
-    def timed(addr, idx, r):                                     # a spread candidate is timed as what it will be: "placed"
-        arena.kept_range = (addr, addr + W * chunk) if idx is not None else (0, 0)
-        return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
-
-    def add(kind, idx):
-        addr = arena.base if idx is None else arena.view(idx)
-        cands.append((kind, addr, idx))
-        ms.append(timed(addr, idx, reps))
-        return ms[-1]
+    def timed(idx, r, placed):                                   # map, time, unmap: one candidate at a time
+        addr = arena.map(idx)
+        arena.kept_range = (addr, addr + W * chunk) if placed else (0, 0)   # a spread candidate is timed as what it will be
+        try:
+            return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
+        finally:
+            stream.synchronize()
+            arena.kept_range = (0, 0)
+            arena.unmap(addr)
 
     def spread_selection(t):
         idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
@@ -219,34 +219,33 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
         off = rnd.randrange(W)
         return "spread, golden stride", [idx[(off + k * g) % W] for k in range(W)]
 
+    first = list(range(W))
     t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
-    while time.perf_counter() - t_warm < 0.05:                   # probe measured 5-8 % slow
-        timed(arena.base, None, 2)
-    t_one = add("as created", None) * 1e-3                       # seconds per launch
+    addr = arena.map(first)                                      # probe measured 5-8 % slow
+    while time.perf_counter() - t_warm < 0.05:
+        _time_launch(time_fn, arena.floats(addr, nfloats), stream, 2)
+    stream.synchronize()
+    arena.unmap(addr)
+    cands = [("as created", first)]
+    ms = [timed(first, reps, False)]
     # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
-    # and its selections differ by 1 %).  ALL candidate mappings are made before the first of them is timed: no page-table
-    # work between launches.
-    count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps + 1) * t_one + 2e-3))))
-    planned = [spread_selection(t) for t in range(count)]
-    views = [(kind, arena.view(idx), idx) for kind, idx in planned]
-    torch.cuda.synchronize(device)
-    for kind, addr, idx in views:
-        cands.append((kind, addr, idx))
-        ms.append(timed(addr, idx, reps))
+    # and its selections differ by 1 %)
+    count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps + 1) * ms[0] * 1e-3 + 4e-3))))
+    for t in range(count):
+        kind, idx = spread_selection(t)
+        cands.append((kind, idx))
+        ms.append(timed(idx, reps, True))
     finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
-    final = {i: timed(cands[i][1], cands[i][2], 2 * reps + 1) for i in finalists}
+    final = {i: timed(cands[i][1], 2 * reps + 1, i > 0) for i in finalists}
     for i, v in final.items():
         ms[i] = v
-    arena.kept_range = (0, 0)
     best = min(final, key=final.get)
-    stream.synchronize()
-    if cands[best][2] is None:
-        arena.keep(0, nbytes)
-    else:
-        arena.keep_view(cands[best][1])
-        arena.kept_range = (cands[best][1], cands[best][1] + W * chunk)
-    flat = arena.floats(cands[best][1], nfloats)
-    spread = sorted(m for c, m in zip(cands, ms) if c[2] is not None)
+    addr = arena.map(cands[best][1])                             # the winner, for good ...
+    arena.trim()                                                 # ... and every other chunk back to the driver
+    if best > 0:
+        arena.kept_range = (addr, addr + W * chunk)
+    flat = arena.floats(addr, nfloats)
+    spread = sorted(ms[1:])
     report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
               "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),

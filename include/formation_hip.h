@@ -171,23 +171,21 @@ typedef struct FgScenario {
 /* Placed device memory ------------------------------------------------------
  * The rate at which the rollout kernels stream observations depends on WHERE in HBM the buffer lies: a multi-GB buffer on
  * physically neighbouring memory runs the same launch at 5.0-5.4 TB/s, one whose chunks are spread over the device's
- * memory at 6.2-6.8 TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  An arena is address space
- * backed by separately created physical chunks (HIP virtual memory management), from which a caller composes buffers:
- *   fg_arena_create     reserves ceil(bytes / chunk) * chunk bytes of address space on `device` (chunk_bytes is rounded up
- *                       to the allocation granularity; 0 = 1 GiB), backs every chunk with device memory, read-write for that
- *                       device; *base = start of the range, *arena = handle, *chunk_out = the chunk size used
- *   fg_arena_view       maps `count` of the chunks (indices into the original range, any order) once more at fresh contiguous
- *                       addresses *base: a candidate buffer made of exactly those chunks
- *   fg_arena_keep_view  keeps the chunks of one view, mapped where that view has them, and hands every other chunk back to
- *                       the driver; the original range and all other views become invalid
- *   fg_arena_keep       the same for a window [offset, offset + bytes) of the original range (all views become invalid)
- *   fg_arena_destroy    releases everything and frees the address ranges
- * Call keep / destroy only when no launch is using the arena.  These are the only entry points that allocate; they
- * enqueue nothing and take no stream. */
-int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, void** base, uint64_t* chunk_out);
-int fg_arena_view(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
-int fg_arena_keep_view(void* arena, void* view_base);
-int fg_arena_keep(void* arena, uint64_t offset, uint64_t bytes);
+ * memory at 6.2-6.8 TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  An arena is a set of
+ * separately created physical chunks (HIP virtual memory management) from which a caller composes buffers:
+ *   fg_arena_create   creates ceil(bytes / chunk) chunks of device memory on `device` (chunk_bytes is rounded up to the
+ *                     allocation granularity; 0 = 1 GiB); nothing is mapped yet.  *chunk_out = chunk size, *chunks_out = count
+ *   fg_arena_map      maps `count` chunks (indices, any order) at fresh contiguous addresses *base, read-write for the
+ *                     device: a buffer made of exactly those chunks.  A chunk is mapped at ONE address at a time
+ *   fg_arena_unmap    removes one such mapping (its chunks become available again; their contents stay)
+ *   fg_arena_trim     hands every chunk that is not mapped right now back to the driver
+ *   fg_arena_destroy  unmaps and releases everything
+ * unmap / destroy drain the device first (no launch may still be using the addresses); map returns when the mapping is
+ * usable.  These are the only entry points that allocate; they enqueue nothing and take no stream. */
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
+int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
+int fg_arena_unmap(void* arena, void* base);
+int fg_arena_trim(void* arena);
 int fg_arena_destroy(void* arena);
 
 /* library / diagnostics --------------------------------------------------- */

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Which allocations are fast?  M candidates of the rollout observation buffer held at once, each timed with the same
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Which allocations are fast?  M candidates of the rollout observation buffer held at once, each timed with the same
 launch; then all freed and M fresh ones timed again.  Prints address, time and GB/s per candidate.
    python profiles/r03_place_scan.py N B K M"""
 import os

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Arena of separately created physical chunks (fg_arena_*, HIP virtual memory management): scan windows with the
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Arena of separately created physical chunks (fg_arena_*, HIP virtual memory management): scan windows with the
 rollout launch, keep the best window's chunks, release the others, time again.
    python profiles/r03_place_scan3.py N B K arena_GB chunk_MB"""
 import ctypes

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Per-chunk rates inside an arena: (a) the rollout launch confined to ONE chunk (K small), (b) torch's fill_ of the chunk.
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Per-chunk rates inside an arena: (a) the rollout launch confined to ONE chunk (K small), (b) torch's fill_ of the chunk.
 Do they rank the chunks alike?   python profiles/r03_place_scan4.py N B Kprobe arena_GB chunk_MB"""
 import ctypes
 import os

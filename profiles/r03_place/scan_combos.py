@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Do arbitrary COMBINATIONS of chunks beat the best contiguous window?  Arena of 1 GiB chunks; contiguous windows
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Do arbitrary COMBINATIONS of chunks beat the best contiguous window?  Arena of 1 GiB chunks; contiguous windows
 first, then views (fg_arena_view) of: the best window reversed, random chunk selections, and a greedy search that swaps
 single chunks of the best window for unused ones.   python profiles/r03_place/scan_combos.py N B K arena_GB"""
 import ctypes

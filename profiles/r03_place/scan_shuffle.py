@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""The buffer as a SHUFFLED set of physical chunks: arena of exactly the buffer's size (+ slack factor), chunks of C MiB,
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+The buffer as a SHUFFLED set of physical chunks: arena of exactly the buffer's size (+ slack factor), chunks of C MiB,
 mapped (a) in allocation order, (b) in random order (fg_arena_view), for several chunk sizes.
    python profiles/r03_place/scan_shuffle.py N B K factor "chunk_MiB ..." """
 import ctypes

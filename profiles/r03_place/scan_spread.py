@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Chunks spread over a LARGE arena: random selections, stratified (one chunk per stratum) ascending / shuffled, for
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Chunks spread over a LARGE arena: random selections, stratified (one chunk per stratum) ascending / shuffled, for
 several chunk sizes.   python profiles/r03_place/scan_spread.py N B K arena_GB "chunk_MiB ..." """
 import ctypes
 import os

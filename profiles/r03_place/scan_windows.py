@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Is the rate a property of the physical REGION?  One big allocation; the rollout launch timed on windows of it at a
+"""[study script: written against the study-time arena API (fg_arena_create with an initial mapping, fg_arena_view,
+fg_arena_keep; library of commits 77e8adc ... f312e76) - the shipped API maps one candidate at a time, include/formation_hip.h]
+Is the rate a property of the physical REGION?  One big allocation; the rollout launch timed on windows of it at a
 stride of a quarter window.   python profiles/r03_place_scan2.py N B K total_GB"""
 import os
 import sys

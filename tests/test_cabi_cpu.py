@@ -139,9 +139,11 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_reset_hd_mt_done(4, 9, 100, *([p] * 9), p + 4, 0, None) == _native.FG_ERR_ALIGNMENT
     # arenas: argument checks (creating one needs a device)
     h, b = ctypes.c_void_p(), ctypes.c_void_p()
-    assert lib.fg_arena_create(0, 0, 0, ctypes.byref(h), ctypes.byref(b), None) == _native.FG_ERR_BAD_ARG
-    assert lib.fg_arena_create(0, 1 << 20, 0, None, ctypes.byref(b), None) == _native.FG_ERR_BAD_ARG
-    assert lib.fg_arena_keep(None, 0, 16) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_create(0, 0, 0, ctypes.byref(h), None, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_create(0, 1 << 20, 0, None, None, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_map(None, None, 0, ctypes.byref(b)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_unmap(None, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_arena_trim(None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_arena_destroy(None) == _native.FG_OK
     # fg_policy_bfs: N must be per_layer^L, 2 <= per_layer <= 8
     assert lib.fg_policy_bfs(0, 9, 3, None, 0, None, None) == _native.FG_OK
