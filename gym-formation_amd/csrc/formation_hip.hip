@@ -361,8 +361,13 @@ extern "C" {
 int fg_abi_version(void) { return FG_ABI_VERSION; }
 
 // ---- placed device memory: separately created physical chunks, mapped into fresh address ranges (HIP virtual memory
-// management).  Discipline: a chunk is mapped at ONE address at a time (no aliases), and the device is drained before any
-// mapping goes away.
+// management).  Discipline: (1) a chunk is mapped at ONE address at a time (no aliases); (2) the device is drained before
+// any mapping goes away; (3) an address range that has held a mapping is NEVER used again in this process: on this stack
+// (ROCm 7.2, MI355X) hipMemUnmap leaves the GPU's translations of the range behind, and a later mapping at the same
+// address has most of its accesses land in the chunks that were mapped there before (profiles/r03_place/va_reuse_check.txt:
+// 73-100 % of the old chunks overwritten).  So reservations are not handed back (hipMemAddressFree would let the very
+// next reservation land on them); they cost address space only - the physical chunks are released as soon as they are
+// not needed.
 namespace {
 struct Arena {
     int dev = 0;
@@ -385,6 +390,8 @@ static void drain_device(int dev) {
     if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
 }
 
+static std::atomic<unsigned long long> g_retired_address_bytes{0};   // reservations retired for good (discipline 3)
+
 static void arena_unmap_slot(Arena* a, size_t slot) {
     Arena::Mapping& m = a->maps[slot];
     if (!m.base) return;
@@ -392,7 +399,7 @@ static void arena_unmap_slot(Arena* a, size_t slot) {
         (void)hipMemUnmap(m.base + j * a->chunk, a->chunk);
         a->mapped_in[m.chunks[j]] = -1;
     }
-    (void)hipMemAddressFree(m.base, m.chunks.size() * a->chunk);
+    g_retired_address_bytes.fetch_add((unsigned long long)(m.chunks.size() * a->chunk));   // the reservation stays: never reused
     m.base = nullptr; m.chunks.clear();
 }
 
@@ -415,6 +422,29 @@ int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** are
         err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
         if (err != hipSuccess) break;
         a->live[i] = 1;
+    }
+    // Physical memory is assigned when a chunk is first mapped, in mapping order: map every chunk once, in index order, so
+    // that a chunk's index says where it lies (chunks far apart in index are far apart in memory - what the caller's
+    // spread selections rely on), then take the mappings away again (the reservation is retired, see above).
+    void* va = nullptr;
+    size_t mapped = 0;
+    if (err == hipSuccess) err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
+    if (err == hipSuccess) {
+        for (; mapped < a->n; ++mapped) {
+            err = hipMemMap((char*)va + mapped * chunk, chunk, 0, a->handle[mapped], 0);
+            if (err != hipSuccess) break;
+        }
+        if (err == hipSuccess) {
+            hipMemAccessDesc desc;
+            memset(&desc, 0, sizeof(desc));
+            desc.location.type = hipMemLocationTypeDevice;
+            desc.location.id = device;
+            desc.flags = hipMemAccessFlagsProtReadWrite;
+            err = hipMemSetAccess(va, a->n * chunk, &desc, 1);
+        }
+        drain_device(device);
+        for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char*)va + i * chunk, chunk);
+        g_retired_address_bytes.fetch_add((unsigned long long)(a->n * chunk));
     }
     if (err != hipSuccess) {
         const int rc = fail(FG_ERR_HIP, "fg_arena_create: %s", hipGetErrorString(err));
@@ -459,7 +489,7 @@ int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void*
         const int rc = fail(FG_ERR_HIP, "fg_arena_map: %s", hipGetErrorString(err));
         (void)hipGetLastError();
         for (uint32_t j = 0; j < done; ++j) (void)hipMemUnmap((char*)va + (size_t)j * a->chunk, a->chunk);
-        (void)hipMemAddressFree(va, (size_t)count * a->chunk);
+        g_retired_address_bytes.fetch_add((unsigned long long)count * a->chunk);   // held a mapping: retired, not freed
         return rc;
     }
     size_t slot = a->maps.size();
@@ -484,6 +514,8 @@ int fg_arena_unmap(void* arena, void* base) {
         }
     return fail(FG_ERR_BAD_ARG, "fg_arena_unmap: not a mapping of this arena%s");
 }
+
+uint64_t fg_arena_retired_address_bytes(void) { return (uint64_t)g_retired_address_bytes.load(); }
 
 int fg_arena_trim(void* arena) {
     Arena* a = (Arena*)arena;

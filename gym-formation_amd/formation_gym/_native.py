@@ -100,6 +100,7 @@ SIGNATURES = {
     "fg_arena_map": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
     "fg_arena_unmap": (_I, [_P, _P]),
     "fg_arena_trim": (_I, [_P]),
+    "fg_arena_retired_address_bytes": (ctypes.c_uint64, []),
     "fg_arena_destroy": (_I, [_P]),
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "fg_step_hd_bytes": (ctypes.c_int64, [_I]),

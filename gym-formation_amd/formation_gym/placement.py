@@ -251,5 +251,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
               "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
               "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
-              "probe_seconds": round(time.perf_counter() - t_start, 2)}
+              "probe_seconds": round(time.perf_counter() - t_start, 2),
+              # address ranges that held a candidate are retired, never reused (stale translations: include/formation_hip.h)
+              "retired_address_space_GB": round(_native.load().fg_arena_retired_address_bytes() / 1e9, 1)}
     return flat, report, arena

@@ -181,11 +181,16 @@ typedef struct FgScenario {
  *   fg_arena_trim     hands every chunk that is not mapped right now back to the driver
  *   fg_arena_destroy  unmaps and releases everything
  * unmap / destroy drain the device first (no launch may still be using the addresses); map returns when the mapping is
- * usable.  These are the only entry points that allocate; they enqueue nothing and take no stream. */
+ * usable.  An address range that has held a mapping is never used again in this process: hipMemUnmap leaves the GPU's
+ * translations of it behind on this stack (profiles/r03_place/va_reuse_check.txt), so the library retires the reservation
+ * instead of freeing it - that costs address space only (fg_arena_retired_address_bytes: the running total; a placement of
+ * a 1.4 GB buffer retires ~250 GB of the 128 TiB), the physical memory goes back at trim / destroy.
+ * These are the only entry points that allocate; they enqueue nothing and take no stream. */
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
 int fg_arena_unmap(void* arena, void* base);
 int fg_arena_trim(void* arena);
+uint64_t fg_arena_retired_address_bytes(void);
 int fg_arena_destroy(void* arena);
 
 /* library / diagnostics --------------------------------------------------- */
