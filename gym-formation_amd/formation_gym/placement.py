@@ -247,7 +247,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     flat = arena.floats(addr, nfloats)
     spread = sorted(ms[1:])
     report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
-              "arena_GB": round(n * chunk / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
+              "arena_GB": round(n * chunk / 1e9, 1), "free_GB_before": round(free / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
               "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
               "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
               "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
