@@ -1,12 +1,12 @@
 #!/usr/bin/env bash
 # Round 3: does the placement probe (formation_gym/placement.py) remove the allocation lottery?  Fresh PROCESSES of the
-# same bench command, with the probe (default: up to 8 candidates, early stop) and without (--placement-candidates 1), interleaved so
+# same bench command, with the probe (default) and without (--placement-candidates 1), interleaved so
 # that both arms see the same box state.  Usage on the GPU box: bash profiles/r03_placement.sh [runs]
 RUNS="${1:-10}"
 R=$PWD
 OUT=$R/gpurun_out/r03_placement
 rm -rf "$OUT"; mkdir -p "$OUT"
-for cfg in "243 8192 4 24" "81 2048 20 200"; do
+for cfg in "243 8192 4 24" "81 2048 20 200" "27 4096 20 1000"; do
   set -- $cfg
   for i in $(seq 1 $RUNS); do
     for arm in 8 1; do
@@ -19,10 +19,10 @@ done
 python3 - "$OUT" <<'PY' | tee "$R/gpurun_out/r03_placement.md"
 import glob, json, os, sys
 out = sys.argv[1]
-print("# Placement probe: fresh bench.py processes on one box, with (up to 8 candidates) and without (1) the probe\n")
+print("# Placement probe: fresh bench.py processes on one box, with the probe (>= 8 spread selections) and without (--placement-candidates 1)\n")
 print("| shape | arm | runs | TB/s min | median | max | spread (max/min - 1) | probe: worst/kept per run |")
 print("|---|---|---|---|---|---|---|---|")
-for n, shape in ((243, "243 x 8192, 4 steps/launch"), (81, "81 x 2048, 20 steps/launch")):
+for n, shape in ((243, "243 x 8192, 4 steps/launch"), (81, "81 x 2048, 20 steps/launch"), (27, "27 x 4096, 20 steps/launch")):
     for arm in (8, 1):
         vals, ratios = [], []
         for f in sorted(glob.glob(os.path.join(out, "n%d_c%d_*.json" % (n, arm)))):
