@@ -226,7 +226,11 @@ static int launch_wide_v(Args a, hipStream_t st) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
         // stream, few enough to keep every CU busy (one workgroup per CU; MI355X sweep, profiles/README.md)
         const int batches = (a.B + E - 1) / E;
+#ifdef FG_EXP_GROUP_DIV
+        a.groups = batches / (NC == 27 ? FG_EXP_GROUP_DIV : 256);
+#else
         a.groups = batches / 256;
+#endif
         if (a.groups < 1) a.groups = 1;
         if (a.groups > 64) a.groups = 64;
     } else {
@@ -575,6 +579,10 @@ int fg_step_hd(const FgParams* params, int B, int N,
     // (74 vs 80 us at 81 x 2048 on the same box, profiles/README.md).
     if (N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
         return launch_wide(a, (hipStream_t)stream);
+#ifdef FG_EXP_STEP27_E
+    if (N == 27 && B >= 2048 && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
+        return launch_wide_v<27, 1, FG_EXP_STEP27_E, FG_EXP_STEP27_TW, false>(a, (hipStream_t)stream);
+#endif
     return launch_step(a, (hipStream_t)stream);
 }
 
