@@ -31,6 +31,11 @@ clock feeds `value`, `ms_per_step` and `roofline.achieved`: the MEDIAN block on
 the GPU's own timeline (gaps between launches included); min / max / count and
 the host wall clock of the same series are reported beside it (`timing`).
 
+`roofline.traffic` (HBM bytes per launch from the PMC counters) is measured in the same run on the same box at N = 1:
+before this process touches the GPU, two short child runs of the workload under `rocprofv3 --pmc WRITE_SIZE` and
+`--pmc FETCH_SIZE` (`live_traffic`; ~40 s; `--no-live-traffic` or any failure falls back to the figure of the committed
+profile, `profiles/*_<N>x<B>*.json`, which is reported beside it either way).
+
 Prints ONE JSON line (rank 0).  `value` = env-steps/s over all GPUs.
 """
 import argparse
@@ -63,6 +68,59 @@ def measured_traffic(n_agents, envs, mode, steps_per_launch):
                 cfg.get("steps_per_launch", 1) == steps_per_launch:
             best = (d["hbm_traffic_bytes_per_launch"], os.path.basename(f))
     return best
+
+
+def live_traffic(a):
+    """HBM bytes per launch of this run's kernel measured NOW, on this box: a short bench of the same workload is run as a
+    CHILD process under `rocprofv3 --pmc`, once per counter (WRITE_SIZE, FETCH_SIZE: separate passes, KiB units, read side
+    doubled on gfx950 - MI355X_MICROARCH.md, HBM section; the same arithmetic as profiles/summarize.py), before this process
+    touches the GPU.  Returns (bytes or None, description).  Any failure (no rocprofv3, a pass that times out, an empty
+    counter file) leaves the committed profile's figure in place - the reason is reported in `traffic_live_error`."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = next((p for p in ("/opt/rocm/bin/rocprofv3", shutil.which("rocprofv3")) if p and os.path.exists(p)), None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    want = "rollout_kernel" if a.mode == "rollout" else "step_kernel"
+    tmp = tempfile.mkdtemp(prefix="fg_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--agents", str(a.agents), "--envs", str(a.envs), "--mode", a.mode,
+             "--chunk", str(a.chunk), "--steps", str(2 * a.chunk), "--warmup", str(a.chunk), "--min-timed-ms", "1",
+             "--prewarm-ms", "0", "--no-cpu-baseline", "--no-extra", "--no-live-traffic",
+             "--placement-candidates", str(a.placement_candidates)]
+    kib, launches = {}, 0
+    try:
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            out = os.path.join(tmp, counter)
+            proc = subprocess.Popen([exe, "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child, cwd="/tmp",
+                                    env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                rc = proc.wait(timeout=150)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)                # the session this call started, nothing else
+                proc.wait()
+                return None, "the %s pass did not finish in 150 s" % counter
+            if rc != 0:
+                return None, "the %s pass exited with %d" % (counter, rc)
+            per_kernel = {}
+            for f in glob.glob(os.path.join(out, "**", "*_counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and "fg::" in r.get("Kernel_Name", "") and want in r["Kernel_Name"]:
+                        per_kernel.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            if not per_kernel:
+                return None, "no %s rows for an fg:: %s" % (counter, want)
+            vals = sorted(max(per_kernel.values(), key=len))       # the kernel with the most launches: the workload's own
+            kib[counter] = vals[len(vals) // 2]
+            launches = len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = int(1024 * (kib["WRITE_SIZE"] + 2.0 * kib["FETCH_SIZE"]))
+    return total, ("live: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, read side x 2) around a short run "
+                   "of this workload on this box, median of %d launches" % launches)
 
 
 def n1_reference(workload_key):
@@ -219,6 +277,9 @@ def main():
     ap.add_argument("--placement-candidates", type=int, default=8,
                     help="observation buffers beyond the Infinity Cache: allocate up to this many candidates, time the launch "
                          "on each, keep the fastest (formation_gym/placement.py); 1 = no probe")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed profile instead of two rocprofv3 --pmc child runs on this box "
+                         "(implied by --no-extra, by more than one rank, and when this process runs under a profiler)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for the timing barrier (gloo: ranks may share a GPU, test only)")
     a = ap.parse_args()
@@ -234,6 +295,16 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode)
+
+    # roofline.traffic measured on THIS box (N = 1 only), before this process initialises the GPU
+    live = (None, None)
+    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and a.gpus == 1 and not (a.no_live_traffic or a.no_extra or profiled) \
+            and a.obs_every == 1:
+        try:
+            live = live_traffic(a)
+        except Exception as exc:                                   # never let the side measurement take the bench down
+            live = (None, "%s: %s" % (type(exc).__name__, exc))
 
     import numpy as np
     import torch
@@ -599,6 +670,9 @@ def main():
         spl = 1 if a.mode == "step" else chunk
         alg_launch = bytes_per_env_step * B * spl
         traffic, traffic_src = measured_traffic(N, B, a.mode, spl)
+        committed = (traffic, traffic_src)
+        if live[0]:
+            traffic, traffic_src = live
         res = {
             "metric": "env-steps/sec", "value": round(value, 1), "unit": "env-steps/s",
             "agent_steps_per_s": round(value * N, 1),
@@ -637,6 +711,10 @@ def main():
         }
         if any(v and v.get("probed") for v in m["placement"].values()):
             res["placement"] = m["placement"]
+        if live[0]:
+            res["roofline"]["traffic_committed_profile"] = {"bytes": committed[0], "source": committed[1]}
+        elif live[1]:
+            res["roofline"]["traffic_live_error"] = live[1]
         if traffic:
             # the SURVEY 8(d) formula counts the pos/vel round trip of every step; a K-step launch keeps the state in
             # registers, so the PMC counters see fewer bytes (committed profile: ratio below); both are reported

@@ -475,6 +475,12 @@ def test_bench_json_contract_single_and_two_ranks():
         assert k in d
     assert d["n_gpus"] == 1 and d["steps"] == 30 and d["dtype"] == "f32" and d["roofline"]["bound"] == "hbm"
     assert d["state_finite"] and d["value"] > 0 and "workload" in d["config"]
+    # roofline.traffic is measured on this box by two rocprofv3 --pmc child runs (or says why it could not be)
+    r = d["roofline"]
+    if str(r.get("traffic_source", "")).startswith("live"):
+        assert 0.5 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.5, r
+    else:
+        assert "traffic_live_error" in r, r
     # ONE clock: value, ms_per_step and roofline.achieved all come from the median HIP-event block, and a short
     # --steps block is repeated until >= 50 ms have been timed
     t = d["timing"]
