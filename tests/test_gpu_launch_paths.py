@@ -665,3 +665,60 @@ def test_placed_closed_loop_rollout_equals_policy_and_step_calls():
     for x, y in zip(a.world.get_state(), b.world.get_state()):
         assert torch.equal(x, y)
     assert bool(done.any())
+
+
+def test_arena_mappings_get_fresh_addresses_and_chunks_keep_their_contents():
+    """The discipline of fg_arena_* (include/formation_hip.h): a chunk has one address at a time, an address range that
+    held a mapping is never handed out again (on this stack a mapping at a reused address corrupts the chunks mapped
+    there before: profiles/r03_place/va_reuse_check.txt), chunks keep their contents across unmap / map, and trimmed
+    memory goes back to the driver."""
+    from formation_gym import _native, placement
+    dev = torch.device("cuda:0")
+    CH, W = 32 << 20, 4
+
+    def free_bytes():                                       # without what torch's own allocator caches
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info(dev)[0]
+
+    x = torch.zeros(1 << 20, device=dev); x.fill_(1.0)     # the kernels used below, loaded before memory is counted
+    assert bool((x == 1.0).all()) and float(x.sum()) == float(1 << 20)
+    del x
+    free0 = free_bytes()
+    retired0 = _native.load().fg_arena_retired_address_bytes()
+    arena = placement.Arena(4 * W * CH, dev, CH)
+    assert arena.chunks == 4 * W and arena.chunk == CH
+    assert _native.load().fg_arena_retired_address_bytes() >= retired0 + 4 * W * CH      # the placing pass at creation
+    nfl = W * CH // 4
+    seen = []
+    for r in range(4):
+        A = list(range(0, 2 * W, 2)) if r % 2 == 0 else list(range(2 * W, 4 * W, 2))    # spread selections
+        Bc = [c + 1 for c in A]
+        va = arena.map(A)
+        with pytest.raises(_native.FormationHipError):                                  # a mapped chunk cannot be mapped again
+            arena.map([A[0], Bc[1], Bc[2], Bc[3]])
+        ta = arena.floats(va, nfl); ta.fill_(float(r + 1)); torch.cuda.synchronize(); del ta
+        arena.unmap(va)
+        vb = arena.map(Bc)
+        tb = arena.floats(vb, nfl); tb.fill_(-float(r + 1)); torch.cuda.synchronize()
+        assert bool((tb == -float(r + 1)).all())
+        del tb
+        arena.unmap(vb)
+        va2 = arena.map(A)
+        ta = arena.floats(va2, nfl)
+        assert bool((ta == float(r + 1)).all()), "chunks lost their contents across unmap / map (round %d)" % r
+        del ta
+        arena.unmap(va2)
+        seen += [va, vb, va2]
+    spans = sorted((v, v + W * CH) for v in seen)
+    assert all(x[1] <= y[0] for x, y in zip(spans, spans[1:])), "an address range was handed out twice"
+    keep = arena.map([1, 5, 9, 13])
+    arena.trim()
+    assert free0 - free_bytes() < W * CH + (128 << 20)                                  # everything but the kept chunks is back
+    with pytest.raises(_native.FormationHipError):
+        arena.map([0, 2, 4, 6])                                                         # trimmed chunks are gone
+    t = arena.floats(keep, nfl); t.fill_(3.0); torch.cuda.synchronize()
+    assert float(t.sum()) == 3.0 * nfl
+    del t
+    arena.close()
+    assert free0 - free_bytes() < (128 << 20)
