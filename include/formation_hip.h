@@ -174,7 +174,10 @@ typedef struct FgScenario {
  * memory at 6.2-6.8 TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  An arena is a set of
  * separately created physical chunks (HIP virtual memory management) from which a caller composes buffers:
  *   fg_arena_create   creates ceil(bytes / chunk) chunks of device memory on `device` (chunk_bytes is rounded up to the
- *                     allocation granularity; 0 = 1 GiB); nothing is mapped yet.  *chunk_out = chunk size, *chunks_out = count
+ *                     allocation granularity; 0 = 1 GiB) and gives them their place in memory in INDEX order (a chunk is
+ *                     placed when it is first mapped, so every chunk is mapped once and unmapped again: chunks far apart
+ *                     in index lie far apart in memory); on return nothing is mapped.  *chunk_out = chunk size,
+ *                     *chunks_out = count
  *   fg_arena_map      maps `count` chunks (indices, any order) at fresh contiguous addresses *base, read-write for the
  *                     device: a buffer made of exactly those chunks.  A chunk is mapped at ONE address at a time
  *   fg_arena_unmap    removes one such mapping (its chunks become available again; their contents stay)
@@ -185,7 +188,8 @@ typedef struct FgScenario {
  * translations of it behind on this stack (profiles/r03_place/va_reuse_check.txt), so the library retires the reservation
  * instead of freeing it - that costs address space only (fg_arena_retired_address_bytes: the running total; a placement of
  * a 1.4 GB buffer retires ~250 GB of the 128 TiB), the physical memory goes back at trim / destroy.
- * These are the only entry points that allocate; they enqueue nothing and take no stream. */
+ * These are the only entry points that allocate; they enqueue nothing and take no stream.  Calls on ONE arena must not
+ * run concurrently (the arena is the caller's object; different arenas are independent). */
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
 int fg_arena_unmap(void* arena, void* base);
