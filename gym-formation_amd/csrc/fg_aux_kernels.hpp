@@ -199,10 +199,52 @@ struct ScnArgs {
     FgScenario sc;
     int B, N, do_phys;
     float* px; float* py; float* vx; float* vy;
-    const float* act; const float* lm; float* opos; float* ovel; int32_t* step;
+    const float* act; float* lm; float* opos; float* ovel; int32_t* step;
     float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
     int stage;     // compose the workgroup's observation rows in LDS and stream them out as ONE contiguous span
 };
+
+// Scenario.reset_world of these scenarios from the device counter RNG (basic_formation_env.py:54-65,
+// formation_hd_partial_env.py:88-99, formation_hd_partial_range_env.py:76-87, formation_hd_obs_env.py:101-114): agents and landmarks U(-1,1)^2, velocities zero,
+// obstacle k from U([s_k, 2.0], [s_k+1, 2.5]) with s = linspace(-1.8, 1.8, M + 1), falling at the scenario's velocity.
+// One Philox block per entity, counter (global env index, entity code, per-launch offset); entity code = agent index,
+// 0x10000000 | landmark index, 0x20000000 | obstacle index (formation_hd_env's reset uses the agent indices and
+// 0xFFFFFFFF the same way).  Distributional parity with the reference's MT19937 draws, as for formation_hd_env.
+constexpr uint32_t SCN_LANDMARK_CODE = 0x10000000u, SCN_OBSTACLE_CODE = 0x20000000u;
+__device__ __forceinline__ float2 scn_fresh_pm1(const FgParams& P, int b, uint32_t code) {
+    uint32_t c[4] = {(uint32_t)(b + P.env_index_base), code, (uint32_t)rng_base(P), (uint32_t)(rng_base(P) >> 32)};
+    philox4x32(c, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
+    return make_float2(u_pm1(c[0]), u_pm1(c[1]));
+}
+__device__ __forceinline__ float2 scn_fresh_obstacle(const FgParams& P, int b, int k, int M) {
+    const float2 r = scn_fresh_pm1(P, b, SCN_OBSTACLE_CODE | (uint32_t)k);
+    const float lo = -1.8f + 3.6f * (float)k / (float)M, hi = -1.8f + 3.6f * (float)(k + 1) / (float)M;
+    return make_float2(lo + (hi - lo) * (0.5f * r.x + 0.5f), 2.0f + 0.5f * (0.5f * r.y + 0.5f));
+}
+
+// standalone masked reset of the landmark scenarios (mask NULL = every env): the draws scn_kernel's fused auto-reset makes
+__global__ __launch_bounds__(256) void scn_reset_kernel(const FgParams P, const FgScenario sc, int B, int N,
+                                                        const uint8_t* __restrict__ mask,
+                                                        float* px, float* py, float* vx, float* vy,
+                                                        float2* lm, float2* opos, float2* ovel, int32_t* step) {
+    const int L = sc.num_landmarks, M = sc.num_obstacles, per = N + L + M;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * per) return;
+    const int b = (int)(t / per), r = (int)(t - (long long)b * per);
+    if (mask && !mask[b]) return;
+    if (r < N) {
+        const float2 q = scn_fresh_pm1(P, b, (uint32_t)r);
+        const size_t o = (size_t)b * N + r;
+        px[o] = q.x; py[o] = q.y; vx[o] = 0.f; vy[o] = 0.f;
+        if (r == 0 && step) step[b] = 0;
+    } else if (r < N + L) {
+        lm[(size_t)b * L + (r - N)] = scn_fresh_pm1(P, b, SCN_LANDMARK_CODE | (uint32_t)(r - N));
+    } else {
+        const int k = r - N - L;
+        opos[(size_t)b * M + k] = scn_fresh_obstacle(P, b, k, M);
+        ovel[(size_t)b * M + k] = make_float2(sc.obstacle_vx, sc.obstacle_vy);
+    }
+}
 
 template <int G, int T>
 __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
@@ -351,6 +393,32 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         if (a.rew) a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
         if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
         if (a.done) a.done[sidx] = is_done ? 1 : 0;
+    }
+    if (a.p.auto_reset && a.do_phys) {                  // uniform over the launch
+        // the vec-env worker's rule (env_wrappers.py:14-18): an env whose episode is over restarts at once, and the
+        // observation returned with the finished step's reward / done is the RESET observation
+        __syncthreads();                                // every lane has finished reading POST / LM of the finished step
+        if (live && is_done) {
+            if (is_agent) {
+                p = scn_fresh_pm1(a.p, b, (uint32_t)i); v = make_float2(0.f, 0.f);
+                POST[i] = p;
+                a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
+            } else if (is_obst) {
+                p = scn_fresh_obstacle(a.p, b, i - N, M);
+                POST[i] = p;
+                reinterpret_cast<float2*>(a.opos)[oidx] = p;
+                reinterpret_cast<float2*>(a.ovel)[oidx] = make_float2(a.sc.obstacle_vx, a.sc.obstacle_vy);
+            }
+            for (int l = i; l < L; l += G) {
+                const float2 m = scn_fresh_pm1(a.p, b, SCN_LANDMARK_CODE | (uint32_t)l);
+                LM[l] = m;
+                reinterpret_cast<float2*>(a.lm)[(size_t)b * L + l] = m;
+            }
+            t_step = 0;
+        }
+        __syncthreads();
+    }
+    if (is_agent) {
         // every lane composes its own row: straight to global memory (rows D floats apart: one 8-byte piece per lane
         // and instruction), or into the workgroup's LDS image of its [E][N][D] block, which all lanes then copy out
         // with consecutive 8-byte stores (a.stage; 16 x 65536 obstacle envs: 203 -> see profiles/r02_aux_kernels.md)

@@ -699,7 +699,7 @@ int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
 
 static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, int N, int do_physics,
                            float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                           const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                           const float* act, float* landmarks, float* obst_pos, float* obst_vel,
                            int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                            int32_t* near_ag, void* stream) {
     const DeviceGuard device_guard(stream, pos_x);
@@ -812,7 +812,7 @@ int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, 
 
 int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int do_physics,
                      float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                     const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                     const float* act, float* landmarks, float* obst_pos, float* obst_vel,
                      int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                      void* stream) {
     return launch_scenario(params, scenario, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
@@ -821,13 +821,39 @@ int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, 
 
 int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                  const float* act, const float* landmarks, int32_t* step,
+                  const float* act, float* landmarks, int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_ag, void* stream) {
     FgScenario sc; memset(&sc, 0, sizeof(sc));
     sc.kind = FG_SCN_BASIC; sc.num_landmarks = L; sc.penalty = 1.0f;
     return launch_scenario(params, &sc, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
                            nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
+}
+
+int fg_reset_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, const uint8_t* mask,
+                      float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                      float* landmarks, float* obst_pos, float* obst_vel, int32_t* step, void* stream) {
+    const DeviceGuard device_guard(stream, pos_x);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (!scenario) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
+    const int L = scenario->num_landmarks, M = scenario->num_obstacles;
+    if (scenario->kind < FG_SCN_BASIC || scenario->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
+    if (B == 0) return FG_OK;
+    if (B < 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B >= 0, L > 0, M >= 0 required%s");
+    if (N < 2 || N + M > FG_MAX_AGENTS || L > 1024)
+        return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 1024, L <= 1024%s");
+    if (!pos_x || !pos_y || !vel_x || !vel_y || !landmarks || (M > 0 && (!obst_pos || !obst_vel)))
+        return fail(FG_ERR_BAD_ARG, "fg_reset_scenario: a required pointer is NULL%s");
+    if (((uintptr_t)landmarks & 7u) || ((uintptr_t)obst_pos & 7u) || ((uintptr_t)obst_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "landmarks / obstacle buffers must be 8-byte aligned%s");
+    const long long count = (long long)B * (N + L + M);
+    hipLaunchKernelGGL(scn_reset_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       *params, *scenario, B, N, mask, pos_x, pos_y, vel_x, vel_y, reinterpret_cast<float2*>(landmarks),
+                       reinterpret_cast<float2*>(obst_pos), reinterpret_cast<float2*>(obst_vel), step);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario reset launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
 }
 
 // the controller from the simulator state: one launch, shared by fg_policy_bfs_state and the chained closed loop

@@ -71,17 +71,18 @@ class Scenario(BaseScenario):
         N, L = len(world.agents), len(world.landmarks)
         return 4 + 2 * L + 4 * (N - 1)
 
-    def params(self, world, rng_offset=0):
+    def params(self, world, rng_offset=0, auto_reset=False):
         a0 = world.agents[0]
-        p = world.native_params(collide_thresh=a0.size + a0.size, seed=self._seed, rng_offset=rng_offset)     # :91
+        p = world.native_params(collide_thresh=a0.size + a0.size, auto_reset=auto_reset, seed=self._seed,
+                                rng_offset=rng_offset)                                # :91
         # the device counter RNG (motor noise) is keyed by seed, GLOBAL env index and the per-step offset, like formation_hd_env's
         p.env_index_base = int(getattr(self, "env_base", 0))
         return p
 
-    def _launch(self, world, act, out, do_physics, rng_offset=0):
+    def _launch(self, world, act, out, do_physics, rng_offset=0, auto_reset=False):
         lib = _native.load()
         _native.check(lib.fg_step_basic(
-            self.params(world, rng_offset), world.num_envs, len(world.agents), len(world.landmarks),
+            self.params(world, rng_offset, auto_reset), world.num_envs, len(world.agents), len(world.landmarks),
             1 if do_physics else 0,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
@@ -92,10 +93,8 @@ class Scenario(BaseScenario):
     def bind_step(self, world, act, out, auto_reset=False):
         """Resolve FgParams and every pointer once; returns `launch(rng_offset)` (one ctypes call
         per step, see MultiAgentEnv._bound_step)."""
-        if auto_reset:
-            raise NotImplementedError("device auto-reset is built for formation_hd_env only")
         lib = _native.load()
-        p = self.params(world)
+        p = self.params(world, auto_reset=auto_reset)
         args = (world.num_envs, len(world.agents), len(world.landmarks), 1,
                 world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
                 act.data_ptr(), world.landmark_pos.data_ptr(), world.step_count.data_ptr(),
@@ -114,9 +113,18 @@ class Scenario(BaseScenario):
         return launch
 
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
-        if auto_reset:
-            raise NotImplementedError("device auto-reset is built for formation_hd_env only")
-        self._launch(world, act, out, True, rng_offset)
+        """auto_reset: envs whose episode ends restart inside the launch (device counter RNG; the reset observation comes
+        back with the finished step's reward / done: the vec-env worker's rule, env_wrappers.py:14-18)."""
+        self._launch(world, act, out, True, rng_offset, auto_reset)
+
+    def reset_device(self, world, mask=None, rng_offset=0):
+        """Throughput-mode reset on the GPU (counter RNG, distributional parity only): the draws the fused auto-reset makes."""
+        sc = _native.FgScenario(kind=_native.FG_SCN_BASIC, num_landmarks=len(world.landmarks), num_obstacles=0, penalty=1.0)
+        _native.check(_native.load().fg_reset_scenario(
+            self.params(world, rng_offset), sc, world.num_envs, len(world.agents), _native.ptr(mask),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            world.landmark_pos.data_ptr(), None, None, world.step_count.data_ptr(), _native.current_stream(world.device)))
+        self._cache = None
 
     def observe_batch(self, world, out):
         self._launch(world, None, out, False)

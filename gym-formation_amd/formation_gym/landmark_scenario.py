@@ -102,9 +102,10 @@ class LandmarkScenario(BaseScenario):
         nbr = self.num_obs if self.KIND == _native.FG_SCN_PARTIAL else N - 1
         return 2 + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1)
 
-    def params(self, world, rng_offset=0):
+    def params(self, world, rng_offset=0, auto_reset=False):
         a0 = world.agents[0]
-        p = world.native_params(collide_thresh=a0.size + a0.size, seed=self._seed, rng_offset=rng_offset)      # is_collision: size_a + size_b
+        p = world.native_params(collide_thresh=a0.size + a0.size, auto_reset=auto_reset, seed=self._seed,
+                                rng_offset=rng_offset)                                 # is_collision: size_a + size_b
         # the device counter RNG (motor noise) is keyed by seed, GLOBAL env index and the per-step offset, like formation_hd_env's
         p.env_index_base = int(getattr(self, "env_base", 0))
         return p
@@ -116,11 +117,11 @@ class LandmarkScenario(BaseScenario):
                                   obstacle_vx=self.OBSTACLE_VEL[0], obstacle_vy=self.OBSTACLE_VEL[1],
                                   obstacle_floor=self.OBSTACLE_FLOOR, penalty=self.PENALTY)
 
-    def _launch(self, world, act, out, do_physics, rng_offset=0):
+    def _launch(self, world, act, out, do_physics, rng_offset=0, auto_reset=False):
         lib = _native.load()
         M = self.num_obstacles
         _native.check(lib.fg_step_scenario(
-            self.params(world, rng_offset), self.descriptor(), world.num_envs, len(world.agents), 1 if do_physics else 0,
+            self.params(world, rng_offset, auto_reset), self.descriptor(), world.num_envs, len(world.agents), 1 if do_physics else 0,
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             _native.ptr(act), world.landmark_pos.data_ptr(),
             world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
@@ -132,12 +133,9 @@ class LandmarkScenario(BaseScenario):
     def bind_step(self, world, act, out, auto_reset=False):
         """Resolve the structs and every pointer once; returns `launch(rng_offset)` (one ctypes call
         per step, see MultiAgentEnv._bound_step)."""
-        if auto_reset:
-            raise NotImplementedError("device auto-reset is built for formation_hd_env only; "
-                                      "use FormationVecEnv(reset_mode='host')")
         lib = _native.load()
         M = self.num_obstacles
-        p, d = self.params(world), self.descriptor()
+        p, d = self.params(world, auto_reset=auto_reset), self.descriptor()
         args = (world.num_envs, len(world.agents), 1,
                 world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
                 act.data_ptr(), world.landmark_pos.data_ptr(),
@@ -158,10 +156,19 @@ class LandmarkScenario(BaseScenario):
         return launch
 
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
-        if auto_reset:
-            raise NotImplementedError("device auto-reset is built for formation_hd_env only; "
-                                      "use FormationVecEnv(reset_mode='host')")
-        self._launch(world, act, out, True, rng_offset)
+        """auto_reset: envs whose episode ends restart inside the launch (device counter RNG; the reset observation comes
+        back with the finished step's reward / done: the vec-env worker's rule, env_wrappers.py:14-18)."""
+        self._launch(world, act, out, True, rng_offset, auto_reset)
+
+    def reset_device(self, world, mask=None, rng_offset=0):
+        """Throughput-mode reset on the GPU (counter RNG, distributional parity only): the draws the fused auto-reset makes."""
+        M = self.num_obstacles
+        _native.check(_native.load().fg_reset_scenario(
+            self.params(world, rng_offset), self.descriptor(), world.num_envs, len(world.agents), _native.ptr(mask),
+            world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+            world.landmark_pos.data_ptr(), world.obstacle_pos.data_ptr() if M else None,
+            world.obstacle_vel.data_ptr() if M else None, world.step_count.data_ptr(), _native.current_stream(world.device)))
+        self._cache = None
 
     def observe_batch(self, world, out):
         self._launch(world, None, out, False)

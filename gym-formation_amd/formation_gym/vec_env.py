@@ -13,8 +13,8 @@ import torch
 class FormationVecEnv(object):
     def __init__(self, env, reset_mode="device"):
         """reset_mode:
-          'device'    counter RNG inside the fused step launch (fastest; distributional parity)
-          'device_mt' the reference's own MT19937 streams continued on the GPU (bit-exact resets,
+          'device'    counter RNG inside the fused step launch (fastest; distributional parity); every scenario in envs/
+          'device_mt' (formation_hd_env) the reference's own MT19937 streams continued on the GPU (bit-exact resets,
                       no host round trip: the host mirrors the step counters, which are deterministic)
           'host'      the reference's streams on the host (bit-exact; needs a device->host sync)"""
         if reset_mode not in ("device", "device_mt", "host"):

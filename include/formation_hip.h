@@ -280,10 +280,11 @@ int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, 
 
 /* MultiAgentEnv.step for basic_formation_env (BASELINE config 1):
  * same physics; observation basic_formation_env.py:29-41, reward :43-52.
- *   landmarks float [B][L][2]; obs float [B][N][4 + 2L + 4(N-1)]. */
+ *   landmarks float [B][L][2]; obs float [B][N][4 + 2L + 4(N-1)].
+ * params->auto_reset: as for fg_step_scenario below. */
 int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
                   float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                  const float* act, const float* landmarks, int32_t* step,
+                  const float* act, float* landmarks, int32_t* step,
                   float* obs, float* reward, float* indiv_reward, uint8_t* done,
                   int32_t* near_ag, void* stream);
 
@@ -292,12 +293,26 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
  * per workgroup beyond):
  *   landmarks float [B][L][2]; obst_pos, obst_vel float [B][M][2] (updated in place, NULL if M = 0);
  *   obs float [B][N][D], D = 2 (+2 basic) + 2L + 2M + 2*nbr + 2(N-1), nbr = num_obs (partial) or N-1.
- * do_physics = 0 evaluates observation/reward/done on the current state (env.reset()). */
+ * do_physics = 0 evaluates observation/reward/done on the current state (env.reset()).
+ * params->auto_reset (with do_physics): the vec-env worker's rule inside the launch (env_wrappers.py:14-18) - an env whose
+ * step counter reaches world_length restarts at once: agents, landmarks and obstacles are re-drawn exactly as
+ * fg_reset_scenario draws them (same counter RNG: seed, env_index_base + b, rng_offset), step = 0, and the observation
+ * written is the RESET observation while reward / indiv_reward / done keep the finished step's values.  `landmarks` is
+ * written only then. */
 int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int do_physics,
                      float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-                     const float* act, const float* landmarks, float* obst_pos, float* obst_vel,
+                     const float* act, float* landmarks, float* obst_pos, float* obst_vel,
                      int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                      void* stream);
+
+/* Scenario.reset_world of the landmark scenarios on device for the envs whose mask byte is non-zero (mask NULL = all),
+ * counter-based RNG (basic_formation_env.py:54-65, formation_hd_partial_env.py:88-99, formation_hd_partial_range_env.py:76-87,
+ * formation_hd_obs_env.py:101-114 draw distribution): agent and landmark positions ~ U(-1,1)^2, velocities 0, obstacle k
+ * ~ U([s_k, 2.0], [s_k+1, 2.5]) with s = linspace(-1.8, 1.8, M + 1) and velocity (obstacle_vx, obstacle_vy), step = 0.
+ * basic_formation_env: scenario->kind = FG_SCN_BASIC, num_landmarks = L, num_obstacles = 0. */
+int fg_reset_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, const uint8_t* mask,
+                      float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                      float* landmarks, float* obst_pos, float* obst_vel, int32_t* step, void* stream);
 
 /* Action decoding of MultiAgentEnv._set_action (environment.py:187-215) for the non-default action
  * modes, before the sensitivity scaling (which the step kernels apply).  `count` = B*N agents.

@@ -117,6 +117,11 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_step_scenario(P, sc, 4, 1022, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 1024
     assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_reset_scenario(P, sc, 0, 4, *([None] * 10)) == _native.FG_OK          # empty batch
+    assert lib.fg_reset_scenario(P, None, 4, 4, *([p] * 10)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_reset_scenario(P, sc, 4, 1022, *([p] * 10)) == _native.FG_ERR_UNSUPPORTED_N
+    assert lib.fg_reset_scenario(P, sc, 4, 4, None, p, p, p, p, p, None, None, p, None) == _native.FG_ERR_BAD_ARG   # obstacles missing
+    assert lib.fg_reset_scenario(P, sc, 4, 4, None, p, p, p, p, p + 4, p, p, p, None) == _native.FG_ERR_ALIGNMENT
     assert lib.fg_decode_actions(0, 12, p, p, None) == _native.FG_ERR_BAD_ARG           # unknown mode
     assert lib.fg_decode_actions(_native.FG_ACT_INDEX, -3, p, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
