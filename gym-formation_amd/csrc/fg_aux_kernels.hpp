@@ -202,6 +202,8 @@ struct ScnArgs {
     const float* act; float* lm; float* opos; float* ovel; int32_t* step;
     float* obs; float* rew; float* indiv; uint8_t* done; int32_t* near_ag;
     int stage;     // compose the workgroup's observation rows in LDS and stream them out as ONE contiguous span
+    int K;         // steps per launch (fg_rollout_scenario; 1 otherwise): act / reward / indiv / done / near_ag [K][B]...,
+    int obs_every; // obs [K / obs_every][B][N][D]
 };
 
 // Scenario.reset_world of these scenarios from the device counter RNG (basic_formation_env.py:54-65,
@@ -211,13 +213,13 @@ struct ScnArgs {
 // 0x10000000 | landmark index, 0x20000000 | obstacle index (formation_hd_env's reset uses the agent indices and
 // 0xFFFFFFFF the same way).  Distributional parity with the reference's MT19937 draws, as for formation_hd_env.
 constexpr uint32_t SCN_LANDMARK_CODE = 0x10000000u, SCN_OBSTACLE_CODE = 0x20000000u;
-__device__ __forceinline__ float2 scn_fresh_pm1(const FgParams& P, int b, uint32_t code) {
-    uint32_t c[4] = {(uint32_t)(b + P.env_index_base), code, (uint32_t)rng_base(P), (uint32_t)(rng_base(P) >> 32)};
+__device__ __forceinline__ float2 scn_fresh_pm1(const FgParams& P, int b, uint32_t code, uint64_t off) {
+    uint32_t c[4] = {(uint32_t)(b + P.env_index_base), code, (uint32_t)off, (uint32_t)(off >> 32)};
     philox4x32(c, (uint32_t)P.seed, (uint32_t)(P.seed >> 32));
     return make_float2(u_pm1(c[0]), u_pm1(c[1]));
 }
-__device__ __forceinline__ float2 scn_fresh_obstacle(const FgParams& P, int b, int k, int M) {
-    const float2 r = scn_fresh_pm1(P, b, SCN_OBSTACLE_CODE | (uint32_t)k);
+__device__ __forceinline__ float2 scn_fresh_obstacle(const FgParams& P, int b, int k, int M, uint64_t off) {
+    const float2 r = scn_fresh_pm1(P, b, SCN_OBSTACLE_CODE | (uint32_t)k, off);
     const float lo = -1.8f + 3.6f * (float)k / (float)M, hi = -1.8f + 3.6f * (float)(k + 1) / (float)M;
     return make_float2(lo + (hi - lo) * (0.5f * r.x + 0.5f), 2.0f + 0.5f * (0.5f * r.y + 0.5f));
 }
@@ -232,16 +234,17 @@ __global__ __launch_bounds__(256) void scn_reset_kernel(const FgParams P, const 
     if (t >= (long long)B * per) return;
     const int b = (int)(t / per), r = (int)(t - (long long)b * per);
     if (mask && !mask[b]) return;
+    const uint64_t off = rng_base(P);
     if (r < N) {
-        const float2 q = scn_fresh_pm1(P, b, (uint32_t)r);
+        const float2 q = scn_fresh_pm1(P, b, (uint32_t)r, off);
         const size_t o = (size_t)b * N + r;
         px[o] = q.x; py[o] = q.y; vx[o] = 0.f; vy[o] = 0.f;
         if (r == 0 && step) step[b] = 0;
     } else if (r < N + L) {
-        lm[(size_t)b * L + (r - N)] = scn_fresh_pm1(P, b, SCN_LANDMARK_CODE | (uint32_t)(r - N));
+        lm[(size_t)b * L + (r - N)] = scn_fresh_pm1(P, b, SCN_LANDMARK_CODE | (uint32_t)(r - N), off);
     } else {
         const int k = r - N - L;
-        opos[(size_t)b * M + k] = scn_fresh_obstacle(P, b, k, M);
+        opos[(size_t)b * M + k] = scn_fresh_obstacle(P, b, k, M, off);
         ovel[(size_t)b * M + k] = make_float2(sc.obstacle_vx, sc.obstacle_vy);
     }
 }
@@ -279,6 +282,12 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     int t_step = (live && a.step) ? a.step[b] : 0;
     __syncthreads();
     const float my_size = 0.5f * (i < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+    const int KS = a.K > 1 ? a.K : 1;
+    // K steps in one launch (fg_rollout_scenario): the state stays in registers / LDS, every step's reward, done and (every
+    // obs_every-th) observation go to their slab - the same arithmetic as K single-step launches, bit for bit
+    for (int ks = 0; ks < KS; ++ks) {
+    const uint64_t off = rng_base(a.p) + (uint64_t)ks;
+    const size_t kb = (size_t)ks * a.B;                 // slab of step ks in the [K][B]... outputs
     if (a.do_phys) {
         if (is_agent || is_obst) {
             // World.step: all pairs of movable colliders, contact distance size_i + size_j
@@ -299,8 +308,8 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                 }
             }
             if (is_agent) {
-                const float2 u = reinterpret_cast<const float2*>(a.act)[sidx];
-                const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p));   // uniform agents (no per-agent table in these scenarios)
+                const float2 u = reinterpret_cast<const float2*>(a.act)[kb * N + sidx];
+                const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, off);   // uniform agents (no per-agent table in these scenarios)
                 fx += fa.x; fy += fa.y;
             }
             if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
@@ -314,9 +323,9 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             } else {
                 // the reward callback re-arms the obstacle velocity every step (:84-89)
                 const bool falling = p.y > a.sc.obstacle_floor;
+                v = make_float2(falling ? a.sc.obstacle_vx : 0.f, falling ? a.sc.obstacle_vy : 0.f);   // what the next step loads
                 reinterpret_cast<float2*>(a.opos)[oidx] = p;
-                reinterpret_cast<float2*>(a.ovel)[oidx] =
-                    make_float2(falling ? a.sc.obstacle_vx : 0.f, falling ? a.sc.obstacle_vy : 0.f);
+                reinterpret_cast<float2*>(a.ovel)[oidx] = v;
             }
         }
         t_step += 1;
@@ -337,7 +346,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                     if (d2 < best) { best = d2; barg = j; }
                 }
                 cover += sqrtf(best);
-                if (a.near_ag) a.near_ag[(size_t)b * L + l] = barg;
+                if (a.near_ag) a.near_ag[(kb + b) * L + l] = barg;
             }
         }
         float red[1] = {cover};
@@ -390,9 +399,9 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     const int nbr = (kind == FG_SCN_PARTIAL) ? a.sc.num_obs : (N - 1);
     const int D = 2 + (kind == FG_SCN_BASIC ? 2 : 0) + 2 * L + 2 * M + 2 * nbr + 2 * (N - 1);
     if (is_agent) {
-        if (a.rew) a.rew[sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
-        if (a.indiv) a.indiv[sidx] = -form - a.sc.penalty * (float)cnt;
-        if (a.done) a.done[sidx] = is_done ? 1 : 0;
+        if (a.rew) a.rew[kb * N + sidx] = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)cs[0]);
+        if (a.indiv) a.indiv[kb * N + sidx] = -form - a.sc.penalty * (float)cnt;
+        if (a.done) a.done[kb * N + sidx] = is_done ? 1 : 0;
     }
     if (a.p.auto_reset && a.do_phys) {                  // uniform over the launch
         // the vec-env worker's rule (env_wrappers.py:14-18): an env whose episode is over restarts at once, and the
@@ -400,17 +409,18 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         __syncthreads();                                // every lane has finished reading POST / LM of the finished step
         if (live && is_done) {
             if (is_agent) {
-                p = scn_fresh_pm1(a.p, b, (uint32_t)i); v = make_float2(0.f, 0.f);
+                p = scn_fresh_pm1(a.p, b, (uint32_t)i, off); v = make_float2(0.f, 0.f);
                 POST[i] = p;
                 a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = 0.f; a.vy[sidx] = 0.f;
             } else if (is_obst) {
-                p = scn_fresh_obstacle(a.p, b, i - N, M);
+                p = scn_fresh_obstacle(a.p, b, i - N, M, off);
+                v = make_float2(a.sc.obstacle_vx, a.sc.obstacle_vy);
                 POST[i] = p;
                 reinterpret_cast<float2*>(a.opos)[oidx] = p;
-                reinterpret_cast<float2*>(a.ovel)[oidx] = make_float2(a.sc.obstacle_vx, a.sc.obstacle_vy);
+                reinterpret_cast<float2*>(a.ovel)[oidx] = v;
             }
             for (int l = i; l < L; l += G) {
-                const float2 m = scn_fresh_pm1(a.p, b, SCN_LANDMARK_CODE | (uint32_t)l);
+                const float2 m = scn_fresh_pm1(a.p, b, SCN_LANDMARK_CODE | (uint32_t)l, off);
                 LM[l] = m;
                 reinterpret_cast<float2*>(a.lm)[(size_t)b * L + l] = m;
             }
@@ -418,12 +428,14 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         }
         __syncthreads();
     }
-    if (is_agent) {
+    const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;
+    const size_t ob = (size_t)(a.obs_every > 1 ? ks / a.obs_every : ks) * a.B;   // slab of this step's observation
+    if (is_agent && want_obs) {
         // every lane composes its own row: straight to global memory (rows D floats apart: one 8-byte piece per lane
         // and instruction), or into the workgroup's LDS image of its [E][N][D] block, which all lanes then copy out
         // with consecutive 8-byte stores (a.stage; 16 x 65536 obstacle envs: 203 -> see profiles/r02_aux_kernels.md)
         float2* const stage0 = tables + E * (2 * NE + L);                              // behind the last env's tables
-        float2* o = a.stage ? stage0 + (size_t)(e * N + i) * (D / 2) : reinterpret_cast<float2*>(a.obs + sidx * D);
+        float2* o = a.stage ? stage0 + (size_t)(e * N + i) * (D / 2) : reinterpret_cast<float2*>(a.obs + (ob * N + sidx) * D);
         int w = 0;
         o[w++] = v;
         if (kind == FG_SCN_BASIC) o[w++] = p;
@@ -446,15 +458,21 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         }
         for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
     }
-    if (a.stage) {
+    if (a.stage && want_obs) {                          // want_obs is uniform over the launch
         __syncthreads();
         const float2* const img = tables + E * (2 * NE + L);
         const int b0 = blockIdx.x * E;
         const int El = min(E, a.B - b0);
         const int units = El * N * (D / 2);
-        float2* const out = reinterpret_cast<float2*>(a.obs + (size_t)b0 * N * D);
+        float2* const out = reinterpret_cast<float2*>(a.obs + (ob + (size_t)b0) * N * D);
         for (int q = tid; q < units; q += T) out[q] = img[q];
     }
+    if (ks + 1 < KS) {                                  // the next step starts from this one's end state
+        __syncthreads();                                // POST read by everyone, the staged image copied out
+        if (is_agent || is_obst) PRE[i] = p;
+        __syncthreads();
+    }
+    }   // steps
     if (a.do_phys && a.step && live && i == 0) a.step[b] = t_step;
 }
 

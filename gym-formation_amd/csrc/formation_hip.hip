@@ -701,11 +701,14 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
                            float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                            const float* act, float* landmarks, float* obst_pos, float* obst_vel,
                            int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
-                           int32_t* near_ag, void* stream) {
+                           int32_t* near_ag, void* stream, int K = 1, int obs_every = 1) {
     const DeviceGuard device_guard(stream, pos_x);
     int rc = check_params(params);
     if (rc) return rc;
     if (!sc) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
+    if (K == 0) return FG_OK;
+    if (K < 0 || obs_every < 1) return fail(FG_ERR_BAD_ARG, "K >= 0 and obs_every >= 1 required%s");
+    if (K > 1 && !do_physics) return fail(FG_ERR_BAD_ARG, "a multi-step launch steps the physics%s");
     if (params->agent_props || params->comm_state)
         return fail(FG_ERR_BAD_ARG, "agent_props / comm_state are honoured by the formation_hd_env entry points only%s");
     const int L = sc->num_landmarks, M = sc->num_obstacles;
@@ -722,12 +725,15 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         ((uintptr_t)obst_pos & 7u) || ((uintptr_t)obst_vel & 7u))
         return fail(FG_ERR_ALIGNMENT, "obs/landmarks/act/obstacle buffers must be 8-byte aligned%s");
     ScnArgs a; memset(&a, 0, sizeof(a));
-    a.p = *params; a.sc = *sc; a.B = B; a.N = N; a.do_phys = do_physics ? 1 : 0;
+    a.p = *params; a.sc = *sc; a.B = B; a.N = N; a.do_phys = do_physics ? 1 : 0; a.K = K; a.obs_every = obs_every;
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act; a.lm = landmarks;
     a.opos = obst_pos; a.ovel = obst_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
+#ifndef FG_SCN_T
+#define FG_SCN_T 64           // threads per workgroup of the scenario kernel up to 64 entities per env
+#endif
     const int G = pow2ceil(N + M) < 4 ? 4 : pow2ceil(N + M);
-    const int E = G <= 64 ? 64 / G : 1;               // more than 64 entities: one env per workgroup of G threads
+    const int E = G <= 64 ? FG_SCN_T / G : 1;         // more than 64 entities: one env per workgroup of G threads
     const int grid = (B + E - 1) / E;
     int lds = (E * (2 * (N + M) + L) + (G > 64 ? 32 : 0)) * (int)sizeof(float2);
     {   // observation rows composed in LDS and streamed out contiguously when the workgroup's block fits
@@ -738,11 +744,11 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         if (a.stage) lds += (int)stage;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (G == 4) hipLaunchKernelGGL((scn_kernel<4, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 32) hipLaunchKernelGGL((scn_kernel<32, 64>), dim3(grid), dim3(64), lds, st, a);
-    else if (G == 64) hipLaunchKernelGGL((scn_kernel<64, 64>), dim3(grid), dim3(64), lds, st, a);
+    if (G == 4) hipLaunchKernelGGL((scn_kernel<4, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
+    else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
+    else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
+    else if (G == 32) hipLaunchKernelGGL((scn_kernel<32, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
+    else if (G == 64) hipLaunchKernelGGL((scn_kernel<64, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
     else if (G == 128) hipLaunchKernelGGL((scn_kernel<128, 128>), dim3(grid), dim3(128), lds, st, a);
     else if (G == 256) hipLaunchKernelGGL((scn_kernel<256, 256>), dim3(grid), dim3(256), lds, st, a);
     else if (G == 512) hipLaunchKernelGGL((scn_kernel<512, 512>), dim3(grid), dim3(512), lds, st, a);
@@ -828,6 +834,16 @@ int fg_step_basic(const FgParams* params, int B, int N, int L, int do_physics,
     sc.kind = FG_SCN_BASIC; sc.num_landmarks = L; sc.penalty = 1.0f;
     return launch_scenario(params, &sc, B, N, do_physics, pos_x, pos_y, vel_x, vel_y, act, landmarks,
                            nullptr, nullptr, step, obs, reward, indiv_reward, done, near_ag, stream);
+}
+
+int fg_rollout_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int K,
+                        float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                        const float* act_seq, float* landmarks, float* obst_pos, float* obst_vel,
+                        int32_t* step, float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                        int32_t* near_ag_seq, int obs_every, void* stream) {
+    return launch_scenario(params, scenario, B, N, 1, pos_x, pos_y, vel_x, vel_y, act_seq, landmarks,
+                           obst_pos, obst_vel, step, obs_seq, reward_seq, indiv_seq, done_seq, near_ag_seq, stream,
+                           K, obs_every < 1 ? 1 : obs_every);
 }
 
 int fg_reset_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, const uint8_t* mask,

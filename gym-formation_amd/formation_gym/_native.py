@@ -114,6 +114,7 @@ SIGNATURES = {
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_reset_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I] + [_P] * 10),
+    "fg_rollout_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14 + [_I, _P]),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
     "fg_update_comm": (_I, [_PP, _I, _I, _P, _P, _P]),
     "fg_policy_bfs": (_I, [_I, _I, _I, _P, ctypes.c_int64, _P, _P]),

@@ -160,6 +160,39 @@ class LandmarkScenario(BaseScenario):
         back with the finished step's reward / done: the vec-env worker's rule, env_wrappers.py:14-18)."""
         self._launch(world, act, out, True, rng_offset, auto_reset)
 
+    def _rollout_args(self, world, act_seq, out, obs_every):
+        M = self.num_obstacles
+        if out.get("obs") is not None and not out["obs"].is_contiguous():
+            raise ValueError("the landmark scenarios write contiguous observation buffers")
+        return (world.num_envs, len(world.agents), int(act_seq.shape[0]),
+                world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
+                act_seq.data_ptr(), world.landmark_pos.data_ptr(),
+                world.obstacle_pos.data_ptr() if M else None, world.obstacle_vel.data_ptr() if M else None,
+                world.step_count.data_ptr(),
+                out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
+                _native.ptr(out.get("done")), None, int(obs_every), _native.current_stream(world.device))
+
+    def rollout_batch(self, world, act_seq, out, obs_every=1, auto_reset=False, rng_offset=0):
+        """K steps in one launch (`fg_rollout_scenario`); act_seq [K,B,N,2], out tensors carry a leading K."""
+        _native.check(_native.load().fg_rollout_scenario(self.params(world, rng_offset, auto_reset), self.descriptor(),
+                                                         *self._rollout_args(world, act_seq, out, obs_every)))
+        self._cache = None
+
+    def bind_rollout(self, world, act_seq, out, obs_every=1, auto_reset=False):
+        """`rollout_batch` with the structs and every pointer resolved once: returns `launch(rng_offset)`."""
+        fn = _native.load().fg_rollout_scenario
+        p, d = self.params(world, auto_reset=auto_reset), self.descriptor()
+        args = self._rollout_args(world, act_seq, out, obs_every)
+        keep = (act_seq, out)
+
+        def launch(rng_offset=0):
+            p.rng_offset = rng_offset
+            rc = fn(p, d, *args)
+            if rc:
+                _native.check(rc)
+            return keep
+        return launch
+
     def reset_device(self, world, mask=None, rng_offset=0):
         """Throughput-mode reset on the GPU (counter RNG, distributional parity only): the draws the fused auto-reset makes."""
         M = self.num_obstacles

@@ -305,6 +305,17 @@ int fg_step_scenario(const FgParams* params, const FgScenario* scenario, int B, 
                      int32_t* step, float* obs, float* reward, float* indiv_reward, uint8_t* done,
                      void* stream);
 
+/* K consecutive fg_step_scenario calls in ONE launch (the landmark scenarios' counterpart of fg_rollout_hd; basic_formation_env
+ * with scenario->kind = FG_SCN_BASIC): the state stays on chip, results are bit-identical to K single-step launches with
+ * rng_offset, rng_offset + 1, ... (params->auto_reset included).  act_seq float [K][B][N][2]; reward_seq, indiv_seq float
+ * [K][B][N]; done_seq uint8 [K][B][N]; near_ag_seq int32 [K][B][L] (basic only, may be NULL); obs_seq float
+ * [K / obs_every][B][N][D] (steps k with (k+1) % obs_every == 0).  K = 0 is a no-op. */
+int fg_rollout_scenario(const FgParams* params, const FgScenario* scenario, int B, int N, int K,
+                        float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                        const float* act_seq, float* landmarks, float* obst_pos, float* obst_vel,
+                        int32_t* step, float* obs_seq, float* reward_seq, float* indiv_seq, uint8_t* done_seq,
+                        int32_t* near_ag_seq, int obs_every, void* stream);
+
 /* Scenario.reset_world of the landmark scenarios on device for the envs whose mask byte is non-zero (mask NULL = all),
  * counter-based RNG (basic_formation_env.py:54-65, formation_hd_partial_env.py:88-99, formation_hd_partial_range_env.py:76-87,
  * formation_hd_obs_env.py:101-114 draw distribution): agent and landmark positions ~ U(-1,1)^2, velocities 0, obstacle k

@@ -117,6 +117,9 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_step_scenario(P, sc, 4, 1022, 1, *([p] * 14)) == _native.FG_ERR_UNSUPPORTED_N   # N + M > 1024
     assert lib.fg_step_scenario(P, _native.FgScenario(kind=9, num_landmarks=4), 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_step_scenario(P, None, 4, 4, 1, *([p] * 14)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_rollout_scenario(P, sc, 4, 4, 0, *([None] * 14), 1, None) == _native.FG_OK     # K = 0: no-op
+    assert lib.fg_rollout_scenario(P, sc, 4, 4, -2, *([p] * 14), 1, None) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_rollout_scenario(P, sc, 4, 1022, 3, *([p] * 14), 1, None) == _native.FG_ERR_UNSUPPORTED_N
     assert lib.fg_reset_scenario(P, sc, 0, 4, *([None] * 10)) == _native.FG_OK          # empty batch
     assert lib.fg_reset_scenario(P, None, 4, 4, *([p] * 10)) == _native.FG_ERR_BAD_ARG
     assert lib.fg_reset_scenario(P, sc, 4, 1022, *([p] * 10)) == _native.FG_ERR_UNSUPPORTED_N

@@ -155,3 +155,43 @@ def test_vec_env_device_mode_runs_episodes_of_the_landmark_scenarios(scenario, k
             env.scenario.observe_batch(env.world, want)
             assert torch.equal(obs, want["obs"])                        # the RESET observation
     assert len(starts) == 3 and starts[1].ne(starts[2]).any()
+
+
+@pytest.mark.parametrize("scenario,kind,N", SCENARIOS)
+@pytest.mark.parametrize("obs_every", [1, 3])
+def test_scenario_rollout_equals_step_calls(scenario, kind, N, obs_every):
+    """env.rollout on the landmark scenarios (`fg_rollout_scenario`: K steps in one launch, state on chip) == K calls of
+    step, bit for bit - physics with obstacle contacts, rewards, dones, the device auto-resets in the middle of the
+    launch, every obs_every-th observation; through internally allocated and through caller-owned (bound) buffers."""
+    B = 45 if N < 64 else 7
+    K = 9
+    a, b = _pair(scenario, N, B, seed=8)
+    W = int(a.world.world_length)
+    step0 = ((torch.arange(B, device="cuda") * 5) % W).to(torch.int32)        # episodes end at different steps of the launch
+    for e in (a, b):
+        e.auto_reset = True
+        e.world.step_count.copy_(step0)
+        if kind == "obstacle":                                                # agents under the falling obstacles: contacts
+            e.world.pos_y.add_(1.6)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(N + obs_every)
+    out = None
+    for rnd in range(3):
+        acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+        if rnd == 1:                                                          # caller-owned buffers from here on
+            D = b._out["obs"].shape[-1]
+            f = dict(dtype=torch.float32, device="cuda")
+            out = dict(obs=torch.empty((K // obs_every, B, N, D), **f), reward=torch.empty((K, B, N), **f),
+                       indiv=torch.empty((K, B, N), **f), done=torch.zeros((K, B, N), dtype=torch.uint8, device="cuda"))
+        obs, rew, done, info = b.rollout(acts, out=out, obs_every=obs_every)
+        assert obs.shape[0] == K // obs_every
+        for k in range(K):
+            o, r, d, i = a.step(acts[k])
+            assert torch.equal(r, rew[k]) and torch.equal(d, done[k]), (rnd, k)
+            assert torch.equal(i["individual_reward"], info["individual_reward"][k])
+            if (k + 1) % obs_every == 0:
+                assert torch.equal(o, obs[k // obs_every]), "observations differ at step %d of launch %d" % (k, rnd)
+        for x, y in zip(_state(a), _state(b)):
+            assert torch.equal(x, y)
+    assert bool(done.any()) or W > 3 * K                                      # resets happened inside the launches
+    if kind == "obstacle" and N < 64:
+        assert float(info["individual_reward"].min()) <= -2.0                 # a collision penalty was paid: contacts were real
