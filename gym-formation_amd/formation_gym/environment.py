@@ -286,7 +286,9 @@ class MultiAgentEnv(object):
     def _snapshot(self):
         """Everything a launch mutates (device state + host counters), for probes that must leave the env untouched."""
         w, sc = self.world, self.scenario
-        dev = {k: getattr(w, k).clone() for k in ("pos_x", "pos_y", "vel_x", "vel_y", "step_count")}
+        dev = {k: getattr(w, k).clone() for k in ("pos_x", "pos_y", "vel_x", "vel_y", "step_count", "landmark_pos",
+                                                  "obstacle_pos", "obstacle_vel")     # obstacles move; resets re-draw landmarks
+               if torch.is_tensor(getattr(w, k, None))}
         scn = {k: getattr(sc, k).clone() for k in ("ideal_shape", "ideal_vel") if torch.is_tensor(getattr(sc, k, None))}
         ctr = None if w.rng_counter is None else w.rng_counter.clone()
         return dev, scn, ctr, (self._rng_offset, self.current_step, w.world_step)

@@ -195,3 +195,48 @@ def test_scenario_rollout_equals_step_calls(scenario, kind, N, obs_every):
     assert bool(done.any()) or W > 3 * K                                      # resets happened inside the launches
     if kind == "obstacle" and N < 64:
         assert float(info["individual_reward"].min()) <= -2.0                 # a collision penalty was paid: contacts were real
+
+
+@pytest.mark.parametrize("scenario,kind,N", [SCENARIOS[1], SCENARIOS[3]])
+def test_captured_loop_of_a_landmark_scenario_equals_the_step_loop(scenario, kind, N):
+    """FormationVecEnv.capture on a landmark scenario: replays of the captured T-step loop (policy + step with device
+    auto-resets, obstacles moving) == the same loop launch by launch, and capturing leaves the env untouched
+    (landmarks and obstacles included)."""
+    import formation_gym
+    from formation_gym.vec_env import FormationVecEnv
+    B, T, R = 48, 4, 3
+    dev = "cuda:0"
+
+    def fresh():
+        env = formation_gym.make_env(scenario, False, N, num_envs=B, device=dev)
+        env.seed(6)
+        v = FormationVecEnv(env, reset_mode="device")
+        v.reset()
+        env.world.world_length = 5                              # short episodes: resets inside every replay
+        env.world.step_count.copy_(torch.arange(B, dtype=torch.int32, device=dev) % 5)
+        return v
+
+    D = fresh().env._out["obs"].shape[-1]
+    gen = torch.Generator(device=dev); gen.manual_seed(N)
+    Wp = (torch.rand((D, 2), generator=gen, device=dev) - 0.5) * 0.3
+    fn = lambda obs: torch.tanh(obs @ Wp)
+    ref = fresh()
+    obs = ref.env._out["obs"]
+    want = {k: [] for k in ("obs", "rew", "done")}
+    for t in range(T * R):
+        obs, rew, done, info = ref.step(fn(obs).contiguous())
+        want["obs"].append(obs.clone()); want["rew"].append(rew.clone()); want["done"].append(done.clone())
+    v = fresh()
+    before = [x.clone() for x in _state(v.env)]
+    loop = v.capture(fn, T)
+    for x, y in zip(before, _state(v.env)):
+        assert torch.equal(x, y)
+    for r in range(R):
+        o, rw, d, info = loop.replay()
+        torch.cuda.synchronize()
+        for t in range(T):
+            k = r * T + t
+            assert torch.equal(o[t], want["obs"][k]) and torch.equal(rw[t], want["rew"][k]) and torch.equal(d[t], want["done"][k]), (r, t)
+    for x, y in zip(_state(ref.env), _state(v.env)):
+        assert torch.equal(x, y)
+    assert any(bool(x.any()) for x in want["done"])
