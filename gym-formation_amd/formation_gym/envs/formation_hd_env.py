@@ -96,7 +96,7 @@ class Scenario(BaseScenario):
         if ideal_shape is not None:
             self.ideal_shape.copy_(torch.as_tensor(np.array(ideal_shape), dtype=torch.float32))
         if ideal_vel is not None:
-            self.ideal_vel.copy_(torch.as_tensor(np.asarray(ideal_vel), dtype=torch.float32))
+            self.ideal_vel.copy_(torch.as_tensor(np.array(ideal_vel), dtype=torch.float32))
         self._cache = None
 
     # ---- batched protocol ----------------------------------------------------
