@@ -150,6 +150,24 @@ class Arena(object):
             pass
 
 
+def arena_geometry(nbytes, free_bytes, mem_fraction=0.7, max_arena_bytes=192 << 30):
+    """(arena bytes, chunk bytes) for a buffer of `nbytes` on a device with `free_bytes` free, or None when there is no
+    room to choose from.  8 ... 16 chunks per buffer, 32 MiB ... 1 GiB each (the chunk size itself does not matter:
+    profiles/r03_place/spread_*); the arena takes `mem_fraction` of the free memory (a buffer larger than half of that:
+    1.5 x the buffer, at most 0.9 of the free memory); at most ~2000 chunks per arena (driver calls, page tables)."""
+    chunk = 32 << 20
+    while chunk < (1 << 30) and nbytes // chunk > 16:
+        chunk <<= 1
+    total = int(min(max_arena_bytes, mem_fraction * free_bytes))
+    if total < 2 * nbytes:
+        total = int(min(0.9 * free_bytes, 1.5 * nbytes))          # a huge buffer: at least some room to shuffle in
+    while chunk < (1 << 30) and total // chunk > 2048:
+        chunk <<= 1
+    if total < nbytes + 2 * chunk:
+        return None
+    return total, chunk
+
+
 def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_bytes=192 << 30, reps=3,
                 min_bytes=MIN_PROBE_BYTES, seed=0, budget_s=1.0):
     """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor lives in the arena, which the caller keeps
@@ -172,16 +190,10 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     if device.type != "cuda" or nbytes < min_bytes:
         return None
     free = torch.cuda.mem_get_info(device)[0]
-    chunk = 32 << 20
-    while chunk < (1 << 30) and nbytes // chunk > 16:            # 8 ... 16 chunks per buffer, 32 MiB ... 1 GiB each (the chunk
-        chunk <<= 1                                              # size itself does not matter: profiles/r03_place/spread_*)
-    total = int(min(max_arena_bytes, mem_fraction * free))
-    if total < 2 * nbytes:
-        total = int(min(0.9 * free, 1.5 * nbytes))                # a huge buffer: at least some room to shuffle in
-    while chunk < (1 << 30) and total // chunk > 2048:           # at most ~2000 chunks per arena (driver calls, page tables)
-        chunk <<= 1
-    if total < nbytes + 2 * chunk:
+    geometry = arena_geometry(nbytes, free, mem_fraction, max_arena_bytes)
+    if geometry is None:
         return None
+    total, chunk = geometry
     try:
         arena = Arena(total, device, chunk)
     except _native.FormationHipError:

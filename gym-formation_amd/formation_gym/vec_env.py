@@ -19,6 +19,10 @@ class FormationVecEnv(object):
           'host'      the reference's streams on the host (bit-exact; needs a device->host sync)"""
         if reset_mode not in ("device", "device_mt", "host"):
             raise ValueError("reset_mode must be 'device', 'device_mt' or 'host'")
+        if reset_mode == "device_mt" and not hasattr(env.scenario, "bind_reset_mt_done"):
+            raise NotImplementedError("reset_mode='device_mt' (the legacy MT19937 streams continued on the GPU) is built for "
+                                      "formation_hd_env; %s resets with 'device' (counter RNG) or 'host' (bit-exact)"
+                                      % type(env.scenario).__module__.rsplit(".", 1)[-1])
         self.env = env
         self.reset_mode = reset_mode
         self.num_envs = env.num_envs
