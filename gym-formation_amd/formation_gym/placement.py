@@ -198,72 +198,80 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
         arena = Arena(total, device, chunk)
     except _native.FormationHipError:
         return None
-    chunk, n = arena.chunk, arena.chunks
-    W = -(-nbytes // chunk)                                      # chunks per buffer
-    stream = torch.cuda.current_stream(device)
-    rnd = random.Random(seed)
 
-    def timed(idx, r, placed):                                   # map, time, unmap: one candidate at a time
-        addr = arena.map(idx)
-        arena.kept_range = (addr, addr + W * chunk) if placed else (0, 0)   # a spread candidate is timed as what it will be
-        try:
-            return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
-        finally:
-            stream.synchronize()
-            arena.kept_range = (0, 0)
-            arena.unmap(addr)
+    def probe():
+        chunk, n = arena.chunk, arena.chunks
+        W = -(-nbytes // chunk)                                      # chunks per buffer
+        stream = torch.cuda.current_stream(device)
+        rnd = random.Random(seed)
 
-    def spread_selection(t):
-        idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
-        while len(idx) < W:                                       # strata narrower than a chunk can collide
-            c = rnd.randrange(n)
-            if c not in idx:
-                idx.append(c)
-        idx.sort()
-        if t % 2 == 0:
-            rnd.shuffle(idx)                                      # strata in random order
-            return "spread, shuffled", idx
-        # strata in a golden-ratio stride order: consecutive chunks of the buffer (the slabs of consecutive steps) always
-        # come from far-apart parts of the arena, and so do chunks two and three apart
-        g = max(1, int(round(W * 0.6180339887)))
-        while math.gcd(g, W) != 1:
-            g += 1
-        off = rnd.randrange(W)
-        return "spread, golden stride", [idx[(off + k * g) % W] for k in range(W)]
+        def timed(idx, r, placed):                                   # map, time, unmap: one candidate at a time
+            addr = arena.map(idx)
+            arena.kept_range = (addr, addr + W * chunk) if placed else (0, 0)   # a spread candidate is timed as what it will be
+            try:
+                return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
+            finally:
+                stream.synchronize()
+                arena.kept_range = (0, 0)
+                arena.unmap(addr)
 
-    first = list(range(W))
-    t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
-    addr = arena.map(first)                                      # probe measured 5-8 % slow
-    while time.perf_counter() - t_warm < 0.05:
-        _time_launch(time_fn, arena.floats(addr, nfloats), stream, 2)
-    stream.synchronize()
-    arena.unmap(addr)
-    cands = [("as created", first)]
-    ms = [timed(first, reps, False)]
-    # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
-    # and its selections differ by 1 %)
-    count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps + 1) * ms[0] * 1e-3 + 4e-3))))
-    for t in range(count):
-        kind, idx = spread_selection(t)
-        cands.append((kind, idx))
-        ms.append(timed(idx, reps, True))
-    finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
-    final = {i: timed(cands[i][1], 2 * reps + 1, i > 0) for i in finalists}
-    for i, v in final.items():
-        ms[i] = v
-    best = min(final, key=final.get)
-    addr = arena.map(cands[best][1])                             # the winner, for good ...
-    arena.trim()                                                 # ... and every other chunk back to the driver
-    if best > 0:
-        arena.kept_range = (addr, addr + W * chunk)
-    flat = arena.floats(addr, nfloats)
-    spread = sorted(ms[1:])
-    report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
-              "arena_GB": round(n * chunk / 1e9, 1), "free_GB_before": round(free / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
-              "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
-              "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
-              "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
-              "probe_seconds": round(time.perf_counter() - t_start, 2),
-              # address ranges that held a candidate are retired, never reused (stale translations: include/formation_hip.h)
-              "retired_address_space_GB": round(_native.load().fg_arena_retired_address_bytes() / 1e9, 1)}
-    return flat, report, arena
+        def spread_selection(t):
+            idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
+            while len(idx) < W:                                       # strata narrower than a chunk can collide
+                c = rnd.randrange(n)
+                if c not in idx:
+                    idx.append(c)
+            idx.sort()
+            if t % 2 == 0:
+                rnd.shuffle(idx)                                      # strata in random order
+                return "spread, shuffled", idx
+            # strata in a golden-ratio stride order: consecutive chunks of the buffer (the slabs of consecutive steps) always
+            # come from far-apart parts of the arena, and so do chunks two and three apart
+            g = max(1, int(round(W * 0.6180339887)))
+            while math.gcd(g, W) != 1:
+                g += 1
+            off = rnd.randrange(W)
+            return "spread, golden stride", [idx[(off + k * g) % W] for k in range(W)]
+
+        first = list(range(W))
+        t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
+        addr = arena.map(first)                                      # probe measured 5-8 % slow
+        while time.perf_counter() - t_warm < 0.05:
+            _time_launch(time_fn, arena.floats(addr, nfloats), stream, 2)
+        stream.synchronize()
+        arena.unmap(addr)
+        cands = [("as created", first)]
+        ms = [timed(first, reps, False)]
+        # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
+        # and its selections differ by 1 %)
+        count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps + 1) * ms[0] * 1e-3 + 4e-3))))
+        for t in range(count):
+            kind, idx = spread_selection(t)
+            cands.append((kind, idx))
+            ms.append(timed(idx, reps, True))
+        finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
+        final = {i: timed(cands[i][1], 2 * reps + 1, i > 0) for i in finalists}
+        for i, v in final.items():
+            ms[i] = v
+        best = min(final, key=final.get)
+        addr = arena.map(cands[best][1])                             # the winner, for good ...
+        arena.trim()                                                 # ... and every other chunk back to the driver
+        if best > 0:
+            arena.kept_range = (addr, addr + W * chunk)
+        flat = arena.floats(addr, nfloats)
+        spread = sorted(ms[1:])
+        report = {"method": "arena: chunks spread over the device memory", "probed": True, "tried": len(ms),
+                  "arena_GB": round(n * chunk / 1e9, 1), "free_GB_before": round(free / 1e9, 1), "chunk_MiB": chunk >> 20, "buffer_chunks": W, "kept": cands[best][0],
+                  "kept_ms": round(ms[best], 4), "as_created_ms": round(ms[0], 4),
+                  "spread_ms_min_median_max": [round(spread[0], 4), round(spread[len(spread) // 2], 4), round(spread[-1], 4)] if spread else [],
+                  "worst_ms": round(max(ms), 4), "worst_over_kept": round(max(ms) / ms[best], 4),
+                  "probe_seconds": round(time.perf_counter() - t_start, 2),
+                  # address ranges that held a candidate are retired, never reused (stale translations: include/formation_hip.h)
+                  "retired_address_space_GB": round(_native.load().fg_arena_retired_address_bytes() / 1e9, 1)}
+        return flat, report, arena
+
+    try:
+        return probe()
+    except _native.FormationHipError:                            # a mapping could not be made (address space, driver): the
+        arena.close()                                            # caller falls back to whole allocations
+        return None

@@ -54,6 +54,6 @@ for item in sys.argv[1:]:
     gbs = (24 * N * N + 53 * N + 16) * B / us / 1e3
     pl = env.placement or {}
     print("%d x %d, %d steps per launch: %.2f us/step (min %.2f max %.2f)  %.0f GB/s  %.1f %%  probe %s%s" % (
-        N, B, K, us, blocks[0], blocks[-1], gbs, gbs / 80, pl.get("candidates_ms", pl.get("ms", [])), digest), flush=True)
+        N, B, K, us, blocks[0], blocks[-1], gbs, gbs / 80, pl.get("spread_ms_min_median_max", []), digest), flush=True)
     del env, out, acts
     torch.cuda.empty_cache()
