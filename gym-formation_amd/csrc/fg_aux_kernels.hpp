@@ -283,32 +283,46 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     __syncthreads();
     const float my_size = 0.5f * (i < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
     const int KS = a.K > 1 ? a.K : 1;
+    float2 u_next = make_float2(0.f, 0.f);              // the action of step ks + 1 is fetched while step ks runs
+    if (a.do_phys && is_agent) u_next = reinterpret_cast<const float2*>(a.act)[sidx];
     // K steps in one launch (fg_rollout_scenario): the state stays in registers / LDS, every step's reward, done and (every
     // obs_every-th) observation go to their slab - the same arithmetic as K single-step launches, bit for bit
     for (int ks = 0; ks < KS; ++ks) {
     const uint64_t off = rng_base(a.p) + (uint64_t)ks;
     const size_t kb = (size_t)ks * a.B;                 // slab of step ks in the [K][B]... outputs
+    const float2 u_now = u_next;
+    if (a.do_phys && is_agent && ks + 1 < KS) u_next = reinterpret_cast<const float2*>(a.act)[(kb + a.B) * N + sidx];
     if (a.do_phys) {
         if (is_agent || is_obst) {
             // World.step: all pairs of movable colliders, contact distance size_i + size_j
             float fx = 0.f, fy = 0.f;
             const float k = a.p.contact_margin;
-            for (int j = 0; j < NE; ++j) {
-                const float2 q = PRE[j];
-                const float dmin = my_size + 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
-                const float cut = dmin + 18.0f * k;
-                const float dx = p.x - q.x, dy = p.y - q.y;
-                const float d2 = dx * dx + dy * dy;
-                if (j != i && d2 < cut * cut) {
-                    const float d = __builtin_amdgcn_sqrtf(d2);
-                    const float x = (dmin - d) / k;
-                    const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
-                    const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
-                    fx += dx * c; fy += dy * c;
+            // (the loops of this kernel run over a handful of entities with run-time counts: four LDS reads are issued
+            // ahead of their use, index clamped, so that a wave waits once per four partners instead of once per partner;
+            // the order of the sums is the ascending-j order of core.py:240-262 either way)
+            for (int j0 = 0; j0 < NE; j0 += 4) {
+                float2 qq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qq[t] = PRE[min(j0 + t, NE - 1)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int j = j0 + t;
+                    const float2 q = qq[t];
+                    const float dmin = my_size + 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+                    const float cut = dmin + 18.0f * k;
+                    const float dx = p.x - q.x, dy = p.y - q.y;
+                    const float d2 = dx * dx + dy * dy;
+                    if (j < NE && j != i && d2 < cut * cut) {
+                        const float d = __builtin_amdgcn_sqrtf(d2);
+                        const float x = (dmin - d) / k;
+                        const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+                        const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                        fx += dx * c; fy += dy * c;
+                    }
                 }
             }
             if (is_agent) {
-                const float2 u = reinterpret_cast<const float2*>(a.act)[kb * N + sidx];
+                const float2 u = u_now;
                 const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, off);   // uniform agents (no per-agent table in these scenarios)
                 fx += fa.x; fy += fa.y;
             }
@@ -340,10 +354,15 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             if (live && l < L) {
                 const float2 m = LM[l];
                 float best = INFINITY; int barg = 0;
-                for (int j = 0; j < N; ++j) {
-                    const float2 q = POST[j];
-                    const float dx = q.x - m.x, dy = q.y - m.y, d2 = dx * dx + dy * dy;
-                    if (d2 < best) { best = d2; barg = j; }
+                for (int j0 = 0; j0 < N; j0 += 4) {
+                    float2 qq[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) qq[t] = POST[min(j0 + t, N - 1)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float dx = qq[t].x - m.x, dy = qq[t].y - m.y, d2 = dx * dx + dy * dy;
+                        if (j0 + t < N && d2 < best) { best = d2; barg = j0 + t; }
+                    }
                 }
                 cover += sqrtf(best);
                 if (a.near_ag) a.near_ag[(kb + b) * L + l] = barg;
@@ -361,16 +380,29 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         float rowmin = -INFINITY, colmax = -INFINITY;
         if (is_agent) {                                         // min over landmarks for my agent
             rowmin = INFINITY;
-            for (int l = 0; l < L; ++l) {
-                const float dx = (p.x - mx) - (LM[l].x - lx), dy = (p.y - my) - (LM[l].y - ly);
-                rowmin = fminf(rowmin, dx * dx + dy * dy);
+            for (int l0 = 0; l0 < L; l0 += 4) {
+                float2 mm[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mm[t] = LM[min(l0 + t, L - 1)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {                  // a clamped repeat of the last landmark does not change a minimum
+                    const float dx = (p.x - mx) - (mm[t].x - lx), dy = (p.y - my) - (mm[t].y - ly);
+                    rowmin = fminf(rowmin, dx * dx + dy * dy);
+                }
             }
         }
         for (int l = i; live && l < L; l += G) {                // min over agents for my landmark(s)
             float cm = INFINITY;
-            for (int j = 0; j < N; ++j) {
-                const float dx = (POST[j].x - mx) - (LM[l].x - lx), dy = (POST[j].y - my) - (LM[l].y - ly);
-                cm = fminf(cm, dx * dx + dy * dy);
+            const float2 ml = LM[l];
+            for (int j0 = 0; j0 < N; j0 += 4) {
+                float2 qq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) qq[t] = POST[min(j0 + t, N - 1)];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float dx = (qq[t].x - mx) - (ml.x - lx), dy = (qq[t].y - my) - (ml.y - ly);
+                    cm = fminf(cm, dx * dx + dy * dy);
+                }
             }
             colmax = fmaxf(colmax, cm);
         }
@@ -382,9 +414,16 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     int cnt = 0;
     if (is_agent) {
         const float thr = a.p.collide_thresh, thr2 = (float)((double)thr * (double)thr);
-        for (int j = 0; j < N; ++j) {
-            const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
-            cnt += ((kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < thr2) ? 1 : 0;
+        for (int j0 = 0; j0 < N; j0 += 4) {
+            float2 qq[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) qq[t] = POST[min(j0 + t, N - 1)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + t;
+                const float dx = qq[t].x - p.x, dy = qq[t].y - p.y;
+                cnt += (j < N && (kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < thr2) ? 1 : 0;
+            }
         }
         const float ot = 0.5f * a.p.dist_min + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
         for (int j = N; j < NE; ++j) {
@@ -439,22 +478,34 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         int w = 0;
         o[w++] = v;
         if (kind == FG_SCN_BASIC) o[w++] = p;
-        for (int l = 0; l < L; ++l) {
-            const float2 m = LM[l];
-            o[w++] = (kind == FG_SCN_BASIC) ? make_float2(m.x - p.x, m.y - p.y) : m;
-        }
-        for (int j = N; j < NE; ++j) { const float2 q = POST[j]; o[w++] = make_float2(q.x - p.x, q.y - p.y); }
-        if (kind == FG_SCN_PARTIAL) {
-            for (int kk = 0; kk < nbr; ++kk) {
-                const float2 q = POST[(i + 1 + kk) % N];
-                o[w++] = make_float2(q.x - p.x, q.y - p.y);
+        // a segment of `count` units, unit t = get(t): four sources are read before the four stores (the staged row lives in
+        // LDS like the tables, so a read behind a store would have to wait for it)
+        auto emit = [&](int count, auto&& get) {
+            for (int t0 = 0; t0 < count; t0 += 4) {
+                float2 r[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) r[t] = get(min(t0 + t, count - 1));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) if (t0 + t < count) o[w + t] = r[t];
+                w += min(4, count - t0);
             }
+        };
+        const bool basic = kind == FG_SCN_BASIC;
+        emit(L, [&](int l) { const float2 m = LM[l]; return basic ? make_float2(m.x - p.x, m.y - p.y) : m; });
+        emit(M, [&](int t) { const float2 q = POST[N + t]; return make_float2(q.x - p.x, q.y - p.y); });
+        if (kind == FG_SCN_PARTIAL) {
+            emit(nbr, [&](int kk) {
+                int j = i + 1 + kk;                            // (i + 1 + kk) mod N
+                while (j >= N) j -= N;
+                const float2 q = POST[j];
+                return make_float2(q.x - p.x, q.y - p.y);
+            });
         } else {
             const float r = (kind == FG_SCN_RANGE) ? a.sc.obs_range : INFINITY;
-            for (int j = 0; j < N; ++j) if (j != i) {
-                const float2 q = POST[j];
-                o[w++] = make_float2(fminf(fmaxf(q.x - p.x, -r), r), fminf(fmaxf(q.y - p.y, -r), r));
-            }
+            emit(N - 1, [&](int t) {
+                const float2 q = POST[t < i ? t : t + 1];     // the t-th OTHER agent, index order
+                return make_float2(fminf(fmaxf(q.x - p.x, -r), r), fminf(fmaxf(q.y - p.y, -r), r));
+            });
         }
         for (int j = 0; j < N - 1; ++j) o[w++] = make_float2(0.f, 0.f);
     }
@@ -465,7 +516,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         const int El = min(E, a.B - b0);
         const int units = El * N * (D / 2);
         float2* const out = reinterpret_cast<float2*>(a.obs + (ob + (size_t)b0) * N * D);
-        for (int q = tid; q < units; q += T) out[q] = img[q];
+        for (int q0 = tid; q0 < units; q0 += 4 * T) {
+            float2 r[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) r[t] = img[min(q0 + t * T, units - 1)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (q0 + t * T < units) out[q0 + t * T] = r[t];
+        }
     }
     if (ks + 1 < KS) {                                  // the next step starts from this one's end state
         __syncthreads();                                // POST read by everyone, the staged image copied out
