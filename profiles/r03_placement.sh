@@ -8,6 +8,7 @@ OUT=$R/gpurun_out/r03_placement
 rm -rf "$OUT"; mkdir -p "$OUT"
 for cfg in "243 8192 4 24" "81 2048 20 200" "27 4096 20 1000"; do
   set -- $cfg
+  if [ -n "${ONLY:-}" ] && [ "$1" != "$ONLY" ]; then continue; fi     # ONLY=27: one shape
   for i in $(seq 1 $RUNS); do
     for arm in 8 1; do
       timeout -k 10 200 python3 bench.py --agents $1 --envs $2 --chunk $3 --steps $4 --warmup $(($4 / 5)) --no-cpu-baseline --no-extra \
