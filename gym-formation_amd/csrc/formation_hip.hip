@@ -138,6 +138,9 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
 #ifndef FG_SPLIT_MAX_B
 #define FG_SPLIT_MAX_B 128         // split step (launch_step) up to this many envs
 #endif
+#ifndef FG_WIDE81_MIN_B
+#define FG_WIDE81_MIN_B 16384      // single-step launches at 81 agents take the pipelined kernel from this batch size up
+#endif
 #ifndef FG_WIDE243_MIN_B
 #define FG_WIDE243_MIN_B 4096      // single-step launches at 243 agents: below this the pipelined kernel's 4-env batches leave CUs
                                    // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
@@ -227,7 +230,7 @@ static int launch_wide_v(Args a, hipStream_t st) {
         // stream, few enough to keep every CU busy (one workgroup per CU; MI355X sweep, profiles/README.md)
         const int batches = (a.B + E - 1) / E;
 #ifdef FG_EXP_GROUP_DIV
-        a.groups = batches / (NC == 27 ? FG_EXP_GROUP_DIV : 256);
+        a.groups = batches / (NC <= 81 ? FG_EXP_GROUP_DIV : 256);
 #else
         a.groups = batches / 256;
 #endif
@@ -575,9 +578,12 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
     // 243 agents, >= 4096 envs: pipeline over env batches inside the launch (no index outputs, no World options):
-    // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192.  At 81 agents the plain kernel is as fast or faster
-    // (74 vs 80 us at 81 x 2048 on the same box, profiles/README.md).
+    // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192 (round 1; 1.75 ms on placed buffers).
     if (N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
+        return launch_wide(a, (hipStream_t)stream);
+    // 81 agents: the pipelined kernel pays from 16 env batches per workgroup on (81 x 16384: 419 vs 448 us; 81 x 12288 equal,
+    // 81 x 2048 62 vs 56: profiles/r03_step/pipelined_single_step_81.txt)
+    if (N == 81 && B >= FG_WIDE81_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
         return launch_wide(a, (hipStream_t)stream);
 #ifdef FG_EXP_STEP27_E
     if (N == 27 && B >= 2048 && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
@@ -657,7 +663,8 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
     // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
-    if (K == 1 && N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p)) return launch_wide(a, (hipStream_t)stream);   // as fg_step_hd
+    if (K == 1 && ((N == 243 && B >= FG_WIDE243_MIN_B) || (N == 81 && B >= FG_WIDE81_MIN_B)) && !world_options_set(a.p))
+        return launch_wide(a, (hipStream_t)stream);                                                  // as fg_step_hd
     if (K >= 2 && !world_options_set(a.p)) {
         if (N == 81 || N == 243) return launch_wide(a, (hipStream_t)stream);
         if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);

@@ -1100,7 +1100,7 @@ def test_action_modes_match_reference_fixtures(golden, name, mode):
             np.testing.assert_array_equal(_np(act)[0] * 5.0, g["acts_after"][t])   # one-hot written back
 
 
-@pytest.mark.parametrize("N,B", [(81, 2048), (243, 8192), (243, 4099)])     # 4099: the smallest batches of the pipelined single-step launch, ragged
+@pytest.mark.parametrize("N,B", [(81, 2048), (243, 8192), (243, 4099), (81, 16387)])     # 4099, 16387: the smallest batches of the pipelined single-step launch, ragged
 def test_baseline_full_size_per_gpu_properties(N, B):
     """BASELINE configs 3 and 4 at their per-GPU batch (81 x 2048, 243 x 8192): size-independent
     properties checked on the device for EVERY env, the fp64 oracle on a sample of envs, and the same
