@@ -240,3 +240,49 @@ def test_captured_loop_of_a_landmark_scenario_equals_the_step_loop(scenario, kin
     for x, y in zip(_state(ref.env), _state(v.env)):
         assert torch.equal(x, y)
     assert any(bool(x.any()) for x in want["done"])
+
+
+@pytest.mark.parametrize("scenario,kind,N", [SCENARIOS[0], SCENARIOS[3]])
+def test_scenario_rollout_with_world_options_equals_step_calls(scenario, kind, N):
+    """The World options of core.py (max_speed :271-276, accel :236, u_noise :232-233, walls :325-362) inside a K-step
+    launch of a landmark scenario: the motor noise of step k is keyed by the launch's offset + k, exactly what k step
+    calls use, so rollout == steps bit for bit, with auto-resets in the middle."""
+    from formation_gym.core import Wall
+    B, K = 33, 7
+    a, b = _pair(scenario, N, B, seed=12)
+    W = int(a.world.world_length)
+    for e in (a, b):
+        e.auto_reset = True
+        e.world.step_count.copy_(((torch.arange(B, device="cuda") * 3) % W).to(torch.int32))
+        for ag in e.world.agents:
+            ag.max_speed, ag.accel, ag.u_noise = 0.7, 3.5, 0.3
+        e.world.walls = [Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS]
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    for rnd in range(2):
+        acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+        obs, rew, done, info = b.rollout(acts)
+        for k in range(K):
+            o, r, d, i = a.step(acts[k])
+            assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k]), (rnd, k)
+        for x, y in zip(_state(a), _state(b)):
+            assert torch.equal(x, y)
+    speed = torch.stack((a.world.vel_x, a.world.vel_y), -1).norm(dim=-1)
+    assert float(speed.max()) <= 0.7 * (1 + 1e-5)
+    # the noise is there: the same actions from the same state without it end elsewhere
+    c, _ = _pair(scenario, N, B, seed=12)
+    c.world.step_count.copy_(((torch.arange(B, device="cuda") * 3) % W).to(torch.int32))
+    for ag in c.world.agents:
+        ag.max_speed, ag.accel = 0.7, 3.5
+    c.world.walls = [Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS]
+    c.auto_reset = True
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    c.rollout(acts)
+    d_, _ = _pair(scenario, N, B, seed=12)
+    d_.world.step_count.copy_(((torch.arange(B, device="cuda") * 3) % W).to(torch.int32))
+    for ag in d_.world.agents:
+        ag.max_speed, ag.accel, ag.u_noise = 0.7, 3.5, 0.3
+    d_.world.walls = [Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS]
+    d_.auto_reset = True
+    d_.rollout(acts)
+    assert c.world.pos_x.ne(d_.world.pos_x).any()
