@@ -286,3 +286,42 @@ def test_scenario_rollout_with_world_options_equals_step_calls(scenario, kind, N
     d_.auto_reset = True
     d_.rollout(acts)
     assert c.world.pos_x.ne(d_.world.pos_x).any()
+
+
+@pytest.mark.parametrize("scenario,kind,N", [SCENARIOS[1], SCENARIOS[3]])
+def test_scenario_shards_reproduce_the_global_batch_across_resets(scenario, kind, N):
+    """Three shards of a landmark-scenario batch (formation_gym/sharding.py: the env-batch cut a multi-GPU run makes),
+    stepped through an episode end with device auto-reset, equal the one-process batch bit for bit: the device draws
+    are keyed by the GLOBAL env index (FgParams.env_index_base), so results do not depend on the number of GPUs."""
+    from formation_gym import sharding
+    G, K = 50, 6
+    whole, lo, hi = sharding.make_env_shard(scenario, N, G, seed=4, rank=0, world_size=1, local_rank=0)
+    assert (lo, hi) == (0, G)
+    parts = [sharding.make_env_shard(scenario, N, G, seed=4, rank=r, world_size=3, local_rank=0) for r in range(3)]
+    W = int(whole.world.world_length)
+    step0 = ((torch.arange(G, device="cuda") * 7) % W).to(torch.int32)
+    envs = [(whole, 0, G)] + parts
+    for e, l, h in envs:
+        e.reset()
+        e.auto_reset = True
+        e.world.step_count.copy_(step0[l:h])
+    for e, l, h in parts:
+        for s, t in zip(_state(whole), _state(e)):
+            assert torch.equal(s[l:h], t)                      # same host reset streams
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    acts = (torch.rand((2 * K, G, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    saw_done = False
+    for k in range(K):                                         # step launches
+        o, r, d, i = whole.step(acts[k])
+        saw_done = saw_done or bool(d.any())
+        for e, l, h in parts:
+            o2, r2, d2, i2 = e.step(acts[k, l:h].contiguous())
+            assert torch.equal(o2, o[l:h]) and torch.equal(r2, r[l:h]) and torch.equal(d2, d[l:h]), (k, l)
+    obs, rew, done, info = whole.rollout(acts[K:])             # and one rollout launch
+    saw_done = saw_done or bool(done.any())
+    for e, l, h in parts:
+        obs2, rew2, done2, _ = e.rollout(acts[K:, l:h].contiguous())
+        assert torch.equal(obs2, obs[:, l:h]) and torch.equal(rew2, rew[:, l:h]) and torch.equal(done2, done[:, l:h])
+        for s, t in zip(_state(whole), _state(e)):
+            assert torch.equal(s[l:h], t)
+    assert saw_done
