@@ -244,6 +244,49 @@ def config1(dev):
                                      "each way per call, host resets (MT19937) every 50 steps; latency-bound by design"}}
 
 
+def other_scenarios(dev):
+    """The landmark scenarios at 65536 envs: 20-step rollout launches (`fg_rollout_scenario`) with device
+    auto-reset, us per env step and observation bytes written per second (their observations are 70-400 B per agent:
+    these kernels are instruction-bound, profiles/r03_scenario_rollout.md); reported beside the headline, never as `value`."""
+    import torch
+    import formation_gym
+    lines = []
+    K = 20
+    for scenario, n, b in (("basic_formation_env", 3, 65536), ("formation_hd_partial_env", 5, 65536),
+                           ("formation_hd_partial_range_env", 4, 65536), ("formation_hd_obs_env", 4, 65536)):
+        env = formation_gym.make_env(scenario, False, n, num_envs=b, device=dev)
+        env.seed(1)
+        env.scenario.reset_device(env.world, rng_offset=999)
+        env.auto_reset = True
+        d = env._out["obs"].shape[-1]
+        gen = torch.Generator(device=dev); gen.manual_seed(0)
+        acts = (torch.rand((K, b, n, 2), generator=gen, device=dev) * 2 - 1).contiguous()
+        f = dict(dtype=torch.float32, device=dev)
+        out = dict(obs=torch.empty((K, b, n, d), **f), reward=torch.empty((K, b, n), **f), indiv=torch.empty((K, b, n), **f),
+                   done=torch.zeros((K, b, n), dtype=torch.uint8, device=dev))
+        for _ in range(10):
+            env.rollout(acts, out=out)
+        torch.cuda.synchronize()
+        blocks = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                env.rollout(acts, out=out)
+            e1.record()
+            torch.cuda.synchronize()
+            blocks.append(e0.elapsed_time(e1) / 10 / K)
+        blocks.sort()
+        ms = blocks[len(blocks) // 2]
+        lines.append({"workload": "%s, %d agents x %d envs, %d steps per launch, device auto-reset" % (scenario, n, b, K),
+                      "ms_per_step": round(ms, 6), "env_steps_per_s": round(b / (ms * 1e-3), 1),
+                      "observation_GBps": round(b * n * d * 4 / (ms * 1e-3) / 1e9, 1),
+                      "state_finite": bool(torch.isfinite(env.world.pos_x).all())})
+        del env, out, acts
+        torch.cuda.empty_cache()
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -608,7 +651,7 @@ def main():
                  "note": "observation buffer resident in the Infinity Cache and overwritten every launch: cache-absorbed "
                          "stores, not an HBM-streaming figure"}
 
-    others, global_cfgs, closed_loop, c1 = [], [], None, None
+    others, global_cfgs, closed_loop, c1, scn_lines = [], [], None, None, None
     if not a.no_extra and not a.no_other_configs and (headline or a.global_div > 1):
         if world_size == 1 and headline:
             # the other BASELINE.json per-GPU shapes, short runs in the same process (reported beside the headline
@@ -667,6 +710,7 @@ def main():
             global_cfgs.append(line)
         if world_size == 1 and headline:
             c1 = config1(dev)
+            scn_lines = other_scenarios(dev)
 
     if rank == 0:
         blocks, walls = m["blocks"], m["wall_blocks"]
@@ -742,6 +786,8 @@ def main():
             res["global_configs"] = global_cfgs
         if c1:
             res["config1"] = c1
+        if scn_lines:
+            res["other_scenarios"] = scn_lines
         if world_size == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(N)
             if others:
