@@ -307,7 +307,8 @@ static int launch_roll(const Args& a, hipStream_t st) {
         // A buffer composed of chunks spread over the device's memory (FgParams.obs_placed) takes the stream of 8 paced
         // writer waves: 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384
         // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
-        // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation keeps 4: its controller tables do not fit beside 16 tiles.
+        // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation cannot hold 16 tiles beside its controller tables: it
+        // takes its 8 writer waves with the rows writer (below).
         if (!POLICY && a.p.obs_placed && hbm)
             return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
 #if FG_R27_POLICY_ROWS512
