@@ -722,3 +722,26 @@ def test_arena_mappings_get_fresh_addresses_and_chunks_keep_their_contents():
     del t
     arena.close()
     assert free0 - free_bytes() < (128 << 20)
+
+
+@pytest.mark.parametrize("N,B,K,obs_every,pad", [(27, 4096, 8, 2, False), (27, 4096, 6, 1, True), (81, 1024, 4, 2, True)])
+def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every, pad):
+    """alloc_rollout_buffers with every obs_every-th observation kept and / or env blocks padded to whole 128-byte lines
+    (FgParams.obs_env_pitch): the placed, strided buffer takes the same bits as K step calls."""
+    a, b = _pair(N, B, seed=6, crowd=0.4, step0=(np.arange(B) * 3) % 100)
+    pitch = -(-6 * N * N // 32) * 32 if pad else 0
+    out = b.alloc_rollout_buffers(K, obs_every=obs_every, obs_env_pitch=pitch)
+    assert b.placement["probed"]
+    assert tuple(out["obs"].shape) == (K // obs_every, B, N, 6 * N)
+    if pad:
+        assert out["obs"].stride(1) == pitch and not out["obs"].is_contiguous()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(N + K)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    obs, rew, done, info = b.rollout(acts, out=out, obs_every=obs_every)
+    for k in range(K):
+        o, r, d, i = a.step(acts[k])
+        assert torch.equal(r, rew[k]) and torch.equal(d, done[k])
+        if (k + 1) % obs_every == 0:
+            assert torch.equal(o, obs[k // obs_every]), "observations differ at step %d" % k
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
