@@ -276,6 +276,11 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
 
     try:
         return probe()
-    except _native.FormationHipError:                            # a mapping could not be made (address space, driver): the
-        arena.close()                                            # caller falls back to whole allocations
+    except Exception as exc:                                     # noqa: BLE001 - a mapping could not be made (address space,
+        # driver), or the mapped range could not be used as a tensor on this device: placement is an optimisation, the
+        # caller falls back to whole allocations
+        import warnings
+        warnings.warn("formation_gym.placement: arena placement failed (%s: %s); using whole allocations"
+                      % (type(exc).__name__, exc), RuntimeWarning)
+        arena.close()
         return None

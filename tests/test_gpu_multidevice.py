@@ -163,3 +163,26 @@ def test_two_rank_processes_on_distinct_devices_with_the_rccl_barrier(tmp_path):
     for g in d["global_configs"]:
         assert len(g["per_rank_ms_per_step"]) == 2 and g["state_finite"]
         assert g["n1_same_run"] and 0.2 < g["scaling_efficiency_vs_n1"] < 1.5
+
+
+def test_placed_buffers_on_the_second_device():
+    """env.alloc_rollout_buffers for an env on cuda:1 from a thread whose current device is cuda:0: the arena is made on
+    the env's device (fg_arena_create(device = 1)), and a rollout into the placed buffer equals step calls."""
+    from formation_gym import placement
+    N, B, K = 27, 4096, 8
+    torch.cuda.set_device(0)
+    a, b = _make(N, B, "cuda:1"), _make(N, B, "cuda:1")
+    for e in (a, b):
+        e.seed(3); e.reset()
+    out = b.alloc_rollout_buffers(K)
+    assert torch.cuda.current_device() == 0
+    assert out["obs"].device == torch.device("cuda:1") and b.placement["probed"]
+    if b.placement.get("kept", "").startswith("spread"):
+        assert placement.is_placed(out["obs"].data_ptr())
+    gen = torch.Generator(device="cuda:1"); gen.manual_seed(1)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda:1") * 2 - 1).contiguous()
+    obs, rew, done, info = b.rollout(acts, out=out)
+    for k in range(K):
+        o, r, d, i = a.step(acts[k])
+        assert torch.equal(o, obs[k]) and torch.equal(r, rew[k])
+    torch.cuda.synchronize(1)
