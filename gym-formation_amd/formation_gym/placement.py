@@ -196,7 +196,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
     total, chunk = geometry
     try:
         arena = Arena(total, device, chunk)
-    except _native.FormationHipError:
+    except Exception:                                            # noqa: BLE001 - no arena (driver, address space): whole allocations
         return None
 
     def probe():
