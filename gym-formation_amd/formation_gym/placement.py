@@ -216,6 +216,15 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
                 arena.unmap(addr)
 
         def spread_selection(t):
+            # What makes a selection fast (profiles/r03_place/selection_rules_*.txt): chunks that are CONSECUTIVE in the
+            # buffer must lie far apart in memory (>= 8-20 GB) - two clusters at the ends of the arena written one after the
+            # other run like neighbours, the same clusters taken alternately run like the best spread.  Three families:
+            if t % 3 == 2:
+                R = 3 + (t // 3) % 3                                  # R regions of the arena taken round-robin
+                per = -(-W // R)
+                if n // R >= per:
+                    starts = [r * (n // R) + rnd.randrange(n // R - per + 1) for r in range(R)]
+                    return "regions round-robin (%d)" % R, [starts[k % R] + k // R for k in range(W)]
             idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
             while len(idx) < W:                                       # strata narrower than a chunk can collide
                 c = rnd.randrange(n)
@@ -260,7 +269,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_
         best = min(final, key=final.get)
         addr = arena.map(cands[best][1])                             # the winner, for good ...
         arena.trim()                                                 # ... and every other chunk back to the driver
-        if best > 0:
+        if best > 0:                                                 # every candidate but "as created" is a spread buffer
             arena.kept_range = (addr, addr + W * chunk)
         flat = arena.floats(addr, nfloats)
         spread = sorted(ms[1:])
