@@ -327,7 +327,11 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             for (unsigned c = 0; c < NFULL; ++c) {
                 const f32x4 v = src4[c * 64 + lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FG_STREAM_NT
+                __builtin_nontemporal_store(v, &dst4[c * 64 + lane]);   // experiment: profiles/r03_wide/ab_27_nt_placed.txt
+#else
                 dst4[c * 64 + lane] = v;
+#endif
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_sleep(1);
             }

@@ -262,7 +262,15 @@ static int launch_wide_v(Args a, hipStream_t st) {
 #endif
 template <bool POLICY = false>
 static int launch_wide(const Args& a, hipStream_t st) {
-    return a.N == 81 ? launch_wide_v<81, 2, FG_W81_E, FG_W81_TW, POLICY>(a, st) : launch_wide_v<243, 4, 4, FG_W243_TW, POLICY>(a, st);
+#ifndef FG_W243_E
+#define FG_W243_E 4
+#endif
+    if (a.N == 81) return launch_wide_v<81, 2, FG_W81_E, FG_W81_TW, POLICY>(a, st);
+    // 243 agents, at most 256 envs: one env per workgroup spreads the batch over more CUs (243 x 256 x 8: 103 -> 82 us/step,
+    // 243 x 64: 90 -> 78; at 81 agents the producer wave's own chain, ~15 us per step, is the bound whatever the geometry:
+    // profiles/r03_wide/ab_wide_small_batches.txt)
+    if (a.K > 1 && a.B <= 256) return launch_wide_v<243, 4, 1, FG_W243_TW, POLICY>(a, st);
+    return launch_wide_v<243, 4, FG_W243_E, FG_W243_TW, POLICY>(a, st);
 }
 
 // N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
@@ -309,6 +317,17 @@ static int launch_roll(const Args& a, hipStream_t st) {
         // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
         // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation cannot hold 16 tiles beside its controller tables: it
         // takes its 8 writer waves with the rows writer (below).
+        // Batches that do not fill the chip with 16-env workgroups (4096 envs = 256 workgroups = one per CU): fewer envs
+        // per workgroup, so that the batch still spreads over the CUs.  27 x 1024 x 20: 9.2 -> 3.4 us/step, 27 x 512: 9.1 ->
+        // 2.6, 27 x 256: 9.1 -> 2.6, 27 x 2048: 8.0 -> 6.0-6.5 (placed or not; 27 x 2560 and up are faster with 16:
+        // profiles/r03_wide/ab_27_small_batches_*.txt)
+        if (a.B <= 512) return launch_roll_v<27, 32, 64, 256, 2, FG_R27_WR, POLICY, false>(a, st);
+        if (a.B <= 1024) return launch_roll_v<27, 32, 128, 256, 4, FG_R27_WR, POLICY, false>(a, st);
+        if (a.B <= 2048) {
+            if constexpr (POLICY) return launch_roll_v<27, 32, 256, 256, 8, FG_R27_WR, POLICY, false>(a, st);
+            else return hbm ? launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st)
+                            : launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, false>(a, st);
+        }
         if (!POLICY && a.p.obs_placed && hbm)
             return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
 #if FG_R27_POLICY_ROWS512

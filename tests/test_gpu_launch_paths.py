@@ -745,3 +745,45 @@ def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every,
             assert torch.equal(o, obs[k // obs_every]), "observations differ at step %d" % k
     for x, y in zip(a.world.get_state(), b.world.get_state()):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("N,B,K", [(27, 300, 6), (27, 513, 6), (27, 1024, 5), (27, 1031, 5), (27, 2048, 4), (27, 2049, 4),
+                                   (27, 2048, 20), (243, 200, 3), (243, 257, 3)])
+def test_small_batch_rollout_geometries_equal_step_calls(N, B, K):
+    """Rollout launches of batches that do not fill the chip take workgroups of fewer envs (27 agents: 2 / 4 / 8 envs per
+    workgroup up to 512 / 1024 / 2048 envs; 243 agents: one env per workgroup up to 256 envs; (27, 2048, 20) is the
+    HBM-streaming form of the 8-env geometry).  Same bits as K step calls, ragged batches and mid-launch resets included."""
+    step0 = np.where(np.arange(B) % 4 == 0, 100 - 1 - (np.arange(B) // 4) % K, (np.arange(B) * 7) % (100 - K))
+    a, b = _pair(N, B, seed=8, crowd=0.45, step0=step0)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(B)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    for launch in range(2):
+        obs, rew, done, info = b.rollout(acts)
+        for k in range(K):
+            o, r, d, i = a.step(acts[k])
+            assert torch.equal(o, obs[k]), "observations differ at step %d of launch %d" % (k, launch)
+            assert torch.equal(r, rew[k]) and torch.equal(d, done[k])
+            assert torch.equal(i["individual_reward"], info["individual_reward"][k])
+        for x, y in zip(a.world.get_state() + (a.scenario.ideal_shape, a.world.step_count),
+                        b.world.get_state() + (b.scenario.ideal_shape, b.world.step_count)):
+            assert torch.equal(x, y)
+    assert bool(done.any())
+
+
+@pytest.mark.parametrize("B", [300, 700, 1500])
+def test_small_batch_closed_loop_rollouts_equal_policy_and_step_calls(B):
+    """The closed-loop instantiations of the small-batch geometries (27 agents, 2 / 4 / 8 envs per workgroup)."""
+    import formation_gym
+    N, K = 27, 6
+    a, b = _pair(N, B, seed=10, crowd=0.6, step0=(np.arange(B) * 11) % 100)
+    for e in (a, b):
+        e.scenario.observe_batch(e.world, {"obs": e._out["obs"], "reward": e._out["reward"]})
+    obs, rew, done, info = b.rollout_policy(K, 3)
+    o = a._out["obs"]
+    for k in range(K):
+        act = formation_gym.get_action_BFS(formation_gym.ezpolicy, o, 3)
+        assert torch.equal(act, info["actions"][k]), k
+        o, r, d, i = a.step(act)
+        assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k])
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
