@@ -342,7 +342,9 @@ static int launch_roll(const Args& a, hipStream_t st) {
         if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10, POLICY>(a, st);
         return launch_roll_v<9, 16, 64, 128, 4, 0, POLICY>(a, st);
     }
-    return launch_roll_v<3, 4, 64, 64, 16, 0, POLICY>(a, st);
+    // 3 agents: two writer waves (rows of 9 units keep 9 of a wave's 64 lanes busy; one wave was the bottleneck: 3 x 1024 x 20
+    // 2.28 -> 1.36 us/step, 3 x 16384 2.48 -> 1.63, 3 x 65536 7.46 -> 7.05; four waves lose from 16384 envs up)
+    return launch_roll_v<3, 4, 64, 128, 16, 0, POLICY>(a, st);
 }
 
 // N = per^L with 2 <= per <= 8: fills the host-rounded constants of the hierarchy
