@@ -138,6 +138,12 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
 #ifndef FG_SPLIT_MAX_B
 #define FG_SPLIT_MAX_B 128         // split step (launch_step) up to this many envs
 #endif
+#ifndef FG_WIDE81_ROLL_MIN_B
+#define FG_WIDE81_ROLL_MIN_B 512    // K-step rollouts take the pipelined kernels above these batch sizes
+#endif
+#ifndef FG_WIDE243_ROLL_MIN_B
+#define FG_WIDE243_ROLL_MIN_B 512
+#endif
 #ifndef FG_WIDE81_MIN_B
 #define FG_WIDE81_MIN_B 16384      // single-step launches at 81 agents take the pipelined kernel from this batch size up
 #endif
@@ -688,7 +694,11 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     if (K == 1 && ((N == 243 && B >= FG_WIDE243_MIN_B) || (N == 81 && B >= FG_WIDE81_MIN_B)) && !world_options_set(a.p))
         return launch_wide(a, (hipStream_t)stream);                                                  // as fg_step_hd
     if (K >= 2 && !world_options_set(a.p)) {
-        if (N == 81 || N == 243) return launch_wide(a, (hipStream_t)stream);
+        // 81 / 243 agents: the pipelined kernels keep one env on ONE producer wave (~15 / ~78 us of dependent work per
+        // step); a batch too small to hide that under other envs' stores is faster in step_kernel's K-loop, which spreads
+        // an env over 2 / 4 waves: 81 x 256 x 20 15.6 -> 12.5 us/step, 81 x 512 18.1 -> 16.1 (81 x 1024: 31.8 vs 33.2, stays),
+        // 243 x 64 x 8 77.8 -> 37.0, 243 x 256 81.8 -> 67.8 (243 x 257 on the pipelined kernel: 103; 243 x 512 equal) - profiles/r03_wide/ab_wide_small_kloop.txt
+        if ((N == 81 && B > FG_WIDE81_ROLL_MIN_B) || (N == 243 && B > FG_WIDE243_ROLL_MIN_B)) return launch_wide(a, (hipStream_t)stream);
         if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);
     }
     return launch_step(a, (hipStream_t)stream);
