@@ -334,7 +334,10 @@ static int launch_roll(const Args& a, hipStream_t st) {
             else return hbm ? launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st)
                             : launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, false>(a, st);
         }
-        if (!POLICY && a.p.obs_placed && hbm)
+        // ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (the memory system is not the
+        // bound then, a workgroup's own store rate is): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072
+        // 12.5 -> 10.7 (27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4: profiles/r03_wide/ab_27_mid_batches.txt)
+        if (!POLICY && hbm && (a.p.obs_placed || a.B <= 3072))
             return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
 #if FG_R27_POLICY_ROWS512
         if (POLICY && a.p.obs_placed && hbm)                       // closed loop: 8 writer waves with the rows writer (no tiles in LDS)

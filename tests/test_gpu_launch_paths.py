@@ -748,10 +748,11 @@ def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every,
 
 
 @pytest.mark.parametrize("N,B,K", [(27, 300, 6), (27, 513, 6), (27, 1024, 5), (27, 1031, 5), (27, 2048, 4), (27, 2049, 4),
-                                   (27, 2048, 20), (243, 200, 3), (243, 520, 2), (81, 512, 4), (81, 520, 4)])
+                                   (27, 2048, 20), (27, 2563, 12), (243, 200, 3), (243, 520, 2), (81, 512, 4), (81, 520, 4)])
 def test_small_batch_rollout_geometries_equal_step_calls(N, B, K):
     """Rollout launches of batches that do not fill the chip take workgroups of fewer envs (27 agents: 2 / 4 / 8 envs per
-    workgroup up to 512 / 1024 / 2048 envs; (27, 2048, 20) is the HBM-streaming form of the 8-env geometry), and at 81 /
+    workgroup up to 512 / 1024 / 2048 envs; (27, 2048, 20) is the HBM-streaming form of the 8-env geometry, (27, 2563, 12)
+    the 8-writer-wave instantiation on an ordinary allocation, taken up to 3072 envs), and at 81 /
     243 agents step_kernel's K-loop up to 512 envs, the pipelined kernels from 513 on.  Same bits as K step calls, ragged
     batches and mid-launch resets included."""
     step0 = np.where(np.arange(B) % 4 == 0, 100 - 1 - (np.arange(B) // 4) % K, (np.arange(B) * 7) % (100 - K))
