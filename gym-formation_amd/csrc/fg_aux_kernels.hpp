@@ -204,6 +204,8 @@ struct ScnArgs {
     int stage;     // compose the workgroup's observation rows in LDS and stream them out as ONE contiguous span
     int K;         // steps per launch (fg_rollout_scenario; 1 otherwise): act / reward / indiv / done / near_ag [K][B]...,
     int obs_every; // obs [K / obs_every][B][N][D]
+    float inv_n, inv_l;   // 1 / N, 1 / L, correctly rounded on the host: the run-time-count kernel and the one-env-per-lane
+                          // kernels (compile-time counts) must multiply by the very same values (cf. Args.inv_n)
 };
 
 // Scenario.reset_world of these scenarios from the device counter RNG (basic_formation_env.py:54-65,
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
         float s4[4] = {is_agent ? p.x : 0.f, is_agent ? p.y : 0.f, 0.f, 0.f};
         for (int l = i; live && l < L; l += G) { s4[2] += LM[l].x; s4[3] += LM[l].y; }
         env_reduce<G, T, 4, R_SUM, R_SUM, R_SUM, R_SUM>(s4, scratch);
-        const float mx = s4[0] / (float)N, my = s4[1] / (float)N;
-        const float lx = s4[2] / (float)L, ly = s4[3] / (float)L;
+        const float mx = s4[0] * a.inv_n, my = s4[1] * a.inv_n;
+        const float lx = s4[2] * a.inv_l, ly = s4[3] * a.inv_l;
         float rowmin = -INFINITY, colmax = -INFINITY;
         if (is_agent) {                                         // min over landmarks for my agent
             rowmin = INFINITY;

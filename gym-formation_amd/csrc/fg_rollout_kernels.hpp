@@ -31,13 +31,14 @@ __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 *
 
 // Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
 // workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.
-template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY = false, bool STREAM = false>
+template <int NC, int G, int TP, int TW, int E, int WR, int PER = 0, bool STREAM = false>
 __global__ __launch_bounds__(TP + TW) __attribute__((amdgpu_waves_per_eu((TP + TW) <= 512 ? 4 : 3)))
 void rollout_kernel(const Args a) {
+    constexpr bool POLICY = PER > 0;
     // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
     // STREAM: HBM-streaming form of the LDS-tile writer (fg_obs_writers.hpp)
-    // POLICY: closed loop - the action of step k is the demo controller (3-ary hierarchy) on the state step k-1
-    //         left, evaluated by the env's own lane group; a.act is not read, a.act_out records the actions
+    // PER > 0: closed loop - the action of step k is the demo controller (PER-ary hierarchy, N = PER^L) on the state
+    //         step k-1 left, evaluated by the env's own lane group; a.act is not read, a.act_out records the actions
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
     constexpr int NPS = NP <= 16 ? NP : 0;              // small N: partners fetched up front (fg_pair_loops.hpp)
@@ -105,7 +106,7 @@ void rollout_kernel(const Args a) {
             // its row 0 holds p_j - p_0, exactly this subtraction; QX / QY hold the current positions
             if (valid) { pol_tab[i] = make_float2(p.x - QX[0], p.y - QY[0]); pol_tab[N + i] = s; }
             WaveSync()();
-            const float2* res = bfs_policy_env<3>(pol_tab, N, a.pl, iv, i, G, WaveSync());
+            const float2* res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, i, G, WaveSync());
             if (valid) {
                 u_act = res[i];
                 if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u_act;
@@ -231,8 +232,9 @@ void rollout_kernel(const Args a) {
 // that every reduction stays inside the wave and producers still need no barrier of their own.
 // The partner loops load each partner pair once and update all A agents of the lane.
 // ---------------------------------------------------------------------------
-template <int NC, int A, int E, int TW, bool POLICY = false>
+template <int NC, int A, int E, int TW, int PER = 0>
 __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a) {
+    constexpr bool POLICY = PER > 0;
     static_assert(A * 64 >= NC && (A - 1) * 64 < NC && TW % 64 == 0, "bad wide rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64, TP = E * 64;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 if (valid[q]) { pol_tab[i] = make_float2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
             }
             WaveSync()();
-            pol_res = bfs_policy_env<3>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
+            pol_res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
         }
         // ---- World.step: all A agents of the lane against each partner pair ----
         float fx[A], fy[A];

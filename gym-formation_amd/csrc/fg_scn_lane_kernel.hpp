@@ -1,0 +1,383 @@
+// fg_scn_lane_kernel.hpp - The landmark scenarios at their reference shapes: ONE ENVIRONMENT PER LANE, every count a
+// compile-time constant.  Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
+//
+// fg::scn_kernel (fg_aux_kernels.hpp) gives one lane to every movable entity and walks run-time loops over 3-7 entities:
+// at 3 agents 3 of 4 lanes work, the loops cost as many scalar and branch instructions as vector ones, and the kernel
+// runs at 0.3-0.4 of the HBM rate (profiles/r03_scn_pmc.txt).  Here a lane owns a whole environment: agents, obstacles
+// and landmarks live in its registers, every pair loop is unrolled, nothing is reduced across lanes, and the 64
+// environments of a wave form ONE contiguous span of the [B][N][D] observation tensor - composed row by row in LDS
+// (conflict-free: odd row pitch) and streamed out with lane-consecutive 8-byte stores.
+// A workgroup is TWO waves sharing 64 environments: the PRODUCER wave (lane = env) runs World.step + reward of step k+1
+// while the WRITER wave streams step k's observations, rewards and done flags from LDS to global memory; two workgroup
+// barriers per step hand the LDS block back and forth.  The split also keeps the two kinds of memory traffic on
+// different waves: on gfx9 loads and stores share one counter (vmcnt), so a wave that both prefetches its next actions
+// and stores its outputs has to drain its whole store stream before it can use the prefetched action - the one-wave form
+// of this kernel spent a third of every step doing that (basic 3 x 65536: 3.99 us/step against the two-wave form's figure
+// in profiles/r04_scenario_rollout.md).
+//
+// The arithmetic is scn_kernel's, operation for operation (same helper functions, same expressions, sums in the
+// association order of its lane-group butterflies), so the two kernels agree bit for bit: tests/test_gpu_scenario_lane.py.
+// Reference lines under /root/reference/formation_gym/envs/:
+//   basic     observation basic_formation_env.py:29-41, reward :43-52 (self "collision" included)
+//   partial   observation formation_hd_partial_env.py:38-57 (ring neighbours), reward :59-72
+//   range     observation formation_hd_partial_range_env.py:38-52 (clipped), reward as partial
+//   obstacle  observation formation_hd_obs_env.py:44-58, reward :60-99 incl. the obstacle velocity override (:84-89)
+//   World.step core.py:206-277, 289-322 (all pairs of movable colliders)
+#ifndef FG_SCN_LANE_KERNEL_HPP_
+#define FG_SCN_LANE_KERNEL_HPP_
+
+#include "fg_common.hpp"
+#include "fg_aux_kernels.hpp"
+
+namespace fg {
+
+// sum of G values in the association order of env_reduce's butterfly over an aligned group of G lanes:
+// a balanced tree over the slots in natural order
+template <int G> FG_DEV float lane_group_sum(const float (&x)[G]) {
+    float t[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) t[g] = x[g];
+#pragma unroll
+    for (int s = 1; s < G; s <<= 1) {
+#pragma unroll
+        for (int g = 0; g < G; g += 2 * s) t[g] = t[g] + t[g + s];
+    }
+    return t[0];
+}
+
+__host__ __device__ constexpr int scn_group_lanes(int entities) {     // scn_kernel's G: pow2 >= N + M, at least 4
+    int g = 4;
+    while (g < entities) g <<= 1;
+    return g;
+}
+__host__ __device__ constexpr int scn_obs_dim(int kind, int n, int l, int m, int nbr) {
+    return 2 + (kind == FG_SCN_BASIC ? 2 : 0) + 2 * l + 2 * m + 2 * nbr + 2 * (n - 1);
+}
+// LDS pitch (float2 units) of one env's [N][D] block: odd, so that the lanes' ds_write_b64 fall on distinct banks
+__host__ __device__ constexpr int scn_lane_pitch(int units) { return units | 1; }
+
+// NBR: neighbours observed = num_obs (partial) or N - 1 (the other kinds)
+// LDS of one workgroup, in float2 units: the observation block [64][SU], then reward / individual reward / done of the
+// 64 x N agents as three arrays of 64 N dwords
+__host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int m, int nbr) {
+    return 64 * scn_lane_pitch(n * scn_obs_dim(kind, n, l, m, nbr) / 2) * 8 + 3 * 64 * n * 4;
+}
+
+template <int KIND, int N, int L, int M, int NBR>
+__global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
+    constexpr int NE = N + M;
+    constexpr int G = scn_group_lanes(NE);
+    constexpr int D = scn_obs_dim(KIND, N, L, M, NBR);
+    constexpr int U = N * D / 2;                        // float2 units per env
+    constexpr int SU = scn_lane_pitch(U);
+    constexpr bool BASIC = KIND == FG_SCN_BASIC;
+    static_assert(NE <= 8 && L <= 8, "one env per lane: a handful of entities");
+    extern __shared__ __attribute__((aligned(16))) float2 smem[];
+    float* const s_rew = reinterpret_cast<float*>(smem + 64 * SU);
+    float* const s_ind = s_rew + 64 * N;
+    uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + 64 * N);
+    const int lane = threadIdx.x & 63;
+    const int b0 = blockIdx.x * 64;
+    const int b = b0 + lane;
+    const bool live = b < a.B;
+    const int bl = live ? b : a.B - 1;                  // loads of a lane beyond the batch stay in range; it stores nothing
+    const int El = min(64, a.B - b0);
+    const int KS = a.K > 1 ? a.K : 1;
+
+    if (threadIdx.x >= 64) {
+        // ---- WRITER wave: block ks (published at barrier B) -> global memory, while the producer computes step ks + 1 ----
+        for (int ks = 0; ks < KS; ++ks) {
+            __syncthreads();                            // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
+            __syncthreads();                            // B: the block of step ks is complete
+            const size_t kb = (size_t)ks * a.B;
+            const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;
+            if (want_obs) {
+                // unit q of the wave's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
+                const size_t ob = (size_t)(a.obs_every > 1 ? ks / a.obs_every : ks) * a.B;
+                float2* const out = reinterpret_cast<float2*>(a.obs + (ob + (size_t)b0) * N * D);
+                constexpr int DR = 64 / U, DC = 64 - DR * U;
+                int row = lane / U, col = lane - row * U;
+                if (El == 64) {                         // a full wave: U instructions, 16 LDS reads in flight at a time
+#pragma unroll
+                    for (int c0 = 0; c0 < U; c0 += 16) {
+                        float2 r[16];
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) {
+                            if (c0 + c < U) {
+                                r[c] = smem[row * SU + col];
+                                row += DR; col += DC;
+                                if (col >= U) { col -= U; row += 1; }
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < 16; ++c)
+                            if (c0 + c < U) out[(c0 + c) * 64 + lane] = r[c];
+                    }
+                } else {
+                    const int units = El * U;
+                    for (int q = lane; q < units; q += 64) {
+                        out[q] = smem[row * SU + col];
+                        row += DR; col += DC;
+                        if (col >= U) { col -= U; row += 1; }
+                    }
+                }
+            }
+            // reward, individual reward, done of the 64 x N agents: [K][B][N], the wave's slice is contiguous
+            const int cnt = El * N;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const int q = c * 64 + lane;
+                if (q < cnt) {
+                    const size_t o = (kb + b0) * N + q;
+                    if (a.rew) a.rew[o] = s_rew[q];
+                    if (a.indiv) a.indiv[o] = s_ind[q];
+                    if (a.done) a.done[o] = (uint8_t)s_done[q];
+                }
+            }
+        }
+        return;
+    }
+
+    float2 p[NE], v[NE], lm[L];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const size_t s = (size_t)bl * N + i;
+        p[i] = make_float2(a.px[s], a.py[s]);
+        v[i] = make_float2(a.vx[s], a.vy[s]);
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        p[N + k] = reinterpret_cast<const float2*>(a.opos)[(size_t)bl * M + k];
+        v[N + k] = reinterpret_cast<const float2*>(a.ovel)[(size_t)bl * M + k];
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) lm[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)bl * L + l];
+    int t_step = a.step ? a.step[bl] : 0;
+    bool fresh_lm = false;                              // landmarks re-drawn by an in-launch reset: written back at the end
+
+    const float k_margin = a.p.contact_margin;
+    const float half_agent = 0.5f * a.p.dist_min, half_obst = 0.5f * (2.0f * a.sc.obstacle_size);
+    const float thr = a.p.collide_thresh, thr2 = (float)((double)thr * (double)thr);
+    const float ot = 0.5f * a.p.dist_min + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
+    float2 u_next[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) u_next[i] = make_float2(0.f, 0.f);
+    if (a.do_phys) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) u_next[i] = reinterpret_cast<const float2*>(a.act)[(size_t)bl * N + i];
+    }
+
+    for (int ks = 0; ks < KS; ++ks) {
+        const uint64_t off = rng_base(a.p) + (uint64_t)ks;
+        const size_t kb = (size_t)ks * a.B;
+        float2 u_now[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) u_now[i] = u_next[i];
+        if (a.do_phys && ks + 1 < KS) {                 // the action of step ks + 1 is fetched while step ks runs
+#pragma unroll
+            for (int i = 0; i < N; ++i) u_next[i] = reinterpret_cast<const float2*>(a.act)[(kb + a.B + bl) * N + i];
+        }
+        if (a.do_phys) {
+            // ---- World.step: every pair once, in lexicographic order - which is ascending j for each entity, the
+            // order core.py:240-262 (and scn_kernel) accumulates in; the pair's two forces are exact negatives
+            float fx[NE], fy[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { fx[i] = 0.f; fy[i] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+#pragma unroll
+                for (int j = i + 1; j < NE; ++j) {
+                    const float dmin = (i < N ? half_agent : half_obst) + (j < N ? half_agent : half_obst);
+                    const float cut = dmin + 18.0f * k_margin;
+                    const float dx = p[i].x - p[j].x, dy = p[i].y - p[j].y;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 < cut * cut) {
+                        const float d = __builtin_amdgcn_sqrtf(d2);
+                        const float x = (dmin - d) / k_margin;
+                        const float pen = k_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
+                        const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                        fx[i] += dx * c; fy[i] += dy * c;
+                        const float ex = -dx, ey = -dy;                 // p_j - p_i, exactly
+                        fx[j] += ex * c; fy[j] += ey * c;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                if (i < N) {
+                    const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u_now[i], (uint32_t)(b + a.p.env_index_base),
+                                                   (uint32_t)i, off);
+                    fx[i] += fa.x; fy[i] += fa.y;
+                }
+                if (a.p.num_walls > 0) wall_forces(a.p, p[i], i < N ? half_agent : half_obst, fx[i], fy[i]);
+                v[i].x = v[i].x * (1.0f - a.p.damping) + (fx[i] / a.p.mass) * a.p.dt;
+                v[i].y = v[i].y * (1.0f - a.p.damping) + (fy[i] / a.p.mass) * a.p.dt;
+                if (i < N) v[i] = clamp_speed(a.p.max_speed, v[i]);
+                p[i].x += v[i].x * a.p.dt; p[i].y += v[i].y * a.p.dt;
+                if (i >= N) {                           // the reward callback re-arms the obstacle velocity every step (:84-89)
+                    const bool falling = p[i].y > a.sc.obstacle_floor;
+                    v[i] = make_float2(falling ? a.sc.obstacle_vx : 0.f, falling ? a.sc.obstacle_vy : 0.f);
+                }
+            }
+            t_step += 1;
+        }
+        // ---- formation term ----
+        float form;
+        if constexpr (BASIC) {
+            float slot[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) slot[g] = 0.f;
+#pragma unroll
+            for (int l = 0; l < L; ++l) {
+                float best = INFINITY; int barg = 0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float dx = p[j].x - lm[l].x, dy = p[j].y - lm[l].y, d2 = dx * dx + dy * dy;
+                    if (d2 < best) { best = d2; barg = j; }
+                }
+                slot[l % G] += sqrtf(best);
+                if (a.near_ag && live) a.near_ag[(kb + b) * L + l] = barg;
+            }
+            form = lane_group_sum<G>(slot);
+        } else {
+            float sx[G], sy[G], tx[G], ty[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                sx[g] = g < N ? p[g < N ? g : 0].x : 0.f; sy[g] = g < N ? p[g < N ? g : 0].y : 0.f;
+                tx[g] = 0.f; ty[g] = 0.f;
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) { tx[l % G] += lm[l].x; ty[l % G] += lm[l].y; }
+            const float mx = lane_group_sum<G>(sx) * a.inv_n, my = lane_group_sum<G>(sy) * a.inv_n;
+            const float lx = lane_group_sum<G>(tx) * a.inv_l, ly = lane_group_sum<G>(ty) * a.inv_l;
+            float rowmax = -INFINITY, colmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {                       // min over landmarks for agent i
+                float rowmin = INFINITY;
+#pragma unroll
+                for (int l = 0; l < L; ++l) {
+                    const float dx = (p[i].x - mx) - (lm[l].x - lx), dy = (p[i].y - my) - (lm[l].y - ly);
+                    rowmin = fminf(rowmin, dx * dx + dy * dy);
+                }
+                rowmax = fmaxf(rowmax, rowmin);
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) {                       // min over agents for landmark l
+                float cm = INFINITY;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float dx = (p[j].x - mx) - (lm[l].x - lx), dy = (p[j].y - my) - (lm[l].y - ly);
+                    cm = fminf(cm, dx * dx + dy * dy);
+                }
+                colmax = fmaxf(colmax, cm);
+            }
+            form = sqrtf(fmaxf(rowmax, colmax));
+        }
+        // ---- collision counts (pairs shared: |p_j - p_i|^2 is the same number from either side) ----
+        int cnt[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) cnt[i] = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if constexpr (BASIC) {                                      // the self pair (basic_formation_env.py:49-51): distance 0,
+                const float dx = p[i].x - p[i].x, dy = p[i].y - p[i].y; //   NaN for a NaN position, as scn_kernel computes it
+                cnt[i] += (dx * dx + dy * dy < thr2) ? 1 : 0;
+            }
+#pragma unroll
+            for (int j = i + 1; j < N; ++j) {
+                const float dx = p[j].x - p[i].x, dy = p[j].y - p[i].y;
+                const int hit = (dx * dx + dy * dy < thr2) ? 1 : 0;
+                cnt[i] += hit; cnt[j] += hit;
+            }
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                const float dx = p[N + k].x - p[i].x, dy = p[N + k].y - p[i].y;
+                cnt[i] += (dx * dx + dy * dy < ot2) ? 1 : 0;
+            }
+        }
+        int total = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) total += cnt[i];
+        const bool is_done = t_step >= a.p.world_length;
+        const float shared = (float)(-(double)N * (double)form - (double)a.sc.penalty * (double)(float)total);
+        float indiv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) indiv[i] = -form - a.sc.penalty * (float)cnt[i];
+        const uint32_t done_flag = is_done ? 1u : 0u;       // the finished step's flag: the reset below does not change it
+        if (a.p.auto_reset && a.do_phys && is_done) {
+            // the vec-env worker's rule (env_wrappers.py:14-18): the env restarts at once, the RESET observation goes out
+            // with the finished step's reward / done.  The draws fg_reset_scenario makes.
+#pragma unroll
+            for (int i = 0; i < N; ++i) { p[i] = scn_fresh_pm1(a.p, b, (uint32_t)i, off); v[i] = make_float2(0.f, 0.f); }
+#pragma unroll
+            for (int k = 0; k < M; ++k) {
+                p[N + k] = scn_fresh_obstacle(a.p, b, k, a.sc.num_obstacles, off);
+                v[N + k] = make_float2(a.sc.obstacle_vx, a.sc.obstacle_vy);
+            }
+#pragma unroll
+            for (int l = 0; l < L; ++l) lm[l] = scn_fresh_pm1(a.p, b, SCN_LANDMARK_CODE | (uint32_t)l, off);
+            fresh_lm = true;
+            t_step = 0;
+        }
+        // ---- hand-over: the lane's [N][D] observation block and its rewards into LDS, for the writer wave ----
+        const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;      // uniform over the launch
+        __syncthreads();                                // A: the writer has read the block of step ks - 1
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            s_rew[lane * N + i] = shared; s_ind[lane * N + i] = indiv[i]; s_done[lane * N + i] = done_flag;
+        }
+        if (want_obs) {
+            float2* const mine = smem + lane * SU;
+            const float r = (KIND == FG_SCN_RANGE) ? a.sc.obs_range : INFINITY;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                float2* const o = mine + i * (D / 2);
+                int w = 0;
+                o[w++] = v[i];
+                if constexpr (BASIC) o[w++] = p[i];
+#pragma unroll
+                for (int l = 0; l < L; ++l) o[w++] = BASIC ? make_float2(lm[l].x - p[i].x, lm[l].y - p[i].y) : lm[l];
+#pragma unroll
+                for (int k = 0; k < M; ++k) o[w++] = make_float2(p[N + k].x - p[i].x, p[N + k].y - p[i].y);
+                if constexpr (KIND == FG_SCN_PARTIAL) {
+#pragma unroll
+                    for (int kk = 0; kk < NBR; ++kk) {
+                        int j = i + 1 + kk;                             // (i + 1 + kk) mod N
+                        while (j >= N) j -= N;
+                        o[w++] = make_float2(p[j].x - p[i].x, p[j].y - p[i].y);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < N - 1; ++t) {
+                        const int j = t < i ? t : t + 1;                // the t-th OTHER agent, index order
+                        o[w++] = make_float2(fminf(fmaxf(p[j].x - p[i].x, -r), r), fminf(fmaxf(p[j].y - p[i].y, -r), r));
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < N - 1; ++t) o[w++] = make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();                                // B: published
+    }   // steps
+    if (live && a.do_phys) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const size_t s = (size_t)b * N + i;
+            a.px[s] = p[i].x; a.py[s] = p[i].y; a.vx[s] = v[i].x; a.vy[s] = v[i].y;
+        }
+#pragma unroll
+        for (int k = 0; k < M; ++k) {
+            reinterpret_cast<float2*>(a.opos)[(size_t)b * M + k] = p[N + k];
+            reinterpret_cast<float2*>(a.ovel)[(size_t)b * M + k] = v[N + k];
+        }
+        if (fresh_lm) {
+#pragma unroll
+            for (int l = 0; l < L; ++l) reinterpret_cast<float2*>(a.lm)[(size_t)b * L + l] = lm[l];
+        }
+        if (a.step) a.step[b] = t_step;
+    }
+}
+
+}  // namespace fg
+
+#endif  // FG_SCN_LANE_KERNEL_HPP_

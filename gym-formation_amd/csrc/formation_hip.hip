@@ -36,6 +36,7 @@
 #include "fg_step_kernel.hpp"
 #include "fg_rollout_kernels.hpp"
 #include "fg_aux_kernels.hpp"
+#include "fg_scn_lane_kernel.hpp"
 #include "fg_policy_kernels.hpp"
 
 namespace fg {
@@ -98,9 +99,6 @@ static hipError_t raise_lds_limit(const void* fn, int lds, std::atomic<unsigned 
 
 static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-#ifndef FG_SINGLE_STEP_VARIANTS
-#define FG_SINGLE_STEP_VARIANTS 1      // 0: experiment builds without the single-step instantiations
-#endif
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
     const int n_split = a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16);
@@ -109,7 +107,6 @@ static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
         const hipError_t err = raise_lds_limit((const void*)&step_kernel<NC, G, T, E, IDX, OPTS>, lds, &raised);
         if (err != hipSuccess) return err;
     }
-#if FG_SINGLE_STEP_VARIANTS
     // the single-step instantiation (no step loop, no slot arithmetic) of the plain variants from 27 agents up: 27 x 4096
     // 15.15 -> 15.03 us, 81 x 2048 -1 %; at 3 and 9 agents it is slower (profiles/r02_step/kone.txt)
     if (!IDX && !OPTS && NC >= 27 && a.K == 1 && a.obs_every == 1) {
@@ -118,7 +115,6 @@ static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
                            (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
         return hipGetLastError();
     }
-#endif
     hipLaunchKernelGGL((step_kernel<NC, G, T, E, IDX, OPTS>), dim3(grid), dim3(T), lds, st,
                        a.B, n_split, (const float*)a.px, (const float*)a.py, (const float*)a.vx, (const float*)a.vy,
                        (const float*)a.shape, (const float*)a.ivel, (const int32_t*)a.step, a);
@@ -135,28 +131,22 @@ struct Variant { int NC, G, T, E, min_B; LaunchFn plain, idx, opts; };
                                        &launch_v<NC, G, T, E, true, false>, &launch_v<NC, G, T, E, true, true>}
 #define FG_VARIANT_BIG(NC, G, T, E, MINB) {NC, G, T, E, MINB, &launch_v<NC, G, T, E, false, false>, nullptr, nullptr}
 
-#ifndef FG_SPLIT_MAX_B
-#define FG_SPLIT_MAX_B 128         // split step (launch_step) up to this many envs
-#endif
-#ifndef FG_WIDE81_ROLL_MIN_B
-#define FG_WIDE81_ROLL_MIN_B 512    // K-step rollouts take the pipelined kernels above these batch sizes
-#endif
-#ifndef FG_WIDE243_ROLL_MIN_B
-#define FG_WIDE243_ROLL_MIN_B 512
-#endif
-#ifndef FG_WIDE81_MIN_B
-#define FG_WIDE81_MIN_B 16384      // single-step launches at 81 agents take the pipelined kernel from this batch size up
-#endif
-#ifndef FG_WIDE243_MIN_B
-#define FG_WIDE243_MIN_B 4096      // single-step launches at 243 agents: below this the pipelined kernel's 4-env batches leave CUs
-                                   // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
-#endif
+// batch-size thresholds of the dispatch below (MI355X sweeps; the profile behind each is named where it is used)
+constexpr int FG_SPLIT_MAX_B = 128;        // split step (launch_step) up to this many envs
+constexpr int FG_WIDE81_MIN_B = 16384;     // single-step launches at 81 agents take the pipelined kernel from this batch size up
+constexpr int FG_WIDE243_MIN_B = 4096;     // single-step launches at 243 agents: below this the pipelined kernel's 4-env batches leave CUs
+                                           // idle and one env per workgroup (step_kernel) is up to 3x faster (profiles/r02_step/wide243_min_b.txt)
 static const Variant kVariants[] = {
     FG_VARIANT(3, 4, 128, 16, 0), FG_VARIANT_BIG(3, 4, 128, 32, 65536),   // every lane owns an agent: 3 x 262144 35.3 -> 27.8 us (profiles/r02_step/n3_big_batches.txt)
     FG_VARIANT(9, 16, 128, 4, 0), FG_VARIANT_BIG(9, 16, 128, 8, 16384),
     FG_VARIANT(27, 32, 256, 4, 0), FG_VARIANT_BIG(27, 32, 256, 8, 32768),
     FG_VARIANT(81, 128, 128, 1, 0),
     FG_VARIANT(243, 256, 256, 1, 0),
+    // the agent counts of the other hierarchies get_action_BFS takes (per_layer 2, 4, 5, 8: __init__.py:49-56): compile-time
+    // N with the register-cached rows writer for the plain launch; index outputs / World options take the run-time-N kernels
+    FG_VARIANT_BIG(4, 4, 128, 16, 0), FG_VARIANT_BIG(8, 8, 128, 8, 0), FG_VARIANT_BIG(16, 16, 128, 4, 0),
+    FG_VARIANT_BIG(25, 32, 256, 4, 0), FG_VARIANT_BIG(32, 32, 256, 4, 0), FG_VARIANT_BIG(64, 64, 256, 2, 0),
+    FG_VARIANT_BIG(125, 128, 128, 1, 0),
     FG_VARIANT(0, 4, 64, 16, 0), FG_VARIANT(0, 8, 64, 8, 0), FG_VARIANT(0, 16, 64, 4, 0), FG_VARIANT(0, 32, 128, 4, 0),
     FG_VARIANT(0, 64, 128, 2, 0), FG_VARIANT(0, 128, 128, 1, 0), FG_VARIANT(0, 256, 256, 1, 0),
     FG_VARIANT(0, 512, 512, 1, 0), FG_VARIANT(0, 1024, 1024, 1, 0),
@@ -192,9 +182,6 @@ static bool world_options_set(const FgParams& p) {
 }
 
 static int launch_step(Args a, hipStream_t st) {
-#ifdef FG_TRACE
-    { const char* e = getenv("FG_TRACE_PTR"); a.trace = e ? (long long*)strtoull(e, nullptr, 0) : nullptr; }
-#endif
     Geometry g;
     const bool opts = world_options_set(a.p);
     const bool idx = a.near_lm || a.near_ag || a.hd_idx;
@@ -229,17 +216,14 @@ static int launch_step(Args a, hipStream_t st) {
 }
 
 // 64 < N <= 256: producer / writer pipelined kernel (rollout: over steps; single step: over env batches)
-template <int NC, int A, int E, int TW, bool POLICY>
+// PER > 0: closed loop with the PER-ary demo controller inside the kernel (fg_rollout_hd_policy)
+template <int NC, int A, int E, int TW, int PER>
 static int launch_wide_v(Args a, hipStream_t st) {
     if (a.K == 1) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
         // stream, few enough to keep every CU busy (one workgroup per CU; MI355X sweep, profiles/README.md)
         const int batches = (a.B + E - 1) / E;
-#ifdef FG_EXP_GROUP_DIV
-        a.groups = batches / (NC <= 81 ? FG_EXP_GROUP_DIV : 256);
-#else
         a.groups = batches / 256;
-#endif
         if (a.groups < 1) a.groups = 1;
         if (a.groups > 64) a.groups = 64;
     } else {
@@ -247,113 +231,146 @@ static int launch_wide_v(Args a, hipStream_t st) {
     }
     const int grid = (a.B + E * a.groups - 1) / (E * a.groups);
     const int lds = E * roll_block_floats(NC) * (int)sizeof(float) +
-                    (POLICY ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
+                    (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, POLICY>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, PER>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, POLICY>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, PER>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
-#ifndef FG_W81_E
-#define FG_W81_E 4            // envs (= producer waves) per workgroup of the 81-agent pipelined kernel
-#endif
-#ifndef FG_W81_TW
-#define FG_W81_TW 256         // writer threads of that kernel
-#endif
-#ifndef FG_W243_TW
-#define FG_W243_TW 256
-#endif
-template <bool POLICY = false>
+// 4 envs (= producer waves) and 4 writer waves per workgroup (MI355X sweeps: profiles/README.md, profiles/r03_wide/)
+template <int NC, int PER>
 static int launch_wide(const Args& a, hipStream_t st) {
-#ifndef FG_W243_E
-#define FG_W243_E 4
-#endif
-    if (a.N == 81) return launch_wide_v<81, 2, FG_W81_E, FG_W81_TW, POLICY>(a, st);
+    static_assert(NC > 64 && NC <= 256, "one producer wave per env, up to 4 agents per lane");
+    constexpr int A = (NC + 63) / 64;
     // 243 agents, at most 256 envs: one env per workgroup spreads the batch over more CUs (243 x 256 x 8: 103 -> 82 us/step,
     // 243 x 64: 90 -> 78; at 81 agents the producer wave's own chain, ~15 us per step, is the bound whatever the geometry:
     // profiles/r03_wide/ab_wide_small_batches.txt)
-    if (a.K > 1 && a.B <= 256) return launch_wide_v<243, 4, 1, FG_W243_TW, POLICY>(a, st);
-    return launch_wide_v<243, 4, FG_W243_E, FG_W243_TW, POLICY>(a, st);
+    if constexpr (NC == 243)
+        if (a.K > 1 && a.B <= 256) return launch_wide_v<243, 4, 1, 256, PER>(a, st);
+    return launch_wide_v<NC, A, 4, 256, PER>(a, st);
 }
 
-// N in {3, 9, 27}, K >= 2: producer / writer pipelined rollout kernel
-template <int NC, int G, int TP, int TW, int E, int WR, bool POLICY, bool STREAM = false>
+// N <= 64, K >= 2: producer / writer pipelined rollout kernel
+template <int NC, int G, int TP, int TW, int E, int WR, int PER, bool STREAM = false>
 static int launch_roll_v(const Args& a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
     if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
-    if (POLICY) lds += E * policy_block_units(NC) * (int)sizeof(float2);
+    if (PER > 0) lds += E * policy_block_units(NC) * (int)sizeof(float2);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, POLICY, STREAM>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR, POLICY, STREAM>), dim3(grid), dim3(TP + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>), dim3(grid), dim3(TP + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
-#ifndef FG_R27_POLICY_ROWS512
-#define FG_R27_POLICY_ROWS512 1    // closed loop into a placed buffer: 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
-#endif
-#ifndef FG_R27_TW
-#define FG_R27_TW 256          // writer threads of the 27-agent rollout kernel
-#endif
-#ifndef FG_R27_WR
-#define FG_R27_WR 10           // its writer: 1 + rows per LDS tile, 0 = register-cached rows
-#endif
-template <bool POLICY = false>
-static int launch_roll(const Args& a, hipStream_t st) {
-    // Defaults from the MI355X sweeps (profiles/README.md).  27 agents: 16 envs per workgroup = 8 producer + 4
-    // writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.  9 agents: a batch of <= 4096 envs is
-    // bound by the producers' dependent chain and wants many small workgroups with the row writer; larger
-    // batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
-    if (a.N == 27) {
-        // HBM-streaming form of the tile writer (line ownership + paced stores, fg_obs_writers.hpp): batches of a few
-        // workgroup generations whose rollout buffer does not fit the 256 MiB Infinity Cache; else the plain form
-        const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
-        bool stream = a.B < 16384 && hbm;
-#ifdef FG_R27_FORCE_STREAM
-        stream = FG_R27_FORCE_STREAM != 0;
-#endif
-        // A buffer composed of chunks spread over the device's memory (FgParams.obs_placed) takes the stream of 8 paced
-        // writer waves: 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384
-        // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
-        // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation cannot hold 16 tiles beside its controller tables: it
-        // takes its 8 writer waves with the rows writer (below).
-        // Batches that do not fill the chip with 16-env workgroups (4096 envs = 256 workgroups = one per CU): fewer envs
-        // per workgroup, so that the batch still spreads over the CUs.  27 x 1024 x 20: 9.2 -> 3.4 us/step, 27 x 512: 9.1 ->
-        // 2.6, 27 x 256: 9.1 -> 2.6, 27 x 2048: 8.0 -> 6.0-6.5 (placed or not; 27 x 2560 and up are faster with 16:
-        // profiles/r03_wide/ab_27_small_batches_*.txt)
-        if (a.B <= 512) return launch_roll_v<27, 32, 64, 256, 2, FG_R27_WR, POLICY, false>(a, st);
-        if (a.B <= 1024) return launch_roll_v<27, 32, 128, 256, 4, FG_R27_WR, POLICY, false>(a, st);
+// writer of the pipelined kernels per agent count: 1 + rows per LDS tile (the rows must divide N: 9 of 27 and 9, 5 of 25,
+// 8 of 16 and 32), 0 = register-cached rows (few agents: a tile is too small to pay; 64 agents: a row is a wave)
+constexpr int roll_writer(int n) { return (n == 27 || n == 9) ? 10 : n == 25 ? 6 : (n == 16 || n == 32) ? 9 : 0; }
+
+// up to 8 agents (3, 4, 8): one wave of producers, two writer waves with the rows writer (rows of 9 units keep 9 of a wave's
+// 64 lanes busy; one writer wave was the bottleneck: 3 x 1024 x 20 2.28 -> 1.36 us/step, 3 x 16384 2.48 -> 1.63, 3 x 65536
+// 7.46 -> 7.05; four waves lose from 16384 envs up)
+template <int NC, int PER>
+static int launch_roll_8(const Args& a, hipStream_t st) {
+    constexpr int G = NC <= 4 ? 4 : 8;
+    return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
+}
+// 9 ... 16 agents: a batch of <= 4096 envs is bound by the producers' dependent chain and wants many small workgroups with
+// the row writer; larger batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
+// (The closed loop at 16 agents has the small geometry only.)
+template <int NC, int PER>
+static int launch_roll_16(const Args& a, hipStream_t st) {
+    constexpr int WR = roll_writer(NC);
+    if constexpr (NC == 9 || PER == 0) {
+        if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+        if (a.B > 4096) return launch_roll_v<NC, 16, 128, 128, 8, WR, PER>(a, st);
+    }
+    return launch_roll_v<NC, 16, 64, 128, 4, 0, PER>(a, st);
+}
+// 17 ... 32 agents (25, 27, 32).  Defaults from the MI355X sweeps at 27 agents (profiles/README.md): 16 envs per workgroup =
+// 8 producer + 4 writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.
+template <int NC, int PER>
+static int launch_roll_32(const Args& a, hipStream_t st) {
+    constexpr int WR = roll_writer(NC);
+    constexpr bool POLICY = PER > 0;
+    // HBM-streaming form of the tile writer (line ownership + paced stores, fg_obs_writers.hpp): batches of a few
+    // workgroup generations whose rollout buffer does not fit the 256 MiB Infinity Cache; else the plain form
+    const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+    const bool stream = a.B < 16384 && hbm;
+    // A buffer composed of chunks spread over the device's memory (FgParams.obs_placed) takes the stream of 8 paced
+    // writer waves: 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384
+    // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
+    // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation cannot hold 16 tiles beside its controller tables: it
+    // takes its 8 writer waves with the rows writer (below).
+    // Batches that do not fill the chip with 16-env workgroups (4096 envs = 256 workgroups = one per CU): fewer envs
+    // per workgroup, so that the batch still spreads over the CUs.  27 x 1024 x 20: 9.2 -> 3.4 us/step, 27 x 512: 9.1 ->
+    // 2.6, 27 x 256: 9.1 -> 2.6, 27 x 2048: 8.0 -> 6.0-6.5 (placed or not; 27 x 2560 and up are faster with 16:
+    // profiles/r03_wide/ab_27_small_batches_*.txt)
+    if constexpr (NC == 27) {                           // the reference's own agent count: a geometry per batch-size class
+        if (a.B <= 512) return launch_roll_v<NC, 32, 64, 256, 2, WR, PER, false>(a, st);
+        if (a.B <= 1024) return launch_roll_v<NC, 32, 128, 256, 4, WR, PER, false>(a, st);
         if (a.B <= 2048) {
-            if constexpr (POLICY) return launch_roll_v<27, 32, 256, 256, 8, FG_R27_WR, POLICY, false>(a, st);
-            else return hbm ? launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st)
-                            : launch_roll_v<27, 32, 256, 512, 8, FG_R27_WR, false, false>(a, st);
+            if constexpr (POLICY) return launch_roll_v<NC, 32, 256, 256, 8, WR, PER, false>(a, st);
+            else return hbm ? launch_roll_v<NC, 32, 256, 512, 8, WR, 0, true>(a, st)
+                            : launch_roll_v<NC, 32, 256, 512, 8, WR, 0, false>(a, st);
         }
-        // ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (the memory system is not the
-        // bound then, a workgroup's own store rate is): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072
-        // 12.5 -> 10.7 (27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4: profiles/r03_wide/ab_27_mid_batches.txt)
-        if (!POLICY && hbm && (a.p.obs_placed || a.B <= 3072))
-            return launch_roll_v<27, 32, 512, 512, 16, FG_R27_WR, false, (FG_R27_WR > 0)>(a, st);
-#if FG_R27_POLICY_ROWS512
-        if (POLICY && a.p.obs_placed && hbm)                       // closed loop: 8 writer waves with the rows writer (no tiles in LDS)
-            return launch_roll_v<27, 32, 512, 512, 16, 0, POLICY, false>(a, st);
-#endif
-        return stream ? launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, (FG_R27_WR > 0)>(a, st)
-                      : launch_roll_v<27, 32, 512, FG_R27_TW, 16, FG_R27_WR, POLICY, false>(a, st);
+        if (POLICY && a.p.obs_placed && hbm)            // closed loop: 8 writer waves with the rows writer (no tiles in LDS):
+            return launch_roll_v<NC, 32, 512, 512, 16, 0, PER, false>(a, st);   // 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
+    } else {
+        if (a.B <= 1024) return launch_roll_v<NC, 32, 128, 256, 4, WR, PER, false>(a, st);
     }
-    if (a.N == 9) {
-        if (a.B >= 8192) return launch_roll_v<9, 16, 256, 256, 16, 10, POLICY>(a, st);
-        if (a.B > 4096) return launch_roll_v<9, 16, 128, 128, 8, 10, POLICY>(a, st);
-        return launch_roll_v<9, 16, 64, 128, 4, 0, POLICY>(a, st);
+    // ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (the memory system is not the
+    // bound then, a workgroup's own store rate is): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072
+    // 12.5 -> 10.7 (27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4: profiles/r03_wide/ab_27_mid_batches.txt)
+    if constexpr (!POLICY) {
+        if (hbm && (a.p.obs_placed || a.B <= 3072)) return launch_roll_v<NC, 32, 512, 512, 16, WR, 0, true>(a, st);
+        if (stream) return launch_roll_v<NC, 32, 512, 256, 16, WR, 0, true>(a, st);
+    } else if constexpr (NC == 27) {
+        if (stream) return launch_roll_v<NC, 32, 512, 256, 16, WR, PER, true>(a, st);
     }
-    // 3 agents: two writer waves (rows of 9 units keep 9 of a wave's 64 lanes busy; one wave was the bottleneck: 3 x 1024 x 20
-    // 2.28 -> 1.36 us/step, 3 x 16384 2.48 -> 1.63, 3 x 65536 7.46 -> 7.05; four waves lose from 16384 envs up)
-    return launch_roll_v<3, 4, 64, 128, 16, 0, POLICY>(a, st);
+    return launch_roll_v<NC, 32, 512, 256, 16, WR, PER, false>(a, st);
+}
+// 64 agents: an env is a wave of producers, a row of its observation 3 stores of a writer wave
+template <int NC, int PER>
+static int launch_roll_64(const Args& a, hipStream_t st) {
+    if constexpr (PER == 0)
+        if (a.B <= 1024) return launch_roll_v<NC, 64, 128, 256, 2, 0, 0>(a, st);
+    return launch_roll_v<NC, 64, 512, 256, 8, 0, PER>(a, st);
+}
+
+// The pipelined K-step kernels exist for the agent counts of the reference's hierarchies, N = per^L: the reference's own
+// 3^L (README.md:34-36) and the other `per_layer` values get_action_BFS takes (__init__.py:49-56: 2, 4, 5, 8).  per = 0: open
+// loop (actions from act_seq); else the closed loop of fg_rollout_hd_policy.  Returns false when (N, per) has no instantiation
+// (the caller then runs step_kernel's K-loop / chained launches).
+static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
+#define FG_ROLL(FN, NN, PP) if (a.N == NN && per == PP) { *rc = FN<NN, PP>(a, st); return true; }
+    FG_ROLL(launch_roll_8, 3, 0) FG_ROLL(launch_roll_8, 3, 3)
+    FG_ROLL(launch_roll_8, 4, 0) FG_ROLL(launch_roll_8, 4, 2) FG_ROLL(launch_roll_8, 4, 4)
+    FG_ROLL(launch_roll_8, 8, 0) FG_ROLL(launch_roll_8, 8, 2) FG_ROLL(launch_roll_8, 8, 8)
+    FG_ROLL(launch_roll_16, 9, 0) FG_ROLL(launch_roll_16, 9, 3)
+    FG_ROLL(launch_roll_16, 16, 0) FG_ROLL(launch_roll_16, 16, 2) FG_ROLL(launch_roll_16, 16, 4)
+    FG_ROLL(launch_roll_32, 25, 0) FG_ROLL(launch_roll_32, 25, 5)
+    FG_ROLL(launch_roll_32, 27, 0) FG_ROLL(launch_roll_32, 27, 3)
+    FG_ROLL(launch_roll_32, 32, 0) FG_ROLL(launch_roll_32, 32, 2)
+    FG_ROLL(launch_roll_64, 64, 0) FG_ROLL(launch_roll_64, 64, 2) FG_ROLL(launch_roll_64, 64, 4) FG_ROLL(launch_roll_64, 64, 8)
+    // more than 64 agents: the pipelined kernels keep one env on ONE producer wave (~15 / ~78 us of dependent work per step
+    // at 81 / 243 agents); a batch too small to hide that under other envs' stores is faster in step_kernel's K-loop, which
+    // spreads an env over 2 / 4 waves: 81 x 256 x 20 15.6 -> 12.5 us/step, 81 x 512 18.1 -> 16.1 (81 x 1024: 31.8 vs 33.2, stays),
+    // 243 x 64 x 8 77.8 -> 37.0, 243 x 256 81.8 -> 67.8 (243 x 257 on the pipelined kernel: 103; 243 x 512 equal) -
+    // profiles/r03_wide/ab_wide_small_kloop.txt.  The closed loop always runs in the pipelined kernel (one launch).
+    if (per == 0 && a.B <= 512) return false;
+    FG_ROLL(launch_wide, 81, 0) FG_ROLL(launch_wide, 81, 3)
+    FG_ROLL(launch_wide, 125, 0) FG_ROLL(launch_wide, 125, 5)
+    FG_ROLL(launch_wide, 243, 0) FG_ROLL(launch_wide, 243, 3)
+#undef FG_ROLL
+    return false;
 }
 
 // N = per^L with 2 <= per <= 8: fills the host-rounded constants of the hierarchy
@@ -441,8 +458,26 @@ static void arena_unmap_slot(Arena* a, size_t slot) {
     m.base = nullptr; m.chunks.clear();
 }
 
-int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out) {
+// An address range that has held a mapping is retired, not freed (discipline 3): a process-wide budget keeps a long-lived
+// caller that places buffers again and again from running the 128 TiB address space dry (then arenas are refused and the
+// caller falls back to ordinary allocations, which is what placement.py does on any arena failure).
+static const unsigned long long kRetiredAddressBudget = 64ull << 40;
+
+// regions > 1: the chunks come in `regions` groups of consecutive indices, and between two groups the call holds
+// `spacer_bytes` of device memory (hipMalloc, never touched, freed before the call returns) so that the groups lie far
+// apart in physical memory although the arena itself is no larger than the buffer it is made for.
+static int arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
+                        void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out) {
     if (!arena || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena and bytes > 0 required%s");
+    if (g_retired_address_bytes.load() > kRetiredAddressBudget)
+        return fail(FG_ERR_HIP, "fg_arena_create: the address-space budget of retired reservations (64 TiB) is spent%s");
+    int prev_dev = -1;
+    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
+    if (prev_dev != device && hipSetDevice(device) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(FG_ERR_BAD_ARG, "fg_arena_create: no such device%s");
+    }
+    struct Restore { int prev, dev; ~Restore() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); } } restore{prev_dev, device};
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned;
@@ -456,31 +491,71 @@ int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** are
     Arena* a = new Arena();
     a->dev = device; a->chunk = chunk; a->n = ((size_t)bytes + chunk - 1) / chunk;
     a->handle.resize(a->n); a->live.assign(a->n, 0); a->mapped_in.assign(a->n, -1);
-    for (size_t i = 0; i < a->n; ++i) {
-        err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
-        if (err != hipSuccess) break;
-        a->live[i] = 1;
-    }
-    // Physical memory is assigned when a chunk is first mapped, in mapping order: map every chunk once, in index order, so
-    // that a chunk's index says where it lies (chunks far apart in index are far apart in memory - what the caller's
-    // spread selections rely on), then take the mappings away again (the reservation is retired, see above).
+    const uint32_t spacer_mode = regions >> 24;            // EXPERIMENT: 0 = hipMalloc, 1 = chunks created, 2 = chunks created + mapped
+    regions &= 0xFFFFFFu;
+    std::vector<hipMemGenericAllocationHandle_t> spacer_chunks;
+    void* spacer_va = nullptr; size_t spacer_va_used = 0, spacer_va_size = 0;
+    if (regions < 1) regions = 1;
+    if (regions > a->n) regions = (uint32_t)a->n;
+    // Physical memory is assigned in allocation order: every chunk is created AND mapped once, in index order, so that a
+    // chunk's index says where it lies (chunks far apart in index are far apart in memory - what the caller's spread
+    // selections rely on), then the mappings are taken away again (the reservation is retired, see above).
     void* va = nullptr;
     size_t mapped = 0;
-    if (err == hipSuccess) err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
+    std::vector<void*> spacers;
+    uint64_t spacer_held = 0;
+    hipMemAccessDesc desc;
+    memset(&desc, 0, sizeof(desc));
+    desc.location.type = hipMemLocationTypeDevice;
+    desc.location.id = device;
+    desc.flags = hipMemAccessFlagsProtReadWrite;
+    err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
     if (err == hipSuccess) {
-        for (; mapped < a->n; ++mapped) {
-            err = hipMemMap((char*)va + mapped * chunk, chunk, 0, a->handle[mapped], 0);
-            if (err != hipSuccess) break;
-        }
-        if (err == hipSuccess) {
-            hipMemAccessDesc desc;
-            memset(&desc, 0, sizeof(desc));
-            desc.location.type = hipMemLocationTypeDevice;
-            desc.location.id = device;
-            desc.flags = hipMemAccessFlagsProtReadWrite;
-            err = hipMemSetAccess(va, a->n * chunk, &desc, 1);
+        for (uint32_t r = 0; r < regions && err == hipSuccess; ++r) {
+            const size_t lo = a->n * r / regions, hi = a->n * (r + 1) / regions;
+            for (size_t i = lo; i < hi; ++i) {
+                err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
+                if (err != hipSuccess) break;
+                a->live[i] = 1;
+                err = hipMemMap((char*)va + i * chunk, chunk, 0, a->handle[i], 0);
+                if (err != hipSuccess) break;
+                mapped = i + 1;
+            }
+            if (err == hipSuccess && hi > lo) err = hipMemSetAccess((char*)va + lo * chunk, (hi - lo) * chunk, &desc, 1);
+            if (err == hipSuccess && r + 1 < regions && spacer_bytes > 0 && spacer_mode > 0) {
+                const size_t sc = (size_t)1 << 30;
+                const size_t cnt = (size_t)(spacer_bytes / sc);
+                if (spacer_mode == 2 && !spacer_va) {
+                    spacer_va_size = cnt * sc * (regions - 1);
+                    if (hipMemAddressReserve(&spacer_va, spacer_va_size, 0, nullptr, 0) != hipSuccess) { spacer_va = nullptr; (void)hipGetLastError(); }
+                }
+                for (size_t q = 0; q < cnt; ++q) {
+                    hipMemGenericAllocationHandle_t h;
+                    if (hipMemCreate(&h, sc, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+                    spacer_chunks.push_back(h); spacer_held += sc;
+                    if (spacer_mode == 2 && spacer_va) {
+                        if (hipMemMap((char*)spacer_va + spacer_va_used, sc, 0, h, 0) == hipSuccess) {
+                            (void)hipMemSetAccess((char*)spacer_va + spacer_va_used, sc, &desc, 1);
+                            spacer_va_used += sc;
+                        } else (void)hipGetLastError();
+                    }
+                }
+            } else if (err == hipSuccess && r + 1 < regions && spacer_bytes > 0) {
+                // the spacer is an optimisation: when the device cannot lend that much, take what it can (down to 1 GiB)
+                uint64_t want = spacer_bytes;
+                while (want >= ((uint64_t)1 << 30)) {
+                    void* sp = nullptr;
+                    if (hipMalloc(&sp, (size_t)want) == hipSuccess) { spacers.push_back(sp); spacer_held += want; break; }
+                    (void)hipGetLastError();
+                    want >>= 1;
+                }
+            }
         }
         drain_device(device);
+        for (void* sp : spacers) (void)hipFree(sp);
+        for (size_t off = 0; off < spacer_va_used; off += (size_t)1 << 30) (void)hipMemUnmap((char*)spacer_va + off, (size_t)1 << 30);
+        if (spacer_va) g_retired_address_bytes.fetch_add((unsigned long long)spacer_va_size);
+        for (auto h : spacer_chunks) (void)hipMemRelease(h);
         for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char*)va + i * chunk, chunk);
         g_retired_address_bytes.fetch_add((unsigned long long)(a->n * chunk));
     }
@@ -494,7 +569,17 @@ int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** are
     *arena = a;
     if (chunk_out) *chunk_out = chunk;
     if (chunks_out) *chunks_out = (uint32_t)a->n;
+    if (spacer_out) *spacer_out = spacer_held;
     return FG_OK;
+}
+
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out) {
+    return arena_create(device, bytes, chunk_bytes, 1, 0, arena, chunk_out, chunks_out, nullptr);
+}
+
+int fg_arena_create_spread(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
+                           void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out) {
+    return arena_create(device, bytes, chunk_bytes, regions, spacer_bytes, arena, chunk_out, chunks_out, spacer_out);
 }
 
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base) {
@@ -507,6 +592,8 @@ int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void*
         if (a->mapped_in[c] >= 0 || seen[c]) return fail(FG_ERR_BAD_ARG, "fg_arena_map: a chunk is mapped at one address at a time%s");
         seen[c] = 1;
     }
+    if (g_retired_address_bytes.load() > kRetiredAddressBudget)
+        return fail(FG_ERR_HIP, "fg_arena_map: the address-space budget of retired reservations (64 TiB) is spent%s");
     void* va = nullptr;
     hipError_t err = hipMemAddressReserve(&va, (size_t)count * a->chunk, 0, nullptr, 0);
     if (err != hipSuccess) return fail(FG_ERR_HIP, "hipMemAddressReserve failed: %s", hipGetErrorString(err));
@@ -611,15 +698,11 @@ int fg_step_hd(const FgParams* params, int B, int N,
     // 243 agents, >= 4096 envs: pipeline over env batches inside the launch (no index outputs, no World options):
     // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192 (round 1; 1.75 ms on placed buffers).
     if (N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
-        return launch_wide(a, (hipStream_t)stream);
+        return launch_wide<243, 0>(a, (hipStream_t)stream);
     // 81 agents: the pipelined kernel pays from 16 env batches per workgroup on (81 x 16384: 419 vs 448 us; 81 x 12288 equal,
     // 81 x 2048 62 vs 56: profiles/r03_step/pipelined_single_step_81.txt)
     if (N == 81 && B >= FG_WIDE81_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
-        return launch_wide(a, (hipStream_t)stream);
-#ifdef FG_EXP_STEP27_E
-    if (N == 27 && B >= 2048 && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
-        return launch_wide_v<27, 1, FG_EXP_STEP27_E, FG_EXP_STEP27_TW, false>(a, (hipStream_t)stream);
-#endif
+        return launch_wide<81, 0>(a, (hipStream_t)stream);
     return launch_step(a, (hipStream_t)stream);
 }
 
@@ -694,16 +777,11 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
     // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
-    if (K == 1 && ((N == 243 && B >= FG_WIDE243_MIN_B) || (N == 81 && B >= FG_WIDE81_MIN_B)) && !world_options_set(a.p))
-        return launch_wide(a, (hipStream_t)stream);                                                  // as fg_step_hd
-    if (K >= 2 && !world_options_set(a.p)) {
-        // 81 / 243 agents: the pipelined kernels keep one env on ONE producer wave (~15 / ~78 us of dependent work per
-        // step); a batch too small to hide that under other envs' stores is faster in step_kernel's K-loop, which spreads
-        // an env over 2 / 4 waves: 81 x 256 x 20 15.6 -> 12.5 us/step, 81 x 512 18.1 -> 16.1 (81 x 1024: 31.8 vs 33.2, stays),
-        // 243 x 64 x 8 77.8 -> 37.0, 243 x 256 81.8 -> 67.8 (243 x 257 on the pipelined kernel: 103; 243 x 512 equal) - profiles/r03_wide/ab_wide_small_kloop.txt
-        if ((N == 81 && B > FG_WIDE81_ROLL_MIN_B) || (N == 243 && B > FG_WIDE243_ROLL_MIN_B)) return launch_wide(a, (hipStream_t)stream);
-        if (N == 27 || N == 9 || N == 3) return launch_roll(a, (hipStream_t)stream);
+    if (K == 1 && !world_options_set(a.p)) {                                                         // as fg_step_hd
+        if (N == 243 && B >= FG_WIDE243_MIN_B) return launch_wide<243, 0>(a, (hipStream_t)stream);
+        if (N == 81 && B >= FG_WIDE81_MIN_B) return launch_wide<81, 0>(a, (hipStream_t)stream);
     }
+    if (K >= 2 && !world_options_set(a.p) && launch_pipelined(a, 0, (hipStream_t)stream, &rc)) return rc;
     return launch_step(a, (hipStream_t)stream);
 }
 
@@ -771,6 +849,32 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act; a.lm = landmarks;
     a.opos = obst_pos; a.ovel = obst_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
+    a.inv_n = (float)(1.0 / (double)N); a.inv_l = (float)(1.0 / (double)L);
+    hipStream_t st = (hipStream_t)stream;
+    if (sc->variant != 1) {
+        // the reference's own shapes: one env per lane, every count a compile-time constant (fg_scn_lane_kernel.hpp)
+        const int nbr = sc->kind == FG_SCN_PARTIAL ? sc->num_obs : N - 1;
+        bool launched = false;
+#define FG_SCN_LANE(KIND, NN, LL, MM, NBR)                                                                              \
+        if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
+            constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
+            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3((B + 63) / 64), dim3(128), lds, st, a);       \
+            launched = true;                                                                                                \
+        }
+        FG_SCN_LANE(FG_SCN_BASIC, 3, 3, 0, 2)            // basic_formation_env.py:7
+        FG_SCN_LANE(FG_SCN_PARTIAL, 5, 5, 0, 3)          // formation_hd_partial_env.py:15
+        FG_SCN_LANE(FG_SCN_RANGE, 4, 4, 0, 3)            // formation_hd_partial_range_env.py:15
+        FG_SCN_LANE(FG_SCN_OBSTACLE, 4, 4, 3, 3)         // formation_hd_obs_env.py:14
+        FG_SCN_LANE(FG_SCN_PARTIAL, 3, 5, 0, 3)          // make_env(name) passes its own default num_agents = 3 (__init__.py:6-11)
+        FG_SCN_LANE(FG_SCN_RANGE, 3, 4, 0, 2)
+        FG_SCN_LANE(FG_SCN_OBSTACLE, 3, 4, 3, 2)
+#undef FG_SCN_LANE
+        if (launched) {
+            const hipError_t err = hipGetLastError();
+            if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario launch failed: %s", hipGetErrorString(err));
+            return FG_OK;
+        }
+    }
 #ifndef FG_SCN_T
 #define FG_SCN_T 64           // threads per workgroup of the scenario kernel up to 64 entities per env
 #endif
@@ -785,7 +889,6 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         a.stage = (lds + stage <= 48 * 1024) ? 1 : 0;
         if (a.stage) lds += (int)stage;
     }
-    hipStream_t st = (hipStream_t)stream;
     if (G == 4) hipLaunchKernelGGL((scn_kernel<4, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
     else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
     else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
@@ -973,11 +1076,8 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     a.pl = pl; a.act_out = act_seq;
     hipStream_t st = (hipStream_t)stream;
-    // the specialised agent counts are powers of 3: the controller runs inside the pipelined kernels
-    if (per_layer == 3 && !world_options_set(a.p)) {
-        if (N == 81 || N == 243) return launch_wide<true>(a, st);
-        if (N == 27 || N == 9 || N == 3) return launch_roll<true>(a, st);
-    }
+    // N = per^L up to 243 agents (per 2, 3, 4, 5, 8): the controller runs inside the pipelined kernels, ONE launch
+    if (!world_options_set(a.p) && launch_pipelined(a, per_layer, st, &rc)) return rc;
     // everything else: K times (controller launch, single-step launch) chained on the stream - the same device
     // function on the same state, so the results equal the in-kernel loop's and fg_policy_bfs on the written rows
     const size_t bn = (size_t)B * N;

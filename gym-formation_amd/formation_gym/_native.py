@@ -14,7 +14,7 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_WALLS = 4
 AGENT_PROPS = 6                 # floats per row of FgParams.agent_props: mass, size, accel, max_speed, u_noise, c_noise
 
@@ -78,6 +78,8 @@ class FgScenario(ctypes.Structure):
         ("obstacle_vy", ctypes.c_float),
         ("obstacle_floor", ctypes.c_float),
         ("penalty", ctypes.c_float),
+        ("variant", ctypes.c_int32),            # 0 = library's choice, 1 = the run-time-count kernel
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -97,6 +99,8 @@ SIGNATURES = {
     "fg_last_error": (ctypes.c_char_p, []),
     "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64),
                              ctypes.POINTER(ctypes.c_uint32)]),
+    "fg_arena_create_spread": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(_P),
+                                    ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]),
     "fg_arena_map": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
     "fg_arena_unmap": (_I, [_P, _P]),
     "fg_arena_trim": (_I, [_P]),

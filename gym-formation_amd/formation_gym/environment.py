@@ -102,7 +102,7 @@ class MultiAgentEnv(object):
         self._launchers = {}              # pre-bound step launches, see _bound_step
         self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
         self.placement = None             # report of the last buffer placement probe (alloc_rollout_buffers)
-        self._arenas = []                 # placement.Arena objects behind placed buffers (kept alive with the env)
+        self._auto_out = {}               # (K, obs_every, policy) -> placed output buffers of rollout(out=None), see _default_out
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -169,7 +169,10 @@ class MultiAgentEnv(object):
             obs [K // obs_every, B, N, D]  (every obs_every-th step; obs_every = 1: every step)
             reward [K, B, N, 1], done [K, B, N] bool, info {'individual_reward': [K, B, N]}
         `out` may hold pre-allocated buffers (keys obs, reward, indiv, done with those shapes, done as
-        uint8), so that a training loop re-uses them."""
+        uint8), so that a training loop re-uses them.  out=None (the default): the env's own buffers for this (K,
+        obs_every), made on first use with the observation buffer PLACED (`alloc_rollout_buffers`: a 0.2 s probe once, then
+        every launch streams at the placed rate) and re-used by every later call - like `step`, the results are views that
+        the next `rollout` of the same shape overwrites.  out=False: fresh, ordinary tensors on every call."""
         roll = getattr(self.scenario, "rollout_batch", None)
         if roll is None:
             raise NotImplementedError("%s has no multi-step launch; call step()" % type(self.scenario).__name__)
@@ -188,8 +191,10 @@ class MultiAgentEnv(object):
             act = act.to(device=self._act.device, dtype=torch.float32).contiguous()
         B, N = self.num_envs, self.num_agents
         D = self._out["obs"].shape[-1]
-        own_buffers = out is not None
         if out is None:
+            out = self._default_out(K, obs_every, False)
+        own_buffers = out is not False
+        if out is False:
             f = dict(dtype=torch.float32, device=self._act.device)
             out = dict(obs=torch.empty((K // obs_every, B, N, D), **f), reward=torch.empty((K, B, N), **f),
                        indiv=torch.empty((K, B, N), **f),
@@ -246,8 +251,10 @@ class MultiAgentEnv(object):
         D = self._out["obs"].shape[-1]
         f = dict(dtype=torch.float32, device=self._act.device)
         want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N), act=(K, B, N, 2))
-        own_buffers = out is not None
         if out is None:
+            out = self._default_out(K, obs_every, True)
+        own_buffers = out is not False
+        if out is False:
             out = {k: (torch.zeros(shp, dtype=torch.uint8, device=self._act.device) if k == "done"
                        else torch.empty(shp, **f)) for k, shp in want.items()}
         # launches into CALLER-OWNED buffers are bound once (cf. rollout): a loop that steps K = 1 at a time pays one
@@ -283,6 +290,22 @@ class MultiAgentEnv(object):
             {"individual_reward": out["indiv"], "actions": out["act"]}
 
     # ------------------------------------------------------------ buffers
+    def _default_out(self, K, obs_every, policy):
+        """The env's own output buffers of `rollout(out=None)` / `rollout_policy(out=None)` for this shape: placed on
+        first use, kept for the next call (two shapes at most: a third evicts the least recently used, whose arena goes
+        back to the driver with its last tensor)."""
+        key = (int(K), int(obs_every), bool(policy))
+        out = self._auto_out.pop(key, None)
+        if out is None:
+            if getattr(self, "_placing", False):       # the probe's own timing launches bring their buffers
+                raise RuntimeError("rollout(out=None) inside a placement probe")
+            while len(self._auto_out) >= 2:
+                self._auto_out.pop(next(iter(self._auto_out)))
+            self._roll_launchers.clear()               # bindings keep evicted buffers alive
+            out = self.alloc_rollout_buffers(K, obs_every=obs_every, policy=policy)
+        self._auto_out[key] = out                      # most recently used last
+        return out
+
     def _snapshot(self):
         """Everything a launch mutates (device state + host counters), for probes that must leave the env untouched."""
         w, sc = self.world, self.scenario
@@ -305,15 +328,18 @@ class MultiAgentEnv(object):
         self._rng_offset, self.current_step, w.world_step = host
         sc._cache = None
 
-    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.7):
+    def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.5,
+                              max_arena_bytes=None):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
-        the bytes - PLACED: when it is larger than the Infinity Cache, candidate buffers are composed of physical chunks
-        spread over the device's free memory, this env's own K-step launch is timed on `candidates` of them and the
-        fastest is kept, every other chunk released (formation_gym/placement.py: the rate of a launch depends on where
-        in HBM its buffer lies, by 15-25 %); where the arena cannot be made, on up to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state is restored
-        afterwards.  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report is left in
-        `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`; it (and the env) keeps the arena
-        behind the observation tensor alive (`out['arena']`)."""
+        the bytes - PLACED: when it is larger than the Infinity Cache, candidate buffers are composed of the chunks of a
+        small arena of device memory (6 x the buffer up to 12 GiB, at least 1.5 x the buffer, never more than
+        `mem_fraction` of the free memory; `max_arena_bytes` overrides), this env's own K-step launch is timed on
+        `candidates` or more of them and the fastest is kept, every other chunk released (formation_gym/placement.py: the
+        rate of a launch depends on which physical memory its buffer is composed of, by 10-20 %; ~0.2 s); where the arena
+        cannot be made, on up to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state
+        is restored afterwards.  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report
+        is left in `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`.  The arena lives exactly
+        as long as the observation tensor (or any view of it): dropping the tensors gives the memory back."""
         from . import placement
         K, obs_every = int(K), int(obs_every)
         B, N = self.num_envs, self.num_agents
@@ -342,22 +368,26 @@ class MultiAgentEnv(object):
         snap = self._snapshot()
         acts = None if policy else torch.zeros((K, B, N, 2), **f)
 
+        per_layer = self._policy_per_layer() if policy else 0
+
         def time_fn(obs):
             out = dict(small, obs=obs)
             if policy:
-                self.rollout_policy(K, 3, out=out, obs_every=obs_every)
+                self.rollout_policy(K, per_layer, out=out, obs_every=obs_every)
             else:
                 self.rollout(acts, out=out, obs_every=obs_every)
             self._roll_launchers.clear()               # one binding per candidate window: do not let them pile up
 
         arena = None
-        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, trials=candidates, mem_fraction=mem_fraction)
+        self._placing = True
+        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, trials=candidates, mem_fraction=mem_fraction,
+                                       max_arena_bytes=max_arena_bytes)
         if placed is not None:
             flat, report, arena = placed
             obs = shaped(flat)
-            self._arenas.append(arena)
         else:
             obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
+        self._placing = False
         self._roll_launchers.clear()                   # bindings made on the candidates keep them alive: drop them,
         torch.cuda.empty_cache()                       # then hand the losers back to the driver
         self._restore(snap)
@@ -367,12 +397,21 @@ class MultiAgentEnv(object):
             report["kept_GBps"] = round(alg / (report["kept_ms"] * 1e-3) / 1e9, 1)
             report["worst_GBps"] = round(alg / (report["worst_ms"] * 1e-3) / 1e9, 1)
         self.placement = report
-        out = dict(small, obs=obs)
-        if arena is not None:
-            out["arena"] = arena
-        return out
+        return dict(small, obs=obs)
 
-    def place_step_buffers(self, candidates=8, mem_fraction=0.7):
+    def _policy_per_layer(self):
+        """Agents per layer of the built-in controller's hierarchy for this agent count (N = per^L): 3 where it fits (the
+        reference's README.md:34-36), else the smallest of 2 ... 8 that does."""
+        N = self.num_agents
+        for per in (3, 2, 4, 5, 6, 7, 8):
+            n = per
+            while n < N:
+                n *= per
+            if n == N:
+                return per
+        raise ValueError("the built-in controller needs N = per^L agents with 2 <= per <= 8, got %d" % N)
+
+    def place_step_buffers(self, candidates=8, mem_fraction=0.5):
         """The same placement for the per-step output buffer `step` writes into (only batches whose single-step
         observation tensor exceeds the Infinity Cache: 243 agents x >= 200 envs, 81 x >= 1700, 27 x >= 15 000)."""
         from . import placement
@@ -407,7 +446,6 @@ class MultiAgentEnv(object):
         if placed is not None:
             flat, report, arena = placed
             flat.zero_()
-            self._arenas.append(arena)
         else:
             flat, report = placement.probe_allocation(alloc, time_fn, nflat * 4, dev, candidates=candidates, mem_fraction=mem_fraction)
         self._flat, self._out = flat, views(flat)
@@ -605,4 +643,8 @@ class MultiAgentEnv(object):
                                   "is out of scope for the MI355X hot path")
 
     def close(self):
-        pass
+        """Drop the env's own placed buffers and bound launches: their arenas go back to the driver with the last tensor."""
+        self._auto_out.clear()
+        self._roll_launchers.clear()
+        self._launchers.clear()
+        self.scenario._cache = None

@@ -118,7 +118,8 @@ class Scenario(BaseScenario):
         self._launch(world, act, out, True, rng_offset, auto_reset)
 
     def _descriptor(self, world):
-        return _native.FgScenario(kind=_native.FG_SCN_BASIC, num_landmarks=len(world.landmarks), num_obstacles=0, penalty=1.0)
+        return _native.FgScenario(kind=_native.FG_SCN_BASIC, num_landmarks=len(world.landmarks), num_obstacles=0, penalty=1.0,
+                                  variant=int(getattr(self, "kernel_variant", 0)))   # 1: the run-time-count kernel (A/B runs)
 
     def _rollout_args(self, world, act_seq, out, obs_every):
         if out.get("obs") is not None and not out["obs"].is_contiguous():

@@ -115,7 +115,8 @@ class LandmarkScenario(BaseScenario):
                                   num_obstacles=self.num_obstacles, num_obs=int(self.num_obs),
                                   obs_range=float(self.obs_range), obstacle_size=self.OBSTACLE_SIZE,
                                   obstacle_vx=self.OBSTACLE_VEL[0], obstacle_vy=self.OBSTACLE_VEL[1],
-                                  obstacle_floor=self.OBSTACLE_FLOOR, penalty=self.PENALTY)
+                                  obstacle_floor=self.OBSTACLE_FLOOR, penalty=self.PENALTY,
+                                  variant=int(getattr(self, "kernel_variant", 0)))   # 1: the run-time-count kernel (A/B runs)
 
     def _launch(self, world, act, out, do_physics, rng_offset=0, auto_reset=False):
         lib = _native.load()

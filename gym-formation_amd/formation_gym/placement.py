@@ -10,9 +10,13 @@ contiguous allocation is the worst case, 2.0-2.6 TB/s, profiles/r02_place/).  No
 the host places the buffer:
 
   `probe_arena`       address space backed by separately created physical chunks (`fg_arena_*`: HIP virtual memory
-                      management), as large as the free memory allows; candidate buffers are composed of chunks SPREAD
-                      over the whole arena (one per stratum, shuffled) and timed with the caller's own launch; the best
+                      management); candidate buffers are composed of chunks SPREAD over the whole arena (one per
+                      stratum, shuffled; regions taken round-robin) and timed with the caller's own launch; the best
                       candidate's chunks are kept, all others go back to the driver.  Nothing is wasted afterwards.
+                      The arena need not be large (round 4, profiles/r04_place/arena_size.txt): what pays is the TIMED
+                      choice among compositions, not the distance - 6 x the buffer (8.6 GB for the 1.4 GB headline
+                      buffer) gives what 206 GB gave, 1.5 x gives it for buffers of several GB; placing chunks by rule
+                      without timing does not work (the driver decides where a chunk lies: spread_rule*.txt).
   `probe_allocation`  the fallback where the arena cannot be made: a few whole allocations held side by side, the
                       fastest kept (coarser: an allocation is one sample of the pattern).
 
@@ -97,10 +101,13 @@ def is_placed(address):
 
 
 class _Raw(object):
-    """A device address range as something torch.as_tensor understands."""
+    """A device address range as something torch.as_tensor understands.  torch keeps this object alive for as long as
+    the tensor's storage lives (any view of it included), and the object keeps the arena: a placed buffer's memory is
+    released when its last tensor goes away, not when some owner remembers to."""
 
-    def __init__(self, ptr, nfloats):
+    def __init__(self, ptr, nfloats, owner=None):
         self.__cuda_array_interface__ = {"shape": (int(nfloats),), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+        self.owner = owner
 
 
 class Arena(object):
@@ -108,20 +115,28 @@ class Arena(object):
     gives a device address range made of exactly those chunks; a chunk is mapped at one address at a time.  Tensors made
     by `floats()` are views of a mapping: keep the Arena alive as long as they are in use."""
 
-    def __init__(self, nbytes, device, chunk_bytes=0):
+    def __init__(self, nbytes, device, chunk_bytes=0, regions=1, spacer_bytes=0):
+        """regions > 1 (`fg_arena_create_spread`): the chunks come in `regions` groups of consecutive indices that lie
+        `spacer_bytes` apart in physical memory (the spacers are held only while the arena is being created)."""
         self.device = torch.device(device)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        handle, chunk, count = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
-        _native.check(_native.load().fg_arena_create(int(index), int(nbytes), int(chunk_bytes), ctypes.byref(handle),
-                                                     ctypes.byref(chunk), ctypes.byref(count)))
+        handle, chunk, count, held = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint64()
+        if regions > 1:
+            _native.check(_native.load().fg_arena_create_spread(int(index), int(nbytes), int(chunk_bytes), int(regions),
+                                                                int(spacer_bytes), ctypes.byref(handle), ctypes.byref(chunk),
+                                                                ctypes.byref(count), ctypes.byref(held)))
+        else:
+            _native.check(_native.load().fg_arena_create(int(index), int(nbytes), int(chunk_bytes), ctypes.byref(handle),
+                                                         ctypes.byref(chunk), ctypes.byref(count)))
         self._handle, self.chunk, self.chunks = handle, int(chunk.value), int(count.value)
+        self.regions, self.spacer_held = max(1, int(regions)), int(held.value)
         self.kept_range = (0, 0)          # address range of the spread buffer kept in the end (see is_placed)
         import weakref
         _live_arenas.append(weakref.ref(self))
 
     def floats(self, address, nfloats):
         """A flat float32 tensor over `nfloats` floats at a device address inside one of the arena's mappings."""
-        return torch.as_tensor(_Raw(int(address), nfloats), device=self.device)
+        return torch.as_tensor(_Raw(int(address), nfloats, self), device=self.device)
 
     def map(self, chunk_index):
         """The given chunks (any order) mapped at fresh contiguous addresses; returns the base address."""
@@ -150,14 +165,24 @@ class Arena(object):
             pass
 
 
-def arena_geometry(nbytes, free_bytes, mem_fraction=0.7, max_arena_bytes=192 << 30):
+def default_arena_bytes(nbytes):
+    """Arena size the probe takes by default: 6 x the buffer up to 12 GiB, at least 1.5 x the buffer
+    (profiles/r04_place/arena_size.txt: the 1.4 GB headline buffer runs at 11.8-12.1 us/step from an 8.6 GB arena, 11.7-12.0
+    from 206 GB, 12.2-13.0 from 4.3 GB; the 6.4 GB buffer of 81 x 2048 x 20 at 50.3-51.6 from 10 GB and 50.5-50.7 from 206)."""
+    return int(max(1.5 * nbytes, min(6 * nbytes, 12 << 30)))
+
+
+def arena_geometry(nbytes, free_bytes, mem_fraction=0.5, max_arena_bytes=None):
     """(arena bytes, chunk bytes) for a buffer of `nbytes` on a device with `free_bytes` free, or None when there is no
     room to choose from.  8 ... 16 chunks per buffer, 32 MiB ... 1 GiB each (the chunk size itself does not matter:
-    profiles/r03_place/spread_*); the arena takes `mem_fraction` of the free memory (a buffer larger than half of that:
-    1.5 x the buffer, at most 0.9 of the free memory); at most ~2000 chunks per arena (driver calls, page tables)."""
+    profiles/r03_place/spread_*); the arena is `default_arena_bytes` (or `max_arena_bytes`), never more than `mem_fraction`
+    of the free memory (a buffer larger than half of that: 1.5 x the buffer, at most 0.9 of the free memory); at most ~2000
+    chunks per arena (driver calls, page tables)."""
     chunk = 32 << 20
     while chunk < (1 << 30) and nbytes // chunk > 16:
         chunk <<= 1
+    if max_arena_bytes is None:
+        max_arena_bytes = default_arena_bytes(nbytes)
     total = int(min(max_arena_bytes, mem_fraction * free_bytes))
     if total < 2 * nbytes:
         total = int(min(0.9 * free_bytes, 1.5 * nbytes))          # a huge buffer: at least some room to shuffle in
@@ -168,7 +193,7 @@ def arena_geometry(nbytes, free_bytes, mem_fraction=0.7, max_arena_bytes=192 << 
     return total, chunk
 
 
-def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.7, max_arena_bytes=192 << 30, reps=3,
+def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_bytes=None, reps=3,
                 min_bytes=MIN_PROBE_BYTES, seed=0, budget_s=1.0):
     """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor lives in the arena, which the caller keeps
     alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back to

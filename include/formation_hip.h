@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 6
+#define FG_ABI_VERSION 7
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -150,7 +150,10 @@ typedef struct FgParams {
  *   num_obs         formation_hd_partial_env.py:15,44 ring neighbours observed
  *   obs_range       formation_hd_partial_range_env.py:15,46 clip of relative positions
  *   obstacle_size   formation_hd_obs_env.py:39;  obstacle_v{x,y}, obstacle_floor  :84-89
- *   penalty         reward per collision: 1 (basic/partial/range), 2 (obstacle, :92-98)          */
+ *   penalty         reward per collision: 1 (basic/partial/range), 2 (obstacle, :92-98)
+ * At the reference's own shapes - basic (N, L) = (3, 3), partial (5, 5, num_obs 3), range (4, 4), obstacle (4, 4, M 3), and
+ * what make_env's default num_agents = 3 makes of the last three - a launch runs the one-env-per-lane kernel
+ * (csrc/fg_scn_lane_kernel.hpp: every count a compile-time constant), else the run-time-count kernel; same results.   */
 typedef enum FgScenarioKind {
     FG_SCN_BASIC = 1, FG_SCN_PARTIAL = 2, FG_SCN_RANGE = 3, FG_SCN_OBSTACLE = 4
 } FgScenarioKind;
@@ -166,6 +169,9 @@ typedef struct FgScenario {
     float obstacle_vy;
     float obstacle_floor;
     float penalty;
+    int32_t variant;         /* 0 = the library's choice of kernel; 1 = the run-time-count kernel even where a
+                                one-env-per-lane instantiation exists (tests / A-B runs: the two agree bit for bit) */
+    int32_t reserved;
 } FgScenario;
 
 /* Placed device memory ------------------------------------------------------
@@ -187,10 +193,21 @@ typedef struct FgScenario {
  * usable.  An address range that has held a mapping is never used again in this process: hipMemUnmap leaves the GPU's
  * translations of it behind on this stack (profiles/r03_place/va_reuse_check.txt), so the library retires the reservation
  * instead of freeing it - that costs address space only (fg_arena_retired_address_bytes: the running total; a placement of
- * a 1.4 GB buffer retires ~250 GB of the 128 TiB), the physical memory goes back at trim / destroy.
+ * a 1.4 GB buffer retires ~250 GB of the 128 TiB; once 64 TiB are retired fg_arena_create / _map refuse with FG_ERR_HIP and the
+ * caller uses ordinary allocations), the physical memory goes back at trim / destroy.
  * These are the only entry points that allocate; they enqueue nothing and take no stream.  Calls on ONE arena must not
  * run concurrently (the arena is the caller's object; different arenas are independent). */
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
+/* Placement BY RULE, without timing candidates: what makes a buffer fast is that chunks which are CONSECUTIVE IN THE BUFFER
+ * lie far apart in physical memory (profiles/r03_place/selection_rules_*.txt).  fg_arena_create_spread creates an arena no
+ * larger than the buffer whose chunks come in `regions` groups of consecutive indices (group r = chunks
+ * [n r / regions, n (r + 1) / regions)); between two groups the call holds `spacer_bytes` of device memory - allocated,
+ * never touched, freed before it returns - so that the groups end up that far apart.  The caller then maps the chunks
+ * round-robin over the groups (fg_arena_map with indices g0[0], g1[0], .., g0[1], g1[1], ..).  When the device cannot
+ * lend the spacer, smaller ones are tried (halving down to 1 GiB, then none): *spacer_out = bytes actually held between
+ * the groups in total.  Everything else as fg_arena_create. */
+int fg_arena_create_spread(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
+                           void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out);
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
 int fg_arena_unmap(void* arena, void* base);
 int fg_arena_trim(void* arena);

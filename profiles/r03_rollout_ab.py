@@ -25,7 +25,8 @@ for item in sys.argv[1:]:
     env.world.step_count.copy_((torch.arange(B, dtype=torch.int32, device=dev) * 7) % 100)
     gen = torch.Generator(device=dev); gen.manual_seed(5)
     acts = torch.rand((K, B, N, 2), device=dev, generator=gen) * 2 - 1
-    out = env.alloc_rollout_buffers(K, candidates=int(os.environ.get("FG_AB_CANDIDATES", "8")))
+    out = env.alloc_rollout_buffers(K, candidates=int(os.environ.get("FG_AB_CANDIDATES", "8")),
+                                    max_arena_bytes=int(float(os.environ.get("FG_AB_ARENA_GB", "192")) * (1 << 30)))
     digest = ""
     if os.environ.get("FG_AB_DIGEST"):
         env.rollout(acts, out=out)
@@ -54,6 +55,6 @@ for item in sys.argv[1:]:
     gbs = (24 * N * N + 53 * N + 16) * B / us / 1e3
     pl = env.placement or {}
     print("%d x %d, %d steps per launch: %.2f us/step (min %.2f max %.2f)  %.0f GB/s  %.1f %%  probe %s%s" % (
-        N, B, K, us, blocks[0], blocks[-1], gbs, gbs / 80, pl.get("spread_ms_min_median_max", []), digest), flush=True)
+        N, B, K, us, blocks[0], blocks[-1], gbs, gbs / 80, [pl.get("arena_GB"), pl.get("kept"), pl.get("probe_seconds")] + pl.get("spread_ms_min_median_max", []), digest), flush=True)
     del env, out, acts
     torch.cuda.empty_cache()

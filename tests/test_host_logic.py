@@ -58,8 +58,9 @@ def test_reference_style_scenario_files_take_the_callback_adapter():
 
 
 def test_arena_geometry_for_the_bench_shapes():
-    """placement.arena_geometry: 8-16 chunks per buffer (32 MiB - 1 GiB each), the arena 0.7 of the free memory capped at
-    192 GiB, at most ~2000 chunks, None when there is nothing to choose from (host arithmetic, no GPU)."""
+    """placement.arena_geometry: 8-16 chunks per buffer (32 MiB - 1 GiB each); the arena is SMALL - 6 x the buffer up to
+    12 GiB, at least 1.5 x the buffer (profiles/r04_place/arena_size.txt) - never more than `mem_fraction` of the free
+    memory, None when there is nothing to choose from (host arithmetic, no GPU)."""
     from formation_gym import placement
     free = 308 * 10 ** 9
     for nbytes in (1433 * 10 ** 6, 6450 * 10 ** 6, 46438 * 10 ** 6, 324 * 10 ** 6, 11627 * 10 ** 6):
@@ -67,10 +68,13 @@ def test_arena_geometry_for_the_bench_shapes():
         W = -(-nbytes // chunk)
         assert chunk & (chunk - 1) == 0 and (32 << 20) <= chunk <= (1 << 30)
         assert W <= 16 or chunk == (1 << 30)
-        assert total <= 192 << 30 and total <= 0.7 * free + 1 and total // chunk <= 2048 and total >= 2 * nbytes
-    total, chunk = placement.arena_geometry(93 * 10 ** 9, 300 * 10 ** 9)        # 243 x 65536: more than half of the arena
+        assert 1.5 * nbytes - 1 <= total <= max(1.5 * nbytes, 12 << 30) + 1 and total <= 0.5 * free + 1 and total // chunk <= 2048
+        assert total >= nbytes + 2 * chunk
+    assert placement.arena_geometry(1433 * 10 ** 6, free)[0] == 6 * 1433 * 10 ** 6          # the headline buffer: 8.6 GB
+    assert placement.arena_geometry(1433 * 10 ** 6, free, max_arena_bytes=192 << 30)[0] == int(0.5 * free)   # the round-3 probe, on request
+    total, chunk = placement.arena_geometry(93 * 10 ** 9, 300 * 10 ** 9)        # 243 x 65536: 1.5 x the buffer
     assert chunk == 1 << 30 and 93 * 10 ** 9 + 2 * chunk <= total <= 0.9 * 300 * 10 ** 9
     assert placement.arena_geometry(93 * 10 ** 9, 96 * 10 ** 9) is None         # no room to shuffle in
     assert placement.arena_geometry(10 ** 9, 10 ** 9) is None
     # two ranks sharing a device halve the fraction
-    assert placement.arena_geometry(1433 * 10 ** 6, free, mem_fraction=0.35)[0] <= 0.35 * free + 1
+    assert placement.arena_geometry(1433 * 10 ** 6, 10 ** 10, mem_fraction=0.25)[0] <= 0.25 * 10 ** 10 + 1
