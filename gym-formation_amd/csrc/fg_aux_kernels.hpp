@@ -204,6 +204,7 @@ struct ScnArgs {
     int stage;     // compose the workgroup's observation rows in LDS and stream them out as ONE contiguous span
     int K;         // steps per launch (fg_rollout_scenario; 1 otherwise): act / reward / indiv / done / near_ag [K][B]...,
     int obs_every; // obs [K / obs_every][B][N][D]
+    float coll_scale;     // per-agent tables (FgParams.agent_props): penalty distance of a pair = coll_scale * (size_a + size_b)
     float inv_n, inv_l;   // 1 / N, 1 / L, correctly rounded on the host: the run-time-count kernel and the one-env-per-lane
                           // kernels (compile-time counts) must multiply by the very same values (cf. Args.inv_n)
 };
@@ -283,7 +284,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     for (int l = i; live && l < L; l += G) LM[l] = reinterpret_cast<const float2*>(a.lm)[(size_t)b * L + l];
     int t_step = (live && a.step) ? a.step[b] : 0;
     __syncthreads();
-    const float my_size = 0.5f * (i < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+    // agents of different mass / size / accel / max_speed / u_noise (FgParams.agent_props; core.py:45-109): the lane's own row;
+    // its partners' mass and size are read from the table in the pair loops (a cold path: no reference scenario has them).
+    // The obstacles keep the scenario's size and Entity's default mass 1 (formation_hd_obs_env.py:36-42).
+    const bool het = a.p.agent_props != nullptr;
+    const AgentProps me = agent_props_of(a.p, i, het && i < N);
+    const float my_size = i < N ? (het ? me.size : 0.5f * a.p.dist_min) : 0.5f * (2.0f * a.sc.obstacle_size);
+    const float my_mass = het ? (i < N ? me.mass : 1.0f) : a.p.mass;
     const int KS = a.K > 1 ? a.K : 1;
     float2 u_next = make_float2(0.f, 0.f);              // the action of step ks + 1 is fetched while step ks runs
     if (a.do_phys && is_agent) u_next = reinterpret_cast<const float2*>(a.act)[sidx];
@@ -310,7 +317,9 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                 for (int t = 0; t < 4; ++t) {
                     const int j = j0 + t;
                     const float2 q = qq[t];
-                    const float dmin = my_size + 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+                    float size_j = 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
+                    if (het && j < N) size_j = a.p.agent_props[(size_t)j * FG_AGENT_PROPS + 1];
+                    const float dmin = my_size + size_j;
                     const float cut = dmin + 18.0f * k;
                     const float dx = p.x - q.x, dy = p.y - q.y;
                     const float d2 = dx * dx + dy * dy;
@@ -318,20 +327,21 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                         const float d = __builtin_amdgcn_sqrtf(d2);
                         const float x = (dmin - d) / k;
                         const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
-                        const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                        float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                        if (het) c = ((j < N ? a.p.agent_props[(size_t)j * FG_AGENT_PROPS] : 1.0f) / my_mass) * c;   // core.py:314-317
                         fx += dx * c; fy += dy * c;
                     }
                 }
             }
             if (is_agent) {
                 const float2 u = u_now;
-                const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, off);   // uniform agents (no per-agent table in these scenarios)
+                const float2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, off);
                 fx += fa.x; fy += fa.y;
             }
             if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
-            v.x = v.x * (1.0f - a.p.damping) + (fx / a.p.mass) * a.p.dt;
-            v.y = v.y * (1.0f - a.p.damping) + (fy / a.p.mass) * a.p.dt;
-            if (is_agent) v = clamp_speed(a.p.max_speed, v);
+            v.x = v.x * (1.0f - a.p.damping) + (fx / my_mass) * a.p.dt;
+            v.y = v.y * (1.0f - a.p.damping) + (fy / my_mass) * a.p.dt;
+            if (is_agent) v = clamp_speed(me.max_speed, v);
             p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
             POST[i] = p;
             if (is_agent) {
@@ -424,10 +434,15 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             for (int t = 0; t < 4; ++t) {
                 const int j = j0 + t;
                 const float dx = qq[t].x - p.x, dy = qq[t].y - p.y;
-                cnt += (j < N && (kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < thr2) ? 1 : 0;
+                float t2 = thr2;
+                if (het && j < N) {                               // is_collision per pair: dist < size_a + size_b
+                    const float tj = a.coll_scale * (my_size + a.p.agent_props[(size_t)j * FG_AGENT_PROPS + 1]);
+                    t2 = tj * tj;
+                }
+                cnt += (j < N && (kind == FG_SCN_BASIC || j != i) && dx * dx + dy * dy < t2) ? 1 : 0;
             }
         }
-        const float ot = 0.5f * a.p.dist_min + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
+        const float ot = (het ? my_size : 0.5f * a.p.dist_min) + a.sc.obstacle_size, ot2 = (float)((double)ot * (double)ot);
         for (int j = N; j < NE; ++j) {
             const float dx = POST[j].x - p.x, dy = POST[j].y - p.y;
             cnt += (dx * dx + dy * dy < ot2) ? 1 : 0;

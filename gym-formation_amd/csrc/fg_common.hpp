@@ -242,12 +242,13 @@ FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
 // ---------------------------------------------------------------------------
 // World options no reference scenario enables: walls, motor noise, speed clamp
 // ---------------------------------------------------------------------------
-// core.py:325-362 get_wall_collision_force, summed over the walls (hard walls, no ghosts)
-FG_DEV void wall_forces(const KParams& P, real2 p, real size, real& fx, real& fy) {
+// core.py:325-362 get_wall_collision_force, summed over the walls; a ghost entity passes through soft walls (:326-327)
+FG_DEV void wall_forces(const KParams& P, real2 p, real size, real& fx, real& fy, bool ghost = false) {
 #pragma unroll
     for (int w = 0; w < FG_MAX_WALLS; ++w) {                                   // static indices: no scratch copy
         if (w >= P.num_walls) break;
         const FgWall wl = P.walls[w];
+        if (ghost && wl.soft) continue;
         const real prll = wl.vertical ? p.y : p.x;
         const real perp = wl.vertical ? p.x : p.y;
         if (prll < wl.end0 - size || prll > wl.end1 + size) continue;      // beyond the endpoints
@@ -279,12 +280,14 @@ FG_DEV real2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset)
 // One agent's own properties (core.py:45-109): the World-wide scalars of FgParams, or its row of FgParams.agent_props
 struct AgentProps {
     real mass, size, accel, max_speed, u_noise, sens;
+    int flags;                 // FG_AGENT_IMMOVABLE | FG_AGENT_NO_COLLIDE | FG_AGENT_GHOST (core.py:54-58); 0 = an ordinary agent
 };
 FG_DEV AgentProps agent_props_of(const KParams& P, int i, bool in_range) {
-    AgentProps q = {P.mass, real(0.5f) * P.dist_min, P.accel, P.max_speed, P.u_noise, P.sensitivity};
+    AgentProps q = {P.mass, real(0.5f) * P.dist_min, P.accel, P.max_speed, P.u_noise, P.sensitivity, 0};
     if (P.agent_props && in_range) {
         const auto* r = P.agent_props + (size_t)i * FG_AGENT_PROPS;
         q.mass = r[0]; q.size = r[1]; q.accel = r[2]; q.max_speed = r[3]; q.u_noise = r[4];
+        q.flags = (int)r[6];
         q.sens = (q.accel > 0.0f) ? q.accel : P.sensitivity;               // environment.py:218-220
     }
     return q;

@@ -85,9 +85,13 @@ FG_DEV real2 contact_force_packed(const real* __restrict__ QX, const real* __res
 // contact distance of a pair is size_i + size_j (core.py:307) and agent i receives force_ratio = m_j / m_i times the
 // pair's force (core.py:314-317: force_a = (m_b / m_a) f, force_b = -(m_a / m_b) f - for either role of i that is
 // (m_j / m_i) * contact_force * (p_i - p_j) / d * penetration).  Plain loop, ascending j as the reference accumulates.
+// FL[j] = partner j's flags (FG_AGENT_*): a pair needs both to collide (core.py:292-293); against an immovable partner
+// the force is taken as it is, not scaled by the mass ratio (:319-321).  (An immovable agent's own force is never used.)
 FG_DEV real2 contact_force_het(const real* __restrict__ QX, const real* __restrict__ QY, const real* __restrict__ MS,
-                               const real* __restrict__ SZ, int N, int i, real2 p, real m_i, real s_i, real cf, real kmargin) {
+                               const real* __restrict__ SZ, const real* __restrict__ FL, int N, int i, real2 p, real m_i,
+                               real s_i, int flags_i, real cf, real kmargin) {
     real fx = 0.0f, fy = 0.0f;
+    if (flags_i & (FG_AGENT_IMMOVABLE | FG_AGENT_NO_COLLIDE)) return make_real2(fx, fy);
     const real inv_k = 1.0f / kmargin;
     const real inv_m = 1.0f / m_i;
     const real far = (FG_F64 ? 40.0f : 18.0f) * kmargin;
@@ -96,11 +100,13 @@ FG_DEV real2 contact_force_het(const real* __restrict__ QX, const real* __restri
         const real d2 = dx * dx + dy * dy;
         const real dmin = s_i + SZ[j];
         const real cut = dmin + far;
-        if (j != i && d2 < cut * cut) {
+        const int fj = (int)FL[j];
+        if (j != i && d2 < cut * cut && !(fj & FG_AGENT_NO_COLLIDE)) {
             const real d = hw_sqrt(d2);
             const real x = (dmin - d) * inv_k;
             const real pen = kmargin * (rmax(x, real(0)) + hw_log(1.0f + hw_exp(-rabs(x))));
-            const real c = (MS[j] * inv_m) * (cf * pen * hw_rcp(d));
+            const real ratio = (fj & FG_AGENT_IMMOVABLE) ? real(1) : MS[j] * inv_m;
+            const real c = ratio * (cf * pen * hw_rcp(d));
             fx += dx * c;
             fy += dy * c;
         }

@@ -57,14 +57,25 @@ __host__ __device__ constexpr int scn_obs_dim(int kind, int n, int l, int m, int
 __host__ __device__ constexpr int scn_lane_pitch(int units) { return units | 1; }
 
 // NBR: neighbours observed = num_obs (partial) or N - 1 (the other kinds)
-// LDS of one workgroup, in float2 units: the observation block [64][SU], then reward / individual reward / done of the
+// LDS of one hand-over block: the observation block [64][SU] (float2), then reward / individual reward / done of the
 // 64 x N agents as three arrays of 64 N dwords
-__host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int m, int nbr) {
+__host__ __device__ constexpr int scn_lane_block_bytes(int kind, int n, int l, int m, int nbr) {
     return 64 * scn_lane_pitch(n * scn_obs_dim(kind, n, l, m, nbr) / 2) * 8 + 3 * 64 * n * 4;
+}
+// Two blocks (the producer composes step k+1 while the writer streams step k: one barrier per step, nobody waits for the
+// compose) where four workgroups per CU still fit the 160 KiB - basic_formation_env's 16 KiB blocks; the larger rows of
+// the other scenarios keep ONE block and two barriers per step (two blocks would halve the workgroups per CU).
+__host__ __device__ constexpr bool scn_lane_double(int kind, int n, int l, int m, int nbr) {
+    return 2 * scn_lane_block_bytes(kind, n, l, m, nbr) <= 40 * 1024;
+}
+__host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int m, int nbr) {
+    return (scn_lane_double(kind, n, l, m, nbr) ? 2 : 1) * scn_lane_block_bytes(kind, n, l, m, nbr);
 }
 
 template <int KIND, int N, int L, int M, int NBR>
 __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
+    constexpr bool DB = scn_lane_double(KIND, N, L, M, NBR);
+    constexpr int BLOCK_UNITS = scn_lane_block_bytes(KIND, N, L, M, NBR) / 8;   // float2 units from one block to the next
     constexpr int NE = N + M;
     constexpr int G = scn_group_lanes(NE);
     constexpr int D = scn_obs_dim(KIND, N, L, M, NBR);
@@ -72,12 +83,16 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
     constexpr int SU = scn_lane_pitch(U);
     constexpr bool BASIC = KIND == FG_SCN_BASIC;
     static_assert(NE <= 8 && L <= 8, "one env per lane: a handful of entities");
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float* const s_rew = reinterpret_cast<float*>(smem + 64 * SU);
-    float* const s_ind = s_rew + 64 * N;
-    uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + 64 * N);
+    extern __shared__ __attribute__((aligned(16))) float2 smem_all[];
     const int lane = threadIdx.x & 63;
-    const int b0 = blockIdx.x * 64;
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2: consecutive workgroup ids take consecutive
+    // 64-env spans WITHIN an XCD's eighth of the batch, so that the cache lines two neighbouring spans share (done bytes,
+    // the ends of an observation span) meet in one L2 instead of leaving two XCDs as partial-line writes.
+    // (the host launches 8 x ceil(workgroups / 8) of them; the ones beyond the batch leave at once)
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int b0 = wg * 64;
+    if (b0 >= a.B) return;                              // uniform over the workgroup, before any barrier
     const int b = b0 + lane;
     const bool live = b < a.B;
     const int bl = live ? b : a.B - 1;                  // loads of a lane beyond the batch stay in range; it stores nothing
@@ -87,8 +102,12 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
     if (threadIdx.x >= 64) {
         // ---- WRITER wave: block ks (published at barrier B) -> global memory, while the producer computes step ks + 1 ----
         for (int ks = 0; ks < KS; ++ks) {
-            __syncthreads();                            // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
+            if (!DB) __syncthreads();                   // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
             __syncthreads();                            // B: the block of step ks is complete
+            const float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
+            const float* const s_rew = reinterpret_cast<const float*>(smem + 64 * SU);
+            const float* const s_ind = s_rew + 64 * N;
+            const uint32_t* const s_done = reinterpret_cast<const uint32_t*>(s_ind + 64 * N);
             const size_t kb = (size_t)ks * a.B;
             const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;
             if (want_obs) {
@@ -321,7 +340,13 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
         }
         // ---- hand-over: the lane's [N][D] observation block and its rewards into LDS, for the writer wave ----
         const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;      // uniform over the launch
-        __syncthreads();                                // A: the writer has read the block of step ks - 1
+        // one block: A - the writer has read the block of step ks - 1.  Two blocks: block (ks & 1) was last read for step
+        // ks - 2, which the writer finished before it arrived at barrier B of step ks - 1
+        if (!DB) __syncthreads();
+        float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
+        float* const s_rew = reinterpret_cast<float*>(smem + 64 * SU);
+        float* const s_ind = s_rew + 64 * N;
+        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + 64 * N);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             s_rew[lane * N + i] = shared; s_ind[lane * N + i] = indiv[i]; s_done[lane * N + i] = done_flag;

@@ -73,7 +73,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     // every env: one copy per workgroup) and each env's communication states - FgParams.agent_props / comm_state
     real* const MS = scratch + 72;
     real* const SZ = MS + NP;
-    real2* const CT = reinterpret_cast<real2*>(SZ + NP) + (e < E ? e : 0) * N;
+    real* const FL = SZ + NP;                        // per-agent flags (FG_AGENT_*), as numbers
+    real2* const CT = reinterpret_cast<real2*>(FL + NP) + (e < E ? e : 0) * N;
     const bool het = OPTS && a.p.agent_props != nullptr;
     const bool comm = OPTS && FLAT && a.p.comm_state != nullptr;
     const AgentProps me = agent_props_of(a.p, i, OPTS && i < N);
@@ -108,7 +109,9 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     if (env_ok && pre_step) t_step = pre_step[b];
     if (tid < 2) reset_flag[tid] = 0;
     if constexpr (OPTS) {
-        if (het && e == 0 && i < NP) { MS[i] = i < N ? me.mass : real(1); SZ[i] = i < N ? me.size : real(0); }
+        if (het && e == 0 && i < NP) {
+            MS[i] = i < N ? me.mass : real(1); SZ[i] = i < N ? me.size : real(0); FL[i] = i < N ? (real)me.flags : real(0);
+        }
         if (comm && valid) CT[i] = reinterpret_cast<const real2*>(a.p.comm_state)[sidx];
     }
     __syncthreads();
@@ -125,23 +128,25 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             if (valid) {
                 const real2 u = reinterpret_cast<const real2*>(a.act)[((size_t)k * pre_B + b) * N + i];
                 real2 f;
-                if (het) f = contact_force_het(QX, QY, MS, SZ, N, i, p, me.mass, me.size, a.p.contact_force, a.p.contact_margin);
+                if (het) f = contact_force_het(QX, QY, MS, SZ, FL, N, i, p, me.mass, me.size, me.flags, a.p.contact_force, a.p.contact_margin);
                 else f = contact_force_packed<NPS, UNR>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                         a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
                     const real2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p) + k);
                     f.x += fa.x; f.y += fa.y;
-                    if (a.p.num_walls > 0) wall_forces(a.p, p, me.size, f.x, f.y);
+                    if (a.p.num_walls > 0) wall_forces(a.p, p, me.size, f.x, f.y, (me.flags & FG_AGENT_GHOST) != 0);
                 } else {
                     f.x += a.p.mass * (a.p.sensitivity * u.x);
                     f.y += a.p.mass * (a.p.sensitivity * u.y);
                 }
                 const real m_own = OPTS ? me.mass : a.p.mass;
-                v.x = v.x * one_minus_damp + (f.x / m_own) * dt;
-                v.y = v.y * one_minus_damp + (f.y / m_own) * dt;
-                if constexpr (OPTS) v = clamp_speed(me.max_speed, v);
-                p.x += v.x * dt;
-                p.y += v.y * dt;
+                if (!(OPTS && (me.flags & FG_AGENT_IMMOVABLE))) {        // core.py:266-267: an immovable entity keeps its state
+                    v.x = v.x * one_minus_damp + (f.x / m_own) * dt;
+                    v.y = v.y * one_minus_damp + (f.y / m_own) * dt;
+                    if constexpr (OPTS) v = clamp_speed(me.max_speed, v);
+                    p.x += v.x * dt;
+                    p.y += v.y * dt;
+                }
                 A[i] = p; V[i] = v; NV[i] = make_real2(-v.x, -v.y);
                 PX[i] = p.x; PY[i] = p.y;
             }
@@ -171,7 +176,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             if (valid)
                 reward_pass_packed<IDX, NPS, UNR>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
                                         rowmin, colmin, cnt, arg_lm, arg_ag);
-            if (het && valid) cnt = collision_count_het(PX, PY, SZ, N, i, p, me.size, a.coll_scale);   // per-pair penalty distance
+            if (het && valid)                                // per-pair penalty distance; `if agent.collide:` (formation_hd_env.py:71)
+                cnt = (me.flags & FG_AGENT_NO_COLLIDE) ? 0 : collision_count_het(PX, PY, SZ, N, i, p, me.size, a.coll_scale);
             real red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (real)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
             const real H = rsqrt_(rmax(red[0], red[1]));
@@ -272,7 +278,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         if constexpr (OPTS) {                  // communication block: c_j of the other agents, j ascending
                             const unsigned jc = u - (unsigned)N;
                             if (comm && jc < (unsigned)(N - 1)) {
-                                const real2* C = reinterpret_cast<const real2*>(SZ + NP) + ee * N;
+                                const real2* C = reinterpret_cast<const real2*>(FL + NP) + ee * N;
                                 val = C[jc + (jc >= row ? 1u : 0u)];
                             }
                         }

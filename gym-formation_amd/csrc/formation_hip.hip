@@ -62,20 +62,27 @@ static int visible_devices() {
     static const int n = [] { int c = 0; return hipGetDeviceCount(&c) == hipSuccess ? c : 1; }();
     return n;
 }
+// the device a launch with this stream and this first data pointer belongs to; -1 = cannot tell (stay on the current device)
+static int resolve_device(void* stream, const void* data) {
+    if (stream) {
+        hipDevice_t sdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess) return (int)sdev;
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (data) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, data) == hipSuccess && attr.type == hipMemoryTypeDevice) return attr.device;
+        (void)hipGetLastError();                                 // a host / unknown pointer: leave the error state clean
+    }
+    return -1;
+}
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
     DeviceGuard(void* stream, const void* data) {
         if (visible_devices() < 2) return;
-        int target = -1;
-        hipDevice_t sdev = -1;
-        if (stream) {
-            if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess) target = (int)sdev;
-        } else if (data) {
-            hipPointerAttribute_t attr;
-            if (hipPointerGetAttributes(&attr, data) == hipSuccess && attr.type == hipMemoryTypeDevice) target = attr.device;
-            else (void)hipGetLastError();                        // a host / unknown pointer: leave the error state clean
-        }
+        const int target = resolve_device(stream, data);
         if (target < 0) return;
         if (hipGetDevice(&prev) == hipSuccess && prev != target) switched = hipSetDevice(target) == hipSuccess;
     }
@@ -188,7 +195,7 @@ static int launch_step(Args a, hipStream_t st) {
     const bool generic = a.p.comm_state != nullptr;
     const Variant* v = variant_for(a.N, a.B, opts || idx, generic);
     if (!v || !geometry_for(a.N, &g, a.B, opts || idx, generic)) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [2, 1024]%s");
-    if (opts) g.lds += (2 * npad(a.N) + 2 * g.E * a.N) * (int)sizeof(float);    // per-agent mass / size, per-env comm states
+    if (opts) g.lds += (3 * npad(a.N) + 2 * g.E * a.N) * (int)sizeof(float);    // per-agent mass / size / flags, per-env comm states
     a.coll_scale = (float)((double)a.p.collide_thresh / (double)a.p.dist_min);
     const int grid = (a.B + g.E - 1) / g.E;
     // Split step: more than 64 agents (one env per workgroup) and fewer envs than half the chip's CUs.  One workgroup per
@@ -463,21 +470,10 @@ static void arena_unmap_slot(Arena* a, size_t slot) {
 // caller falls back to ordinary allocations, which is what placement.py does on any arena failure).
 static const unsigned long long kRetiredAddressBudget = 64ull << 40;
 
-// regions > 1: the chunks come in `regions` groups of consecutive indices, and between two groups the call holds
-// `spacer_bytes` of device memory (hipMalloc, never touched, freed before the call returns) so that the groups lie far
-// apart in physical memory although the arena itself is no larger than the buffer it is made for.
-static int arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
-                        void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out) {
+int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out) {
     if (!arena || bytes == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_create: arena and bytes > 0 required%s");
     if (g_retired_address_bytes.load() > kRetiredAddressBudget)
         return fail(FG_ERR_HIP, "fg_arena_create: the address-space budget of retired reservations (64 TiB) is spent%s");
-    int prev_dev = -1;
-    if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
-    if (prev_dev != device && hipSetDevice(device) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(FG_ERR_BAD_ARG, "fg_arena_create: no such device%s");
-    }
-    struct Restore { int prev, dev; ~Restore() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); } } restore{prev_dev, device};
     hipMemAllocationProp prop;
     memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned;
@@ -491,71 +487,32 @@ static int arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, uint32
     Arena* a = new Arena();
     a->dev = device; a->chunk = chunk; a->n = ((size_t)bytes + chunk - 1) / chunk;
     a->handle.resize(a->n); a->live.assign(a->n, 0); a->mapped_in.assign(a->n, -1);
-    const uint32_t spacer_mode = regions >> 24;            // EXPERIMENT: 0 = hipMalloc, 1 = chunks created, 2 = chunks created + mapped
-    regions &= 0xFFFFFFu;
-    std::vector<hipMemGenericAllocationHandle_t> spacer_chunks;
-    void* spacer_va = nullptr; size_t spacer_va_used = 0, spacer_va_size = 0;
-    if (regions < 1) regions = 1;
-    if (regions > a->n) regions = (uint32_t)a->n;
-    // Physical memory is assigned in allocation order: every chunk is created AND mapped once, in index order, so that a
-    // chunk's index says where it lies (chunks far apart in index are far apart in memory - what the caller's spread
-    // selections rely on), then the mappings are taken away again (the reservation is retired, see above).
+    for (size_t i = 0; i < a->n; ++i) {
+        err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
+        if (err != hipSuccess) break;
+        a->live[i] = 1;
+    }
+    // Every chunk is mapped once, in index order, and unmapped again (the reservation is retired, see above): a chunk has
+    // its physical place from here on, whatever selection it is mapped in later.  (Where that place is, the driver
+    // decides: holding memory between two groups of chunks while they are created does NOT put them reliably apart -
+    // profiles/r04_place/spread_rule*.txt - which is why selections are timed, not composed by rule.)
     void* va = nullptr;
     size_t mapped = 0;
-    std::vector<void*> spacers;
-    uint64_t spacer_held = 0;
-    hipMemAccessDesc desc;
-    memset(&desc, 0, sizeof(desc));
-    desc.location.type = hipMemLocationTypeDevice;
-    desc.location.id = device;
-    desc.flags = hipMemAccessFlagsProtReadWrite;
-    err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
+    if (err == hipSuccess) err = hipMemAddressReserve(&va, a->n * chunk, 0, nullptr, 0);
     if (err == hipSuccess) {
-        for (uint32_t r = 0; r < regions && err == hipSuccess; ++r) {
-            const size_t lo = a->n * r / regions, hi = a->n * (r + 1) / regions;
-            for (size_t i = lo; i < hi; ++i) {
-                err = hipMemCreate(&a->handle[i], chunk, &prop, 0);
-                if (err != hipSuccess) break;
-                a->live[i] = 1;
-                err = hipMemMap((char*)va + i * chunk, chunk, 0, a->handle[i], 0);
-                if (err != hipSuccess) break;
-                mapped = i + 1;
-            }
-            if (err == hipSuccess && hi > lo) err = hipMemSetAccess((char*)va + lo * chunk, (hi - lo) * chunk, &desc, 1);
-            if (err == hipSuccess && r + 1 < regions && spacer_bytes > 0 && spacer_mode > 0) {
-                const size_t sc = (size_t)1 << 30;
-                const size_t cnt = (size_t)(spacer_bytes / sc);
-                if (spacer_mode == 2 && !spacer_va) {
-                    spacer_va_size = cnt * sc * (regions - 1);
-                    if (hipMemAddressReserve(&spacer_va, spacer_va_size, 0, nullptr, 0) != hipSuccess) { spacer_va = nullptr; (void)hipGetLastError(); }
-                }
-                for (size_t q = 0; q < cnt; ++q) {
-                    hipMemGenericAllocationHandle_t h;
-                    if (hipMemCreate(&h, sc, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-                    spacer_chunks.push_back(h); spacer_held += sc;
-                    if (spacer_mode == 2 && spacer_va) {
-                        if (hipMemMap((char*)spacer_va + spacer_va_used, sc, 0, h, 0) == hipSuccess) {
-                            (void)hipMemSetAccess((char*)spacer_va + spacer_va_used, sc, &desc, 1);
-                            spacer_va_used += sc;
-                        } else (void)hipGetLastError();
-                    }
-                }
-            } else if (err == hipSuccess && r + 1 < regions && spacer_bytes > 0) {
-                // the spacer is an optimisation: when the device cannot lend that much, take what it can (down to 1 GiB)
-                uint64_t want = spacer_bytes;
-                while (want >= ((uint64_t)1 << 30)) {
-                    void* sp = nullptr;
-                    if (hipMalloc(&sp, (size_t)want) == hipSuccess) { spacers.push_back(sp); spacer_held += want; break; }
-                    (void)hipGetLastError();
-                    want >>= 1;
-                }
-            }
+        for (; mapped < a->n; ++mapped) {
+            err = hipMemMap((char*)va + mapped * chunk, chunk, 0, a->handle[mapped], 0);
+            if (err != hipSuccess) break;
+        }
+        if (err == hipSuccess) {
+            hipMemAccessDesc desc;
+            memset(&desc, 0, sizeof(desc));
+            desc.location.type = hipMemLocationTypeDevice;
+            desc.location.id = device;
+            desc.flags = hipMemAccessFlagsProtReadWrite;
+            err = hipMemSetAccess(va, a->n * chunk, &desc, 1);
         }
         drain_device(device);
-        for (void* sp : spacers) (void)hipFree(sp);
-        for (size_t off = 0; off < spacer_va_used; off += (size_t)1 << 30) (void)hipMemUnmap((char*)spacer_va + off, (size_t)1 << 30);
-        if (spacer_va) g_retired_address_bytes.fetch_add((unsigned long long)spacer_va_size);
-        for (auto h : spacer_chunks) (void)hipMemRelease(h);
         for (size_t i = 0; i < mapped; ++i) (void)hipMemUnmap((char*)va + i * chunk, chunk);
         g_retired_address_bytes.fetch_add((unsigned long long)(a->n * chunk));
     }
@@ -569,17 +526,7 @@ static int arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, uint32
     *arena = a;
     if (chunk_out) *chunk_out = chunk;
     if (chunks_out) *chunks_out = (uint32_t)a->n;
-    if (spacer_out) *spacer_out = spacer_held;
     return FG_OK;
-}
-
-int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out) {
-    return arena_create(device, bytes, chunk_bytes, 1, 0, arena, chunk_out, chunks_out, nullptr);
-}
-
-int fg_arena_create_spread(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
-                           void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out) {
-    return arena_create(device, bytes, chunk_bytes, regions, spacer_bytes, arena, chunk_out, chunks_out, spacer_out);
 }
 
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base) {
@@ -661,6 +608,8 @@ int fg_arena_destroy(void* arena) {
 }
 
 const char* fg_last_error(void) { return g_err; }
+
+int fg_launch_device(void* stream, const void* data) { return resolve_device(stream, data); }
 
 int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes) {
     Geometry g;
@@ -829,8 +778,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     if (K == 0) return FG_OK;
     if (K < 0 || obs_every < 1) return fail(FG_ERR_BAD_ARG, "K >= 0 and obs_every >= 1 required%s");
     if (K > 1 && !do_physics) return fail(FG_ERR_BAD_ARG, "a multi-step launch steps the physics%s");
-    if (params->agent_props || params->comm_state)
-        return fail(FG_ERR_BAD_ARG, "agent_props / comm_state are honoured by the formation_hd_env entry points only%s");
+    if (params->comm_state)
+        return fail(FG_ERR_BAD_ARG, "comm_state is honoured by the formation_hd_env entry points only%s");
     const int L = sc->num_landmarks, M = sc->num_obstacles;
     if (sc->kind < FG_SCN_BASIC || sc->kind > FG_SCN_OBSTACLE) return fail(FG_ERR_BAD_ARG, "unknown scenario kind%s");
     if (B == 0) return FG_OK;
@@ -850,15 +799,17 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
     a.opos = obst_pos; a.ovel = obst_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done; a.near_ag = near_ag;
     a.inv_n = (float)(1.0 / (double)N); a.inv_l = (float)(1.0 / (double)L);
+    a.coll_scale = (float)((double)params->collide_thresh / (double)params->dist_min);
     hipStream_t st = (hipStream_t)stream;
-    if (sc->variant != 1) {
+    if (sc->variant != 1 && !params->agent_props) {        // (per-agent tables: the run-time-count kernel)
         // the reference's own shapes: one env per lane, every count a compile-time constant (fg_scn_lane_kernel.hpp)
         const int nbr = sc->kind == FG_SCN_PARTIAL ? sc->num_obs : N - 1;
         bool launched = false;
 #define FG_SCN_LANE(KIND, NN, LL, MM, NBR)                                                                              \
         if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
             constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
-            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3((B + 63) / 64), dim3(128), lds, st, a);       \
+            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)), dim3(128),    \
+                               lds, st, a);                                                                                 \
             launched = true;                                                                                                \
         }
         FG_SCN_LANE(FG_SCN_BASIC, 3, 3, 0, 2)            // basic_formation_env.py:7

@@ -16,7 +16,8 @@ BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
 ABI_VERSION = 7
 MAX_WALLS = 4
-AGENT_PROPS = 6                 # floats per row of FgParams.agent_props: mass, size, accel, max_speed, u_noise, c_noise
+AGENT_PROPS = 8                 # floats per row of FgParams.agent_props: mass, size, accel, max_speed, u_noise, c_noise, flags, 0
+AGENT_IMMOVABLE, AGENT_NO_COLLIDE, AGENT_GHOST = 1, 2, 4         # the flags column
 
 FG_OK = 0
 FG_ERR_BAD_ARG = -1
@@ -28,7 +29,7 @@ FG_ERR_HIP = -4
 class FgWall(ctypes.Structure):
     """Mirror of `struct FgWall`."""
     _fields_ = [("vertical", ctypes.c_int32), ("axis_pos", ctypes.c_float), ("end0", ctypes.c_float),
-                ("end1", ctypes.c_float), ("width", ctypes.c_float), ("reserved", ctypes.c_int32)]
+                ("end1", ctypes.c_float), ("width", ctypes.c_float), ("soft", ctypes.c_int32)]
 
 
 class FgParams(ctypes.Structure):
@@ -97,10 +98,9 @@ _PP = ctypes.POINTER(FgParams)
 SIGNATURES = {
     "fg_abi_version": (_I, []),
     "fg_last_error": (ctypes.c_char_p, []),
+    "fg_launch_device": (_I, [_P, _P]),
     "fg_arena_create": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_uint64),
                              ctypes.POINTER(ctypes.c_uint32)]),
-    "fg_arena_create_spread": (_I, [_I, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(_P),
-                                    ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint64)]),
     "fg_arena_map": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
     "fg_arena_unmap": (_I, [_P, _P]),
     "fg_arena_trim": (_I, [_P]),

@@ -6,7 +6,9 @@ A scenario written for the reference knows nothing of batches or devices: it has
 world from `formation_gym.core.World / Agent / Landmark`, and reads `entity.state.p_pos` etc. as NumPy vectors.  The
 kernels of this package cannot run arbitrary Python, so such a file takes the SLOW path, loudly labelled
 (`env.info['path']`, one warning): `_set_action` and `World.step` - the O(N^2) physics - run on the GPU for all envs in
-one launch (`fg_physics_step`, including agents of different mass / size / accel / max_speed and walls), the state comes
+one launch (`fg_physics_step`, including agents of different mass / size / accel / max_speed, walls, and LANDMARKS THAT
+COLLIDE - movable ones like the reference's formation_hd_obs_env obstacles, immovable ones that only push back: they ride
+along as physics-only bodies behind the agents, core.py:240-262 runs over all entities), the state comes
 back to the host once per step, and the file's own per-agent callbacks run there on host views of it, exactly as
 the reference calls them (environment.py:126-134).  Scenarios that want the fused path implement the batched protocol of
 `scenario.BaseScenario` (step_batch / observe_batch), as the five scenarios in `envs/` do.
@@ -48,17 +50,26 @@ class CallbackScenario(BaseScenario):
         finally:
             np.random.set_state(saved)    # the draws of make_world's own reset_world must not move the caller's stream
         hw = self.host_worlds[0]
-        for e in hw.landmarks:
-            if e.collide and (e.movable or any(a.collide for a in hw.agents)):
-                raise NotImplementedError("colliding landmarks are simulated by the batched landmark scenarios "
-                                          "(envs/formation_hd_obs_env.py), not by the callback adapter")
         world = World(world_length=getattr(hw, "world_length", 50), num_envs=B, device=device)
         for k in ("dim_c", "dim_p", "dt", "damping", "contact_force", "contact_margin", "collaborative", "discrete_action"):
             if hasattr(hw, k):
                 setattr(world, k, getattr(hw, k))
         world.walls = list(hw.walls)
-        world.agents = [self._clone(a, Agent()) for a in hw.agents]
-        world.landmarks = [self._clone(l, Landmark()) for l in hw.landmarks]
+        # Landmarks that take part in the physics (core.py:292-295: collide, and somebody of the pair moves) are simulated as
+        # bodies BEHIND the agents in the device World's entity table, in the reference's entity order (agents, then
+        # landmarks in list order: core.py:147-149), flagged immovable where they are; the others stay host-side.
+        self._bodies = [i for i, l in enumerate(hw.landmarks)
+                        if l.movable or (l.collide and any(a.collide for a in hw.agents))]     # (a movable non-collider still drifts, :264-277)
+        self._statics = [i for i in range(len(hw.landmarks)) if i not in self._bodies]
+        self._num_real = len(hw.agents)
+        bodies = []
+        for i in self._bodies:
+            b_ = self._clone(hw.landmarks[i], Agent())
+            b_.silent = True; b_._physics_only = True
+            b_.accel = None; b_.u_noise = None; b_.c_noise = None
+            bodies.append(b_)
+        world.agents = [self._clone(a, Agent()) for a in hw.agents] + bodies
+        world.landmarks = [self._clone(hw.landmarks[i], Landmark()) for i in self._statics]
         world.allocate()
         world.scenario = self
         self._step_host = np.zeros(B, dtype=np.int64)
@@ -81,25 +92,47 @@ class CallbackScenario(BaseScenario):
         lm = np.zeros((B, max(len(world.landmarks), 1), 2))
         for b in range(B):
             hw = self.host_worlds[b]
-            for i, a in enumerate(hw.agents):
+            for i, a in enumerate(self._host_entities(hw)):
                 pos[b, i] = a.state.p_pos
                 vel[b, i] = a.state.p_vel if a.state.p_vel is not None else 0.0
-            for i, l in enumerate(hw.landmarks):
-                lm[b, i] = l.state.p_pos
+            for k, i in enumerate(self._statics):
+                lm[b, k] = hw.landmarks[i].state.p_pos
         world.set_state(pos, vel)
         world.landmark_pos.copy_(torch.as_tensor(lm, dtype=torch.float32))
         self._cache = None
+
+    def _host_entities(self, hw):
+        """The host world's simulated entities in device order: its agents, then its colliding landmarks."""
+        return list(hw.agents) + [hw.landmarks[i] for i in self._bodies]
 
     def _download(self, world):
         """Device state -> the host worlds' entity states (float64 views of the fp32 values)."""
         pos, vel = world.get_state()
         pos = pos.double().cpu().numpy(); vel = vel.double().cpu().numpy()
         for b, hw in enumerate(self.host_worlds[:world.num_envs]):
-            for i, a in enumerate(hw.agents):
+            for i, a in enumerate(self._host_entities(hw)):
                 a.state.p_pos = pos[b, i].copy()
                 a.state.p_vel = vel[b, i].copy()
+            for a in hw.agents:
                 if a.state.c is None or a.silent:
                     a.state.c = np.zeros(hw.dim_c)
+
+    def _upload_bodies(self, world):
+        """Host -> device for the colliding landmarks only: a reward callback may have written their state (the reference's
+        formation_hd_obs_env re-arms its obstacles' velocity there, :82-89)."""
+        if not self._bodies:
+            return
+        n0, nb = self._num_real, len(self._bodies)
+        B = world.num_envs
+        pos = np.zeros((B, nb, 2), dtype=np.float32); vel = np.zeros((B, nb, 2), dtype=np.float32)
+        for b in range(B):
+            for k, i in enumerate(self._bodies):
+                st = self.host_worlds[b].landmarks[i].state
+                pos[b, k] = st.p_pos
+                vel[b, k] = st.p_vel if st.p_vel is not None else 0.0
+        dev = world.device
+        world.pos_x[:, n0:] = torch.as_tensor(pos[..., 0]).to(dev); world.pos_y[:, n0:] = torch.as_tensor(pos[..., 1]).to(dev)
+        world.vel_x[:, n0:] = torch.as_tensor(vel[..., 0]).to(dev); world.vel_y[:, n0:] = torch.as_tensor(vel[..., 1]).to(dev)
 
     # ---- RNG: the reference draws from NumPy's global legacy generator -------
     def seed(self, seed=None):
@@ -139,7 +172,7 @@ class CallbackScenario(BaseScenario):
         for b, hw in enumerate(self.host_worlds[:world.num_envs]):
             if env_mask[b]:
                 continue
-            for i, a in enumerate(hw.agents):
+            for i, a in enumerate(self._host_entities(hw)):
                 a.state.p_pos = pos[b, i].copy(); a.state.p_vel = vel[b, i].copy()
 
     # ---- batched protocol (what MultiAgentEnv drives) ------------------------
@@ -147,9 +180,10 @@ class CallbackScenario(BaseScenario):
         hw = self.host_worlds[0]
         return int(len(self.users[0].observation(hw.agents[0], hw)))
 
-    def _callbacks(self, world, out):
-        """environment.py:126-134 for every env: the user's observation / reward per agent, on the host."""
-        B, N = world.num_envs, len(world.agents)
+    def _callbacks(self, world, out, rewards=True):
+        """environment.py:126-134 for every env: the user's observation / reward per agent, on the host.  rewards=False:
+        what reset() does (environment.py:154-155: observations only - a reward callback with side effects must not run)."""
+        B, N = world.num_envs, self._num_real
         self._download(world)
         D = out["obs"].shape[-1]
         obs = np.zeros((B, N, D), dtype=np.float32)
@@ -157,8 +191,13 @@ class CallbackScenario(BaseScenario):
         for b in range(B):
             u, hw = self.users[b], self.host_worlds[b]
             for i, a in enumerate(hw.agents):
+                # environment.py:127-130: observation, reward for reward_n, and the reward AGAIN for info['individual_reward']
                 obs[b, i] = np.asarray(u.observation(a, hw), dtype=np.float64)
-                indiv[b, i] = float(u.reward(a, hw))
+                if rewards:
+                    u.reward(a, hw)
+                    indiv[b, i] = float(u.reward(a, hw))
+        if rewards:
+            self._upload_bodies(world)
         out["obs"].copy_(torch.as_tensor(obs))
         if out.get("indiv") is not None:
             out["indiv"].copy_(torch.as_tensor(indiv))
@@ -173,7 +212,10 @@ class CallbackScenario(BaseScenario):
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
         if auto_reset:
             raise NotImplementedError("device auto-reset needs a batched scenario; use FormationVecEnv(reset_mode='host')")
-        if act.data_ptr() != world.action_u.data_ptr():
+        if self._bodies:                          # the bodies behind the agents take no action (core.py:229-237: agents only)
+            world.action_u.zero_()
+            world.action_u[:, :self._num_real].copy_(act)
+        elif act.data_ptr() != world.action_u.data_ptr():
             world.action_u.copy_(act)
         world.step()                              # _set_action's scaling + World.step: one launch (fg_physics_step)
         world.world_step -= 1                     # MultiAgentEnv.step counts the step itself
@@ -182,7 +224,7 @@ class CallbackScenario(BaseScenario):
         self._callbacks(world, out)
 
     def observe_batch(self, world, out):
-        self._callbacks(world, out)
+        self._callbacks(world, out, rewards=False)
 
     # ---- per-agent callbacks with the reference's signature ------------------
     def _host_agent(self, agent, b=0):

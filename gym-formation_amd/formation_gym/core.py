@@ -153,8 +153,8 @@ class Action(object):
 
 class Wall(object):
     """Wall description (core.py:27-41).  No reference scenario creates walls
-    (world.walls == []); when present (at most 4, hard) they are simulated in-kernel
-    (core.py:325-362)."""
+    (world.walls == []); when present (at most 4) they are simulated in-kernel
+    (core.py:325-362); a soft wall (hard=False) lets ghost entities through (:326-327)."""
 
     def __init__(self, orient="H", axis_pos=0.0, endpoints=(-1, 1), width=0.1, hard=True):
         self.orient = orient
@@ -255,7 +255,9 @@ class World(object):
 
     @property
     def policy_agents(self):
-        return [agent for agent in self.agents if agent.action_callback is None]
+        """core.py:152-154; entities the callback adapter simulates as physics-only bodies (colliding landmarks of a
+        reference-style Scenario file, callback_scenario.py) are agents of the device World but nobody's policy."""
+        return [agent for agent in self.agents if agent.action_callback is None and not getattr(agent, "_physics_only", False)]
 
     @property
     def scripted_agents(self):
@@ -307,12 +309,16 @@ class World(object):
         return any(not a.silent for a in self.agents)
 
     def agent_props(self):
-        """Device table float [N, 6] = (mass, size, accel, max_speed, u_noise, c_noise) per agent for
+        """Device table float [N, 8] = (mass, size, accel, max_speed, u_noise, c_noise, flags, 0) per agent for
         `FgParams.agent_props`, or None while all agents are alike (then the scalars of FgParams say it all).
-        accel / max_speed / u_noise / c_noise: 0 = None; c_noise < 0 marks a silent agent (`fg_update_comm`)."""
+        accel / max_speed / u_noise / c_noise: 0 = None; c_noise < 0 marks a silent agent (`fg_update_comm`);
+        flags: 1 = not movable, 2 = does not collide, 4 = ghost (core.py:54-58), 0 for the agents of every reference scenario."""
+        def flags(a):
+            return float((0 if a.movable else _native.AGENT_IMMOVABLE) | (0 if a.collide else _native.AGENT_NO_COLLIDE) |
+                         (_native.AGENT_GHOST if a.ghost else 0))
         rows = [(float(a.mass), float(a.size), float(a.accel or 0.0), float(a.max_speed or 0.0), float(a.u_noise or 0.0),
-                 -1.0 if a.silent else float(a.c_noise or 0.0)) for a in self.agents]
-        alike = len({r[:5] for r in rows}) == 1
+                 -1.0 if a.silent else float(a.c_noise or 0.0), flags(a), 0.0) for a in self.agents]
+        alike = len({r[:5] + r[6:] for r in rows}) == 1 and rows[0][6] == 0.0      # any flag: the table (the scalars cannot say it)
         if alike and not self.any_non_silent():
             return None
         if alike and all(r[5] == rows[0][5] for r in rows) and rows[0][5] == 0.0:
@@ -343,10 +349,11 @@ class World(object):
     def native_params(self, sensitivity=5.0, collide_thresh=0.0, auto_reset=False, seed=0, rng_offset=0):
         """FgParams for the C ABI from this world's constants (uniform agents)."""
         a0 = self.agents[0]
-        for a in self.agents:
-            if not a.movable or not a.collide or a.ghost:
-                raise NotImplementedError("immovable / non-colliding / ghost agents do not occur in the "
-                                          "reference scenarios and are not built")
+        if self.scripted_agents:
+            # core.py:210-211 runs `agent.action = agent.action_callback(agent, self)` per env on the host before the physics:
+            # arbitrary Python per agent and env, which a batched device step cannot call.  No reference scenario has one.
+            raise NotImplementedError("scripted agents (Agent.action_callback, core.py:210-211) are not built: set the "
+                                      "agent's action.u yourself before World.step()")
         # agents that differ in mass / size / accel / max_speed / u_noise (core.py:45-109): a per-agent table; the
         # scalars below then only carry agent 0's contact distance (the scale of collide_thresh) and the sensitivity
         # of agents without an accel of their own
@@ -354,8 +361,6 @@ class World(object):
         hetero = props is not None and not self._props[2]
         if len(self.walls) > _native.MAX_WALLS:
             raise NotImplementedError("at most %d walls" % _native.MAX_WALLS)
-        if any(not w.hard for w in self.walls):
-            raise NotImplementedError("soft walls only matter for ghost entities, which are not built")
         sens = a0.accel if (a0.accel is not None and not hetero) else sensitivity     # environment.py:218-220
         p = _native.FgParams(
             dt=self.dt, damping=self.damping, contact_force=self.contact_force,
@@ -373,15 +378,15 @@ class World(object):
         for k, w in enumerate(self.walls):
             p.walls[k] = _native.FgWall(vertical=0 if w.orient == "H" else 1, axis_pos=float(w.axis_pos),
                                         end0=float(w.endpoints[0]), end1=float(w.endpoints[1]),
-                                        width=float(w.width), reserved=0)
+                                        width=float(w.width), soft=0 if w.hard else 1)
         return p
 
     def params_signature(self):
         """Cheap tuple of everything `native_params` reads from the world and from agent 0:
         callers that cache an FgParams re-derive it when this changes."""
         return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
-                len(self.agents), tuple((a.size, a.initial_mass, a.accel, a.max_speed, a.u_noise, a.silent, a.c_noise)
-                                        for a in self.agents),
+                len(self.agents), tuple((a.size, a.initial_mass, a.accel, a.max_speed, a.u_noise, a.silent, a.c_noise,
+                                         a.movable, a.collide, a.ghost, a.action_callback is not None) for a in self.agents),
                 None if self.comm_c is None else self.comm_c.data_ptr(),
                 None if self.rng_counter is None else self.rng_counter.data_ptr(),
                 tuple((w.orient, float(w.axis_pos), float(w.endpoints[0]), float(w.endpoints[1]), float(w.width), w.hard)

@@ -129,6 +129,11 @@ class MultiAgentEnv(object):
     def step(self, action_n):
         self.current_step += 1
         self.agents = self.world.policy_agents
+        if any(not a.movable and a.silent for a in self.agents):
+            # environment.py:191-236: `_set_action` consumes the action only `if agent.movable` (or as the communication of
+            # a non-silent agent) and then asserts that nothing is left - a silent immovable agent trips that assertion
+            # (fixture hd_n6_immovable records it).  Such agents are driven through the World API: world.step().
+            raise AssertionError
         if self.world.any_non_silent():
             # The reference cannot step non-silent (movable) agents either: `_set_action` consumes the whole action for
             # the physical part and then indexes the exhausted list for the communication part (environment.py:216-231;

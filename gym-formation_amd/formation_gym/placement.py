@@ -115,21 +115,13 @@ class Arena(object):
     gives a device address range made of exactly those chunks; a chunk is mapped at one address at a time.  Tensors made
     by `floats()` are views of a mapping: keep the Arena alive as long as they are in use."""
 
-    def __init__(self, nbytes, device, chunk_bytes=0, regions=1, spacer_bytes=0):
-        """regions > 1 (`fg_arena_create_spread`): the chunks come in `regions` groups of consecutive indices that lie
-        `spacer_bytes` apart in physical memory (the spacers are held only while the arena is being created)."""
+    def __init__(self, nbytes, device, chunk_bytes=0):
         self.device = torch.device(device)
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        handle, chunk, count, held = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint64()
-        if regions > 1:
-            _native.check(_native.load().fg_arena_create_spread(int(index), int(nbytes), int(chunk_bytes), int(regions),
-                                                                int(spacer_bytes), ctypes.byref(handle), ctypes.byref(chunk),
-                                                                ctypes.byref(count), ctypes.byref(held)))
-        else:
-            _native.check(_native.load().fg_arena_create(int(index), int(nbytes), int(chunk_bytes), ctypes.byref(handle),
-                                                         ctypes.byref(chunk), ctypes.byref(count)))
+        handle, chunk, count = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
+        _native.check(_native.load().fg_arena_create(int(index), int(nbytes), int(chunk_bytes), ctypes.byref(handle),
+                                                     ctypes.byref(chunk), ctypes.byref(count)))
         self._handle, self.chunk, self.chunks = handle, int(chunk.value), int(count.value)
-        self.regions, self.spacer_held = max(1, int(regions)), int(held.value)
         self.kept_range = (0, 0)          # address range of the spread buffer kept in the end (see is_placed)
         import weakref
         _live_arenas.append(weakref.ref(self))

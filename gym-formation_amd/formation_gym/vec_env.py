@@ -11,12 +11,18 @@ import torch
 
 
 class FormationVecEnv(object):
-    def __init__(self, env, reset_mode="device"):
+    def __init__(self, env, reset_mode="device", numpy=False, infos="dict"):
         """reset_mode:
           'device'    counter RNG inside the fused step launch (fastest; distributional parity); every scenario in envs/
           'device_mt' (formation_hd_env) the reference's own MT19937 streams continued on the GPU (bit-exact resets,
                       no host round trip: the host mirrors the step counters, which are deterministic)
-          'host'      the reference's streams on the host (bit-exact; needs a device->host sync)"""
+          'host'      the reference's streams on the host (bit-exact; needs a device->host sync)
+        numpy=True: `reset` / `step` return what the reference's vec envs return (env_wrappers.py:68-72, :113-122): NumPy float64
+          obs [B,N,D] and rews [B,N,1], bool dones [B,N] (one device-to-host copy per step); default: device tensors.
+        infos: 'dict' = one dict of [B,N] tensors; 'tuple' = the reference's shape, a tuple of B lists of N dicts
+          {'individual_reward': float} (SubprocVecEnv.step_wait; B x N Python objects per step: for small batches)."""
+        if infos not in ("dict", "tuple"):
+            raise ValueError("infos must be 'dict' or 'tuple'")
         if reset_mode not in ("device", "device_mt", "host"):
             raise ValueError("reset_mode must be 'device', 'device_mt' or 'host'")
         if reset_mode == "device_mt" and not hasattr(env.scenario, "bind_reset_mt_done"):
@@ -29,35 +35,63 @@ class FormationVecEnv(object):
         self.num_agents = env.num_agents
         self.observation_space = env.observation_space
         self.action_space = env.action_space
-        self.agent_types = ['agent' for _ in env.agents]        # env_wrappers.py:33-34
+        if all(hasattr(a, 'adversary') for a in env.agents):    # env_wrappers.py:29-34, :102-106
+            self.agent_types = ['adversary' if a.adversary else 'agent' for a in env.agents]
+        else:
+            self.agent_types = ['agent' for _ in env.agents]
         env.auto_reset = reset_mode == "device"
-        self.ts = torch.zeros(self.num_envs, dtype=torch.int64)
-        self._host_steps = None
+        self.numpy, self.infos = bool(numpy), infos
+        import numpy as np
+        # steps since each env's last reset (DummyVecEnv.ts, env_wrappers.py:108, :116-120): a host mirror of the device's
+        # step counters - they are deterministic (+1 per step, 0 at world_length), so no read-back is needed after the first
+        self.ts = np.zeros(self.num_envs, dtype='int')
+        self._ts_synced = False
         self._mt_launch = None
+
+    def _to_numpy(self, obs, rew, done, info):
+        if self.infos == "tuple":
+            indiv = info["individual_reward"].double().cpu().numpy()
+            info = tuple([{'individual_reward': float(r)} for r in row] for row in indiv)
+        if not self.numpy:
+            return obs, rew, done, info
+        return obs.double().cpu().numpy(), rew.double().cpu().numpy(), done.cpu().numpy(), info
 
     def get_spaces(self):
         return self.observation_space, self.action_space
 
     def reset(self):
+        self.ts[:] = 0
+        self._ts_synced = True
         if self.reset_mode == "device_mt":
-            import numpy as np
             sc, world = self.env.scenario, self.env.world
             sc.upload_mt_streams(world)
             sc.reset_mt(world)                                    # all envs, on device
             self.env.current_step = 0
             sc.observe_batch(world, {"obs": self.env._out["obs"]})
-            self._host_steps = np.zeros(self.num_envs, dtype=np.int64)
-            return self.env._out["obs"]
-        return self.env.reset(batched=True)
+            obs = self.env._out["obs"]
+        else:
+            obs = self.env.reset(batched=True)
+        return obs.double().cpu().numpy() if self.numpy else obs
+
+    def reset_task(self):
+        """SubprocVecEnv.reset_task (env_wrappers.py:79-82) asks every worker for `env.reset_task()`, which the reference's
+        MultiAgentEnv does not have: the call fails there, and it fails the same way here."""
+        raise AttributeError("'MultiAgentEnv' object has no attribute 'reset_task'")
 
     def step(self, actions):
-        """actions [B, N, 2] -> obs [B,N,D], rews [B,N,1], dones [B,N] (bool), infos dict."""
+        """actions [B, N, 2] (a tensor, or anything torch.as_tensor takes) -> obs [B,N,D], rews [B,N,1], dones [B,N] (bool),
+        infos; `ts` counts the steps since each env's last reset."""
+        if not torch.is_tensor(actions):
+            import numpy as np
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.float32), device=self.env._act.device)
+        if not self._ts_synced:                                   # the env was stepped / loaded behind our back: read the counters once
+            self.ts[:] = self.env.world.step_count.cpu().numpy()
+            self._ts_synced = True
         obs, rew, done, info = self.env.step(actions)
+        self.ts += 1
+        finished = self.ts >= int(self.env.world.world_length)
+        self.ts[finished] = 0
         if self.reset_mode == "device_mt":
-            if self._host_steps is None:
-                self._host_steps = self.env.world.step_count.cpu().numpy().astype("int64") - 1
-            self._host_steps += 1
-            finished = self._host_steps >= int(self.env.world.world_length)
             if finished.any():
                 # ONE launch, decided on the device (step counter >= world_length): the finished envs restart from their
                 # own MT19937 streams and their reset observation replaces the step's; no mask upload, no second pass over
@@ -67,8 +101,7 @@ class FormationVecEnv(object):
                     self._mt_launch = (self.env._out["obs"].data_ptr(),
                                        self.env.scenario.bind_reset_mt_done(self.env.world, self.env._out["obs"]))
                 self._mt_launch[1]()
-                self._host_steps[finished] = 0
-            return self.env._out["obs"], rew, done, info
+            return self._to_numpy(self.env._out["obs"], rew, done, info)
         if self.reset_mode == "host":
             mask = done.all(dim=1)
             if bool(mask.any()):
@@ -78,7 +111,7 @@ class FormationVecEnv(object):
                 self.env.scenario.reset_world(self.env.world, env_mask=mask.cpu().numpy())
                 self.env.scenario.observe_batch(self.env.world, {"obs": self.env._out["obs"]})
                 obs = self.env._out["obs"]
-        return obs, rew, done, info
+        return self._to_numpy(obs, rew, done, info)
 
     def rollout(self, action_seq, out=None, obs_every=1):
         """K vec-env steps in ONE launch (`env.rollout`): action_seq [K,B,N,2] -> obs [K//obs_every,B,N,D],
@@ -86,6 +119,7 @@ class FormationVecEnv(object):
         exactly as K `step` calls would ('device' reset mode only: the other modes reset between launches)."""
         if self.reset_mode != "device":
             raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
+        self._ts_synced = False                                   # (re-read after a multi-step launch)
         return self.env.rollout(action_seq, out=out, obs_every=obs_every)
 
     def rollout_policy(self, K, num_agents_per_layer=3, out=None, obs_every=1):
@@ -93,6 +127,7 @@ class FormationVecEnv(object):
         test.py:17-27 in one call; infos carries the actions taken ('device' reset mode only)."""
         if self.reset_mode != "device":
             raise NotImplementedError("multi-step launches reset on the device: use reset_mode='device' or call step()")
+        self._ts_synced = False
         return self.env.rollout_policy(K, num_agents_per_layer, out=out, obs_every=obs_every)
 
     def capture(self, policy_fn, steps_per_replay):
@@ -190,6 +225,7 @@ class CapturedLoop(object):
     def replay(self):
         env, T = self.env, self.steps
         self.graph.replay()
+        self.venv._ts_synced = False                                     # `ts` is re-read from the device when next asked for
         env._rng_offset += T
         env.current_step += T
         env.world.world_step += T

@@ -76,7 +76,7 @@ typedef enum FgStatus {
  *   accel           core.py:236 + environment.py:219-220: force = mass*accel*(accel*action)
  *   max_speed       core.py:271-276 speed clamp after the velocity update
  *   u_noise         core.py:232-233 Gaussian motor noise (device counter RNG, distributional parity)
- *   walls           core.py:27-41,255-261,325-362 get_wall_collision_force, hard walls
+ *   walls           core.py:27-41,255-261,325-362 get_wall_collision_force; hard or soft (FgWall.soft)
  * Layout option of the observation output (fg_step_hd, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy):
  *   obs_env_pitch   the [N][6N] block of env b starts obs_env_pitch floats after env b-1's (even, >= 6 N^2);
  *                   every agent count of the reference is odd, so contiguous env blocks are only 8-byte aligned -
@@ -88,7 +88,7 @@ typedef struct FgWall {
     float axis_pos;
     float end0, end1;    /* endpoints along the wall */
     float width;
-    int32_t reserved;
+    int32_t soft;        /* core.py:36-37 Wall.hard: 0 = hard (every entity feels it), 1 = soft (ghost entities pass through, :326-327) */
 } FgWall;
 
 typedef struct FgParams {
@@ -128,9 +128,21 @@ typedef struct FgParams {
                                   [3] max_speed  Entity.max_speed (0 = None): core.py:271-276
                                   [4] u_noise    Agent.u_noise (0 = None): core.py:232-233
                                   [5] c_noise    Agent.c_noise for fg_update_comm (0 = None; < 0 = a silent agent)
+                                  [6] flags      an integer stored as a float, 0 for an ordinary agent:
+                                                 1 = not movable (core.py:231, 266-267: no action force, state never
+                                                     integrated; a partner's contact force is then not scaled by the mass
+                                                     ratio, :319-321),
+                                                 2 = does not collide (:292-293: no contact force with anybody; the reward's
+                                                     collision penalties of such an agent are not counted,
+                                                     formation_hd_env.py:71),
+                                                 4 = ghost (passes through soft walls, :326-327)
+                                  [7] reserved (0)
                                 With a table, `sensitivity` is the value for agents whose accel is None (5.0) and
                                 mass / dist_min / accel / max_speed / u_noise above are not read.  Honoured by
-                                fg_step_hd, fg_physics_step, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy. */
+                                fg_step_hd, fg_physics_step, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy, and - columns
+                                [0] ... [4], the agents only: obstacles keep FgScenario.obstacle_size and unit mass - by
+                                fg_step_scenario, fg_step_basic, fg_rollout_scenario (penalty distance of a pair =
+                                collide_thresh / dist_min * (size_a + size_b)). */
     const float* comm_state;   /* optional DEVICE float [B][N][2] = AgentState.c of every agent (World.dim_c = 2): copied
                                 into the communication block of the observation, row i = c_j for j != i in index order
                                 (formation_hd_env.py:48-51,59); NULL = zeros, the silent agents of every reference
@@ -141,7 +153,10 @@ typedef struct FgParams {
                                 27 x 4096) where 4 are best on an ordinary allocation (12.9 there, 13.2-14.4 with 8).  0 = unknown */
     int32_t reserved0;
 } FgParams;
-#define FG_AGENT_PROPS 6
+#define FG_AGENT_PROPS 8
+#define FG_AGENT_IMMOVABLE 1
+#define FG_AGENT_NO_COLLIDE 2
+#define FG_AGENT_GHOST 4
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:
  *   kind            which Scenario file under formation_gym/envs/
@@ -175,10 +190,13 @@ typedef struct FgScenario {
 } FgScenario;
 
 /* Placed device memory ------------------------------------------------------
- * The rate at which the rollout kernels stream observations depends on WHERE in HBM the buffer lies: a multi-GB buffer on
- * physically neighbouring memory runs the same launch at 5.0-5.4 TB/s, one whose chunks are spread over the device's
- * memory at 6.2-6.8 TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  An arena is a set of
- * separately created physical chunks (HIP virtual memory management) from which a caller composes buffers:
+ * The rate at which the rollout kernels stream observations depends on WHICH physical memory the buffer is composed of: a
+ * multi-GB buffer on physically neighbouring memory runs the same launch at 5.0-5.4 TB/s, a well composed one at 6.2-6.8
+ * TB/s (a physically contiguous allocation: 2-2.6 TB/s; profiles/r03_place/).  Which composition is fast cannot be told in
+ * advance (the driver decides where a chunk lies; compositions made by rule do not hold up: profiles/r04_place/), so a caller
+ * TIMES its own launch on a few compositions and keeps the best - from an arena that need not be larger than 1.5-6 x the
+ * buffer (profiles/r04_place/arena_size.txt).  An arena is a set of separately created physical chunks (HIP virtual memory
+ * management) from which a caller composes buffers:
  *   fg_arena_create   creates ceil(bytes / chunk) chunks of device memory on `device` (chunk_bytes is rounded up to the
  *                     allocation granularity; 0 = 1 GiB) and gives them their place in memory in INDEX order (a chunk is
  *                     placed when it is first mapped, so every chunk is mapped once and unmapped again: chunks far apart
@@ -198,16 +216,6 @@ typedef struct FgScenario {
  * These are the only entry points that allocate; they enqueue nothing and take no stream.  Calls on ONE arena must not
  * run concurrently (the arena is the caller's object; different arenas are independent). */
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
-/* Placement BY RULE, without timing candidates: what makes a buffer fast is that chunks which are CONSECUTIVE IN THE BUFFER
- * lie far apart in physical memory (profiles/r03_place/selection_rules_*.txt).  fg_arena_create_spread creates an arena no
- * larger than the buffer whose chunks come in `regions` groups of consecutive indices (group r = chunks
- * [n r / regions, n (r + 1) / regions)); between two groups the call holds `spacer_bytes` of device memory - allocated,
- * never touched, freed before it returns - so that the groups end up that far apart.  The caller then maps the chunks
- * round-robin over the groups (fg_arena_map with indices g0[0], g1[0], .., g0[1], g1[1], ..).  When the device cannot
- * lend the spacer, smaller ones are tried (halving down to 1 GiB, then none): *spacer_out = bytes actually held between
- * the groups in total.  Everything else as fg_arena_create. */
-int fg_arena_create_spread(int device, uint64_t bytes, uint64_t chunk_bytes, uint32_t regions, uint64_t spacer_bytes,
-                           void** arena, uint64_t* chunk_out, uint32_t* chunks_out, uint64_t* spacer_out);
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
 int fg_arena_unmap(void* arena, void* base);
 int fg_arena_trim(void* arena);
@@ -217,6 +225,13 @@ int fg_arena_destroy(void* arena);
 /* library / diagnostics --------------------------------------------------- */
 int fg_abi_version(void);
 const char* fg_last_error(void);
+/* The device an entry point would launch on for this stream and this first state pointer: the stream's device when the
+ * stream is not NULL, else the device the pointer's memory lives on (hipPointerGetAttributes), else -1 = "cannot tell: the
+ * calling thread's current device".  Every entry point applies this rule (and switches device for the duration of the call
+ * when the process sees more than one GPU), so that an env living on cuda:1 can be driven from a thread whose current device
+ * is cuda:0; this call only reports it.  Memory composed with fg_arena_map counts as the device's like any other allocation
+ * (tests/test_gpu_multidevice.py::test_launch_device_rule_on_one_gpu). */
+int fg_launch_device(void* stream, const void* data);
 /* Launch geometry the library will use for N agents: threads per workgroup,
  * environments per workgroup, dynamic LDS bytes.  Returns FgStatus. */
 int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes);

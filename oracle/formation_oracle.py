@@ -134,12 +134,14 @@ def reset_basic(seed, N, L=3):
 # --------------------------------------------------------------------------
 
 GOLDEN_WALLS = [("V", -0.9, (-1.0, 1.0), 0.1), ("V", 0.9, (-0.6, 0.6), 0.1), ("H", 0.8, (-0.5, 0.5), 0.2)]
+GOLDEN_SOFT_WALLS = [("H", -0.05, (-0.4, 0.4), 0.1)]    # the soft wall of fixture hd_n9_flags (tests/golden/make_golden.py SOFT_WALLS)
 
 
-def wall_force(pos, size, wall, P, dtype=np.float64):
+def wall_force(pos, size, wall, P, dtype=np.float64, ghost=None):
     """core.py:325-362 get_wall_collision_force for every entity [B,N,2] against one wall
-    (orient, axis_pos, endpoints, width); hard wall, no ghosts."""
-    orient, axis_pos, ep, width = wall
+    (orient, axis_pos, endpoints, width[, hard]); a ghost entity passes through a soft wall (:326-327)."""
+    orient, axis_pos, ep, width = wall[:4]
+    hard = wall[4] if len(wall) > 4 else True
     prll, perp = (0, 1) if orient == "H" else (1, 0)
     x = pos[..., prll]
     beyond = (x < ep[0] - size) | (x > ep[1] + size)
@@ -156,10 +158,13 @@ def wall_force(pos, size, wall, P, dtype=np.float64):
     f = np.zeros_like(pos)
     f[..., perp] = np.cos(theta) * mag
     f[..., prll] = np.sin(theta) * np.abs(mag)
+    if ghost is not None and not hard:
+        beyond = beyond | np.asarray(ghost, dtype=bool)[None, :]
     return np.where(beyond[..., None], dtype(0), f)
 
 
-def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None, mass=None, size=None):
+def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None, mass=None, size=None,
+                 movable=None, collide=None, ghost=None):
     """World.step for agent-only colliders (core.py:206-322 with the early-outs
     of :292-297 applied: landmarks have collide=False, so only agent-agent
     pairs survive).  pos, vel, act: [B,N,2].  Returns new (pos, vel).
@@ -170,6 +175,9 @@ def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None,
     core.py:268-277         v = v*(1-damping) + F/m*dt ; p += v*dt
     max_speed / accel: a scalar for every agent or one value per agent [N] (NaN = None for that agent);
     mass / size: per-agent arrays [N] (core.py:68-75: Entity.initial_mass, Entity.size), default P.mass / P.agent_size.
+    movable / collide / ghost: per-agent booleans [N] (core.py:54-58): a pair needs both to collide and one to move
+    (:292-295); against an immovable partner the force is not scaled by the mass ratio (:319-321); an immovable agent
+    takes no action force (:231) and is not integrated (:266-267); a ghost passes through soft walls (:326-327).
     """
     pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
     act = np.asarray(act, dtype=dtype)
@@ -187,21 +195,25 @@ def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None,
     pen = softplus_penetration(dist, dist_min[None], dtype(P.contact_margin))
     with np.errstate(invalid="ignore", divide="ignore"):
         f = dtype(P.contact_force) * delta / dist[..., None] * pen[..., None]
-    ratio = (m[None, :] / m[:, None]).astype(dtype)            # core.py:314-317: agent i receives (m_j / m_i) f
+    mov = np.ones(N, dtype=bool) if movable is None else np.asarray(movable, dtype=bool)
+    col = np.ones(N, dtype=bool) if collide is None else np.asarray(collide, dtype=bool)
+    both = mov[:, None] & mov[None, :]
+    ratio = np.where(both, m[None, :] / m[:, None], 1.0).astype(dtype)   # core.py:314-321: agent i receives (m_j / m_i) f, or f
     f = ratio[None, :, :, None] * f
-    eye = np.eye(N, dtype=bool)[None, :, :, None]
-    f = np.where(eye, dtype(0), f)                             # core.py:296 same entity
-    F = F + f.sum(2)
+    pair = col[:, None] & col[None, :] & (mov[:, None] | mov[None, :]) & ~np.eye(N, dtype=bool)   # :292-297
+    f = np.where(pair[None, :, :, None], f, dtype(0))
+    F = np.where(mov[None, :, None], F, dtype(0)) + f.sum(2)   # :231 an immovable agent takes no action force
     for w in (walls or []):                                    # core.py:255-261
-        F = F + wall_force(pos, sz[None, :], w, P, dtype)
-    vel = vel * dtype(1 - P.damping) + (F / m[None, :, None]) * dtype(P.dt)
+        F = F + wall_force(pos, sz[None, :], w, P, dtype, ghost=ghost)
+    new_vel = vel * dtype(1 - P.damping) + (F / m[None, :, None]) * dtype(P.dt)
     if max_speed is not None:                                  # core.py:271-276
         ms = np.broadcast_to(np.asarray(max_speed, dtype=np.float64), (N,))[None, :, None]
-        speed = np.sqrt((vel ** 2).sum(-1, keepdims=True))
+        speed = np.sqrt((new_vel ** 2).sum(-1, keepdims=True))
         with np.errstate(invalid="ignore", divide="ignore"):
-            vel = np.where(speed > ms, vel / speed * ms.astype(dtype), vel)     # NaN (None) compares False
-    pos = pos + vel * dtype(P.dt)
-    return pos, vel
+            new_vel = np.where(speed > ms, new_vel / speed * ms.astype(dtype), new_vel)     # NaN (None) compares False
+    new_pos = pos + new_vel * dtype(P.dt)
+    keep = ~mov[None, :, None]                                 # :266-267 not movable: state untouched
+    return np.where(keep, pos, new_pos), np.where(keep, vel, new_vel)
 
 
 def update_comm(action_c, silent=None, dtype=np.float64):
@@ -256,7 +268,7 @@ def observation_hd(pos, vel, ideal_shape, ideal_vel, dtype=np.float64, comm=None
     return obs
 
 
-def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64, size=None):
+def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64, size=None, collide=None):
     """formation_hd_env.py:61-75 for every agent + the integer by-products.
     Returns dict(indiv[B,N], shared[B], hd[B,2], hd_idx[B,4], near_lm[B,N],
     near_ag[B,N], cnt[B,N], gap_lm, gap_ag, cnt_margin)."""
@@ -278,6 +290,8 @@ def reward_hd(pos, vel, ideal_shape, ideal_vel, P, dtype=np.float64, size=None):
     close = PD < thr                                           # :121 strict <
     close[:, np.arange(N), np.arange(N)] = False               # :73 agent != a
     cnt = close.sum(2)
+    if collide is not None:                                    # :71 `if agent.collide:` - the penalties of a non-collider are not counted
+        cnt = np.where(np.asarray(collide, dtype=bool)[None, :], cnt, 0)
     indiv = -H[:, None] - velterm[:, None] - cnt               # :66,:69,:74
     shared = indiv.sum(1)                                      # environment.py:136
     near_lm = D.argmin(2); near_ag = D.argmin(1)
@@ -306,7 +320,8 @@ def step_hd(state, act, P=None, dtype=np.float64, **world_options):
     comm = world_options.pop("comm", None)                     # AgentState.c [B,N,2] of non-silent agents
     pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype, **world_options)
     step = np.asarray(state["step"]) + 1                       # environment.py:114
-    out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype, size=world_options.get("size"))
+    out = reward_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], P, dtype, size=world_options.get("size"),
+                    collide=world_options.get("collide"))
     out["obs"] = observation_hd(pos, vel, state["ideal_shape"], state["ideal_vel"], dtype, comm=comm)
     N = pos.shape[1]
     out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]    # :136-138
@@ -686,20 +701,27 @@ def reset_scn(kind, seed, N):
                 obst_vel=np.tile(np.array(P.obstacle_vel), (1, M, 1)), step=np.zeros(1, dtype=np.int32))
 
 
-def physics_entities(pos, vel, force0, size, P):
-    """World.step over E movable colliding entities with per-entity size and unit mass
-    (core.py:240-277; force ratio m_b/m_a = 1).  force0 = non-contact force per entity."""
+def physics_entities(pos, vel, force0, size, P, mass=None, max_speed=None):
+    """World.step over E movable colliding entities with per-entity size and mass
+    (core.py:240-277; force ratio m_b / m_a :314-317; speed clamp :271-276, NaN = None).  force0 = non-contact force per entity."""
     pos = np.asarray(pos, dtype=np.float64); vel = np.asarray(vel, dtype=np.float64)
     E = pos.shape[1]
+    m = np.full(E, P.mass) if mass is None else np.asarray(mass, dtype=np.float64)
     delta = pos[:, :, None, :] - pos[:, None, :, :]
     dist = np.sqrt((delta ** 2).sum(-1))
     dmin = size[:, None] + size[None, :]
     pen = softplus_penetration(dist, dmin[None], P.contact_margin)
     with np.errstate(invalid="ignore", divide="ignore"):
         f = P.contact_force * delta / dist[..., None] * pen[..., None]
+    f = (m[None, :] / m[:, None])[None, :, :, None] * f
     f = np.where(np.eye(E, dtype=bool)[None, :, :, None], 0.0, f)
     F = force0 + f.sum(2)
-    vel = vel * (1 - P.damping) + (F / P.mass) * P.dt
+    vel = vel * (1 - P.damping) + (F / m[None, :, None]) * P.dt
+    if max_speed is not None:
+        ms = np.asarray(max_speed, dtype=np.float64)[None, :, None]
+        speed = np.sqrt((vel ** 2).sum(-1, keepdims=True))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            vel = np.where(speed > ms, vel / speed * ms, vel)
     return pos + vel * P.dt, vel
 
 
@@ -727,9 +749,10 @@ def observation_scn(kind, pos, vel, lm, obst_pos, P):
     return np.concatenate((vel, lm_abs, ob_rel, rel[:, keep].reshape(B, N, 2 * (N - 1)), zeros), 2)
 
 
-def step_scn(kind, state, act, P=None):
+def step_scn(kind, state, act, P=None, mass=None, size=None, max_speed=None):
     """One env.step of the three scenarios.  state: pos, vel [B,N,2], landmarks [B,L,2],
-    obst_pos, obst_vel [B,M,2], step [B]."""
+    obst_pos, obst_vel [B,M,2], step [B].  mass / size / max_speed: per-agent arrays [N] (core.py:45-109; the obstacles keep
+    the scenario's size and unit mass)."""
     P = P or ScnParams(kind)
     pos = np.asarray(state["pos"], dtype=np.float64); vel = np.asarray(state["vel"], dtype=np.float64)
     act = np.asarray(act, dtype=np.float64)
@@ -737,22 +760,26 @@ def step_scn(kind, state, act, P=None):
     M = P.num_obstacles
     op = np.asarray(state["obst_pos"], dtype=np.float64).reshape(B, M, 2)
     ov = np.asarray(state["obst_vel"], dtype=np.float64).reshape(B, M, 2)
-    size = np.array([P.agent_size] * N + [P.obstacle_size] * M)
-    F0 = np.concatenate((P.mass * P.sensitivity * act, np.zeros((B, M, 2))), 1)
-    ep, ev = physics_entities(np.concatenate((pos, op), 1), np.concatenate((vel, ov), 1), F0, size, P)
+    asz = np.full(N, P.agent_size) if size is None else np.asarray(size, dtype=np.float64)
+    am = np.full(N, P.mass) if mass is None else np.asarray(mass, dtype=np.float64)
+    size = np.concatenate((asz, [P.obstacle_size] * M))
+    F0 = np.concatenate((am[None, :, None] * P.sensitivity * act, np.zeros((B, M, 2))), 1)
+    ems = None if max_speed is None else np.concatenate((np.asarray(max_speed, dtype=np.float64), [np.nan] * M))
+    ep, ev = physics_entities(np.concatenate((pos, op), 1), np.concatenate((vel, ov), 1), F0, size, P,
+                              mass=np.concatenate((am, [1.0] * M)), max_speed=ems)
     pos, vel, op, ov = ep[:, :N], ev[:, :N], ep[:, N:], ev[:, N:]
     step = np.asarray(state["step"]) + 1
     lm = np.asarray(state["landmarks"], dtype=np.float64)
     H = _hausdorff_centred(pos, lm)
     PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
-    close = PD < P.collide_thresh
+    close = PD < (asz[:, None] + asz[None, :])[None]           # is_collision: dist < size_a + size_b
     close[:, np.arange(N), np.arange(N)] = False
     indiv = -H[:, None] - P.penalty * close.sum(2)
     if M:
         # reward side effect: obstacles keep falling until the floor (formation_hd_obs_env.py:84-89)
         ov = np.where((op[..., 1] > P.obstacle_floor)[..., None], np.array(P.obstacle_vel), 0.0)
         OD = np.sqrt(((pos[:, :, None, :] - op[:, None, :, :]) ** 2).sum(-1))
-        indiv = indiv - P.penalty * (OD < P.agent_size + P.obstacle_size).sum(2)
+        indiv = indiv - P.penalty * (OD < asz[None, :, None] + P.obstacle_size).sum(2)
     out = dict(indiv=indiv, shared=indiv.sum(1), obs=observation_scn(kind, pos, vel, lm, op, P))
     out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]
     out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)

@@ -25,7 +25,7 @@ for N, B in ((9, 4096), (27, 4096), (27, 256), (81, 2048)):
         venv.reset()
         env.world.step_count.copy_((torch.arange(B, device=dev) % 100).int())     # episodes end at different steps
         if mode == "device_mt":
-            venv._host_steps = env.world.step_count.cpu().numpy().astype("int64")
+            venv.ts[:] = env.world.step_count.cpu().numpy()
         act = torch.rand((B, N, 2), device=dev) * 2 - 1
         for _ in range(30):
             venv.step(act)

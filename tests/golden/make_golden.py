@@ -119,6 +119,7 @@ def _hd_extras(pos, shape, thresh):
 
 
 WALLS = [("V", -0.9, (-1.0, 1.0), 0.1), ("V", 0.9, (-0.6, 0.6), 0.1), ("H", 0.8, (-0.5, 0.5), 0.2)]
+SOFT_WALLS = [("H", -0.05, (-0.4, 0.4), 0.1)]            # through the crowd: felt by everybody but the ghosts
 
 
 def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=None):
@@ -140,6 +141,12 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
                 a.accel = options.get("accel")
             if options.get("walls"):
                 env.world.walls = [rcore.Wall(o, ax, ep, w) for (o, ax, ep, w) in WALLS]
+            if options.get("soft_walls"):                 # a ghost entity passes through a soft wall (core.py:326-327)
+                env.world.walls = env.world.walls + [rcore.Wall(o, ax, ep, w, hard=False) for (o, ax, ep, w) in SOFT_WALLS]
+            fl = options.get("flags")                     # Entity.collide / Entity.ghost per agent (core.py:54-58)
+            if fl:
+                for a, c_, g_ in zip(env.world.agents, fl["collide"], fl["ghost"]):
+                    a.collide = bool(c_); a.ghost = bool(g_)
             het = options.get("hetero")                   # per-agent mass / size / accel / max_speed (core.py:45-109)
             if het:
                 for a, m_, s_, ac_, ms_ in zip(env.world.agents, het["mass"], het["size"], het["accel"], het["max_speed"]):
@@ -197,6 +204,50 @@ def rollout_hd(fg, N, B, T, seed, act_seed, crowd=None, obs_at=None, options=Non
         res.update({"world_" + k: np.array(v) for k, v in options["world"].items()})
     if options and options.get("hetero"):
         res.update({"agent_" + k: np.array(v, dtype=np.float64) for k, v in options["hetero"].items()})
+    if options and options.get("flags"):
+        res.update({"agent_" + k: np.array(v, dtype=np.bool_) for k, v in options["flags"].items()})
+    return res
+
+
+def immovable_fixture(fg, N, T, seed, act_seed, crowd):
+    """An immovable agent (core.py:231, 266-267, 294-295, 319-321) and a non-colliding one (:292-293) among agents of
+    different mass.  The reference's env.step cannot take a silent immovable agent (`assert len(action) == 0`,
+    environment.py:236 - recorded below), so the World is driven through core.py's own API as in comm_fixture."""
+    env = fg.make_env("formation_hd_env", False, N)
+    sc = _scenario_of(env)
+    world = env.world
+    movable = np.ones(N, dtype=bool); movable[1] = False
+    collide = np.ones(N, dtype=bool); collide[N - 2] = False
+    mass = np.random.RandomState(seed).uniform(0.5, 2.5, N)
+    for a, m_, c_, ms_ in zip(world.agents, movable, collide, mass):
+        a.movable = bool(m_); a.collide = bool(c_); a.initial_mass = float(ms_)
+    env.seed(seed)
+    env.reset()
+    for a in world.agents:
+        a.state.p_pos = a.state.p_pos * crowd
+    world.agents[1].state.p_vel = np.array([0.3, -0.2])          # an immovable agent keeps whatever velocity it has (:266-267)
+    p0, v0 = _state(env)
+    try:
+        env.step([np.zeros(2) for _ in range(N)])
+        raised = "none"
+    except Exception as exc:                                      # noqa: BLE001
+        raised = type(exc).__name__ + ": " + str(exc)
+    for a, p_, v_ in zip(world.agents, p0, v0):                  # undo whatever the failed call did
+        a.state.p_pos = p_.copy(); a.state.p_vel = v_.copy()
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    rec = {k: [] for k in ("pos", "vel", "obs", "indiv")}
+    for t in range(T):
+        for i, a in enumerate(world.agents):
+            a.action.u = 5.0 * acts[t, i].astype(np.float64)     # what _set_action does for a movable agent (environment.py:216-221)
+        world.step()
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["obs"].append(np.array([sc.observation(a, world) for a in world.agents], dtype=np.float64))
+        rec["indiv"].append(np.array([sc.reward(a, world) for a in world.agents], dtype=np.float64))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, acts=acts, movable=movable, collide=collide, mass=mass,
+               ideal_shape=np.array(sc.ideal_shape, dtype=np.float64), ideal_vel=np.array(sc.ideal_vel, dtype=np.float64),
+               seed=np.array(seed), env_step_raises=np.array(raised))
     return res
 
 
@@ -295,9 +346,10 @@ def rollout_action_mode(fg, mode, N, T, seed, act_seed):
     return res
 
 
-def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None):
+def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None, hetero=None):
     """Seeded rollout of one of the remaining scenarios (formation_hd_partial_env,
-    formation_hd_partial_range_env, formation_hd_obs_env) through the reference API."""
+    formation_hd_partial_range_env, formation_hd_obs_env) through the reference API.  hetero: per-agent mass / size /
+    max_speed (core.py:45-109) on top of the file's own make_world - the obstacles keep theirs."""
     acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
     keys = ("pos", "vel", "lm", "lmvel", "obs", "indiv", "shared", "done")
     out = {k: [] for k in keys}
@@ -305,6 +357,10 @@ def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None):
     meta = {}
     for b in range(B):
         env = fg.make_env(name, False, N)
+        if hetero:
+            for a, m_, s_, ms_ in zip(env.world.agents, hetero["mass"], hetero["size"], hetero["max_speed"]):
+                a.initial_mass = float(m_); a.size = float(s_)
+                a.max_speed = None if np.isnan(ms_) else float(ms_)
         env.seed(seed + 1000 * b)
         o0 = env.reset()
         if crowd is not None:
@@ -340,6 +396,8 @@ def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None):
     res.update(meta)
     res.update(acts=acts, seed=np.array(seed), act_seed=np.array(act_seed),
                crowd=np.array(-1.0 if crowd is None else crowd))
+    if hetero:
+        res.update({"agent_" + k: np.array(v, dtype=np.float64) for k, v in hetero.items()})
     return res
 
 
@@ -472,19 +530,70 @@ def plugin_fixture(fg, path, N, T, seed, act_seed):
     obs0 = np.array(env.reset(), dtype=np.float64)
     p0, v0 = _state(env)
     acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, N, 2)).astype(np.float32)
-    rec = {k: [] for k in ("pos", "vel", "obs", "indiv", "shared", "done")}
+    rec = {k: [] for k in ("pos", "vel", "obs", "indiv", "shared", "done", "lm_pos", "lm_vel")}
+    lm0 = np.array([l.state.p_pos for l in world.landmarks], dtype=np.float64)
+    lv0 = np.array([l.state.p_vel if l.state.p_vel is not None else np.zeros(2) for l in world.landmarks], dtype=np.float64)
     for t in range(T):
         obs_n, rew_n, done_n, info_n = env.step([acts[t, i].astype(np.float64) for i in range(N)])
         p, v = _state(env)
         rec["pos"].append(p); rec["vel"].append(v)
+        rec["lm_pos"].append(np.array([l.state.p_pos for l in world.landmarks], dtype=np.float64))
+        rec["lm_vel"].append(np.array([l.state.p_vel if l.state.p_vel is not None else np.zeros(2) for l in world.landmarks],
+                                      dtype=np.float64))
         rec["obs"].append(np.array(obs_n, dtype=np.float64))
         rec["indiv"].append(np.array([inf["individual_reward"] for inf in info_n]))
         rec["shared"].append(rew_n[0][0])
         rec["done"].append(np.array(done_n, dtype=np.bool_))
     res = {k: np.array(v) for k, v in rec.items()}
-    res.update(pos0=p0, vel0=v0, obs0=obs0, acts=acts, seed=np.array(seed), radius=np.array(scenario.radius),
+    res.update(pos0=p0, vel0=v0, obs0=obs0, acts=acts, seed=np.array(seed), radius=np.array(getattr(scenario, "radius", 0.0)),
+               lm_pos0=lm0, lm_vel0=lv0,
                beacon=np.array(world.landmarks[0].state.p_pos, dtype=np.float64),
                obs_dim=np.array(env.observation_space[0].shape[0]), world_length=np.array(env.world_length))
+    return res
+
+
+def vec_env_fixture(fg, N, B, T, seed, act_seed):
+    """What an RL caller of the reference gets from its vectorised env (train/maddpg-v2/utils/env_wrappers.py): B envs seeded
+    seed + 1000 rank (main.py:19-30), stepped by the body of DummyVecEnv.step_wait (:113-122; `baselines`, its base class, is
+    absent, so the loop is restated HERE, in the generator): stack, ts += 1, reset the envs whose agents are all done, return
+    the RESET observation with the finished step's rewards / dones.  SubprocVecEnv's worker does the same per env (:14-18)."""
+    envs = []
+    for rank in range(B):
+        env = fg.make_env("formation_hd_env", False, N)
+        env.seed(seed + rank * 1000)
+        np.random.seed(seed + rank * 1000)                       # main.py:24-25
+        envs.append(env)
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
+    states = [np.random.RandomState(seed + rank * 1000).get_state() for rank in range(B)]
+
+    def with_stream(b, fn):                                       # every env draws from its own global stream, as its process would
+        saved = np.random.get_state()
+        np.random.set_state(states[b])
+        try:
+            return fn()
+        finally:
+            states[b] = np.random.get_state()
+            np.random.set_state(saved)
+    obs0 = np.array([with_stream(b, envs[b].reset) for b in range(B)])
+    ts = np.zeros(B, dtype='int')
+    rec = {k: [] for k in ("obs", "rews", "dones", "ts", "indiv")}
+    info_kind = None
+    for t in range(T):
+        results = [env.step([a_.astype(np.float64) for a_ in a]) for (a, env) in zip(acts[t], envs)]
+        obs, rews, dones, infos = map(np.array, zip(*results))
+        ts += 1
+        for (i, done) in enumerate(dones):
+            if all(done):
+                obs[i] = with_stream(i, envs[i].reset)
+                ts[i] = 0
+        rec["obs"].append(np.array(obs)); rec["rews"].append(np.array(rews)); rec["dones"].append(np.array(dones))
+        rec["ts"].append(ts.copy())
+        rec["indiv"].append(np.array([[d["individual_reward"] for d in row] for row in infos]))
+        info_kind = "%s %s %s" % (type(infos).__name__, infos.shape, sorted(infos[0][0].keys()))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(obs0=obs0, acts=acts, seed=np.array(seed), info_kind=np.array(info_kind),
+               agent_types=np.array(['adversary' if a.adversary else 'agent' for a in envs[0].agents]),
+               world_length=np.array(envs[0].world_length))
     return res
 
 
@@ -542,6 +651,12 @@ def main():
                                             options=dict(hetero=hetero_options(9, 95))))
     save("hd_n27_masses", lambda: rollout_hd(fg, 27, 2, 10, seed=96, act_seed=97, crowd=0.45, obs_at=[10],
                                              options=dict(hetero=hetero_options(27, 98), walls=True)))
+    # agents that do not collide, ghosts and a soft wall (core.py:292-293, 326-327), through env.step
+    save("hd_n9_flags", lambda: rollout_hd(fg, 9, 2, 14, seed=103, act_seed=104, crowd=0.22, obs_at=[1, 14],
+                                           options=dict(walls=True, soft_walls=True, hetero=hetero_options(9, 105),
+                                                        flags=dict(collide=np.arange(9) % 4 != 2, ghost=np.arange(9) % 3 == 1))))
+    # an immovable agent, driven through the World API (env.step asserts on it)
+    save("hd_n6_immovable", lambda: immovable_fixture(fg, 6, 12, seed=107, act_seed=108, crowd=0.2))
     # non-silent agents: World.step + Scenario.observation with state.c in the communication block
     save("hd_n5_comm", lambda: comm_fixture(fg, 5, 10, seed=99, act_seed=100, crowd=0.3))
     save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))
@@ -562,6 +677,11 @@ def main():
     # a reference-style plugin file of this repo (not of the reference), executed by the reference's env shell
     plugin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plugins", "ring_patrol_env.py")
     save("ring_patrol_n5", lambda: plugin_fixture(fg, plugin, 5, 22, seed=61, act_seed=62))
+    # the vec-env loop of the trainers (DummyVecEnv.step_wait restated), across an episode end
+    save("vec_env_n3", lambda: vec_env_fixture(fg, 3, 3, 104, seed=81, act_seed=82))
+    # ... and one whose landmarks collide (movable rocks, an immovable pillar) and whose reward callback writes state
+    rocks = os.path.join(os.path.dirname(plugin), "drifting_rocks_env.py")
+    save("drifting_rocks_n4", lambda: plugin_fixture(fg, rocks, 4, 15, seed=71, act_seed=72))
     # non-default action modes of _set_action (environment.py:187-216)
     save("act_onehot5_n3", lambda: rollout_action_mode(fg, "onehot5", 3, 8, seed=71, act_seed=81))
     save("act_index_n9", lambda: rollout_action_mode(fg, "index", 9, 8, seed=72, act_seed=82))
@@ -574,6 +694,13 @@ def main():
     save("range_n7_crowd", lambda: rollout_scn(fg, "formation_hd_partial_range_env", 7, 3, 12, seed=55, act_seed=65, crowd=0.2))
     save("obst_n4", lambda: rollout_scn(fg, "formation_hd_obs_env", 4, 3, 52, seed=56, act_seed=66))
     save("obst_n8", lambda: rollout_scn(fg, "formation_hd_obs_env", 8, 2, 40, seed=57, act_seed=67))
+    # agents of different mass / size / max_speed among the falling obstacles (force ratio m_b / m_a, contact distance size_a + size_b)
+    save("obst_n5_masses", lambda: rollout_scn(fg, "formation_hd_obs_env", 5, 3, 30, seed=58, act_seed=68, crowd=0.35,
+                                               hetero=dict(mass=[0.6, 1.0, 2.5, 1.4, 0.8], size=[0.06, 0.1, 0.14, 0.08, 0.12],
+                                                           max_speed=[np.nan, 0.5, np.nan, np.nan, 0.8])))
+    save("partial_n6_masses", lambda: rollout_scn(fg, "formation_hd_partial_env", 6, 2, 14, seed=59, act_seed=69, crowd=0.12,
+                                                  hetero=dict(mass=[0.5, 1.0, 2.0, 3.0, 1.5, 0.7], size=[0.03, 0.05, 0.07, 0.04, 0.06, 0.05],
+                                                              max_speed=[np.nan] * 6)))
 
 
 if __name__ == "__main__":

@@ -59,7 +59,7 @@ def test_abi_version_and_struct_layout(lib, tmp_path):
         for fname, _ in cls._fields_:
             assert int(got["%s.%s" % (name, fname)]) == getattr(cls, fname).offset, (name, fname)
     assert _native.MAX_WALLS == 4 and "#define FG_MAX_WALLS 4" in open(HEADER).read()
-    assert _native.AGENT_PROPS == 6 and "#define FG_AGENT_PROPS 6" in open(HEADER).read()
+    assert _native.AGENT_PROPS == 8 and "#define FG_AGENT_PROPS 8" in open(HEADER).read()
 
 
 def test_algorithmic_bytes_and_geometry(lib):
@@ -129,12 +129,12 @@ def test_argument_validation_before_any_launch(lib):
     assert lib.fg_decode_actions(_native.FG_ACT_INDEX, -3, p, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ONEHOT5, 12, None, p, None) == _native.FG_ERR_BAD_ARG
     assert lib.fg_decode_actions(_native.FG_ACT_ARGMAX, 12, p + 4, p, None) == _native.FG_ERR_ALIGNMENT
-    # ABI 6: per-agent table / communication state pointers are checked for alignment, the landmark-scenario entry
-    # points refuse them instead of ignoring them
+    # per-agent table / communication state pointers are checked for alignment; the landmark-scenario entry points take
+    # the table (ABI 7) and refuse the communication state instead of ignoring it
     assert lib.fg_step_hd(_params(agent_props=p + 2), 4, 9, *ok_ptrs) == _native.FG_ERR_ALIGNMENT
     assert lib.fg_step_hd(_params(comm_state=p + 4), 4, 9, *ok_ptrs) == _native.FG_ERR_ALIGNMENT
     assert lib.fg_step_hd(_params(dist_min=0.0), 4, 9, *ok_ptrs) == _native.FG_ERR_BAD_ARG
-    assert lib.fg_step_basic(_params(agent_props=p), 4, 3, 3, 1, *([p] * 13)) == _native.FG_ERR_BAD_ARG
+    assert lib.fg_step_basic(_params(comm_state=p), 4, 3, 3, 1, *([p] * 13)) == _native.FG_ERR_BAD_ARG
     assert b"formation_hd_env entry points only" in lib.fg_last_error()
     assert lib.fg_update_comm(P, 0, 9, None, None, None) == _native.FG_OK
     assert lib.fg_update_comm(P, 4, 9, None, p, None) == _native.FG_ERR_BAD_ARG

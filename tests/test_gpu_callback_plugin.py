@@ -85,3 +85,60 @@ def test_reference_style_plugin_batched():
     assert many.benchmark_data if hasattr(many, "benchmark_data") else True
     bd = many.scenario.benchmark_data(many.world.agents[1], many.world)
     assert "ring_error" in bd
+
+
+def test_plugin_with_colliding_landmarks_matches_the_reference(golden):
+    """tests/plugins/drifting_rocks_env.py (ORIGINAL): movable rocks of their own mass that push the agents, an immovable
+    pillar that only pushes back, a beacon nobody collides with, and a reward callback that re-arms the rocks' velocity every
+    step - the features of the reference's formation_hd_obs_env.py (:36-42, :82-89) in a file the real reference ran
+    (fixture drifting_rocks_n4).  Through make_env(<path>): the landmarks that collide ride along in the GPU physics."""
+    import formation_gym
+    g = golden("drifting_rocks_n4")
+    T, N = g["acts"].shape[:2]
+    rocks = os.path.join(os.path.dirname(PLUGIN), "drifting_rocks_env.py")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        env = formation_gym.make_env(rocks, False, N, device="cuda:0")
+    assert env.num_agents == N and len(env.world.agents) == N + 3          # two rocks and the pillar behind the agents
+    assert env.observation_space[0].shape == (int(g["obs_dim"]),)
+    env.seed(int(g["seed"]))
+    obs0 = env.reset()
+    np.testing.assert_allclose(np.array(obs0), g["obs0"], rtol=0, atol=ATOL)
+    hw = env.scenario.host_worlds[0]
+
+    def landmarks():
+        return (np.array([l.state.p_pos for l in hw.landmarks]), np.array([l.state.p_vel for l in hw.landmarks]))
+    # free-running from the reset (the rewards are smooth): the trajectory, the rocks' included
+    for t in range(T):
+        obs_n, rew_n, done_n, info_n = env.step([g["acts"][t, i].astype(np.float64) for i in range(N)])
+        pos, vel = env.world.get_state()
+        tol = ATOL if t < 5 else 2e-4
+        np.testing.assert_allclose(pos[0, :N].double().cpu().numpy(), g["pos"][t], rtol=0, atol=tol)
+        lp, lv = landmarks()
+        np.testing.assert_allclose(lp, g["lm_pos"][t], rtol=0, atol=tol)
+        np.testing.assert_allclose(lv, g["lm_vel"][t], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=10 * tol)
+        assert done_n == list(g["done"][t])
+    assert np.abs(g["lm_pos"][-1][1] - g["lm_pos0"][1]).max() > 0.1           # the rocks really moved ...
+    np.testing.assert_array_equal(g["lm_pos"][-1][2], g["lm_pos0"][2])        # ... the pillar never does
+    # teacher-forced at 1e-5: every step from the reference's own previous state of agents AND landmarks
+    env.seed(int(g["seed"]))
+    env.reset()
+    prev = dict(pos=g["pos0"], vel=g["vel0"], lp=g["lm_pos0"], lv=g["lm_vel0"])
+    for t in range(T):
+        for a, p_, v_ in zip(hw.agents, prev["pos"], prev["vel"]):
+            a.state.p_pos = p_.copy(); a.state.p_vel = v_.copy()
+        for l, p_, v_ in zip(hw.landmarks, prev["lp"], prev["lv"]):
+            l.state.p_pos = p_.copy(); l.state.p_vel = v_.copy()
+        env.scenario._upload(env.world)
+        obs_n, rew_n, done_n, info_n = env.step([g["acts"][t, i].astype(np.float64) for i in range(N)])
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(pos[0, :N].double().cpu().numpy(), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(vel[0, :N].double().cpu().numpy(), g["vel"][t], rtol=0, atol=ATOL)
+        lp, lv = landmarks()
+        np.testing.assert_allclose(lp, g["lm_pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(lv, g["lm_vel"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=ATOL)
+        prev = dict(pos=g["pos"][t], vel=g["vel"][t], lp=g["lm_pos"][t], lv=g["lm_vel"][t])

@@ -102,7 +102,7 @@ def test_identical_table_rows_equal_the_scalar_description():
         e.seed(4); e.reset()
         e.world.set_state(pos=e.world.get_state()[0] * 0.3)
     p = e2.scenario.params(e2.world)
-    rows = torch.tensor([[1.0, 0.03, 0, 0, 0, -1.0]] * N, dtype=torch.float32, device="cuda")
+    rows = torch.tensor([[1.0, 0.03, 0, 0, 0, -1.0, 0, 0]] * N, dtype=torch.float32, device="cuda")
     act = torch.rand((B, N, 2), device="cuda") * 2 - 1
     o1, r1, _, i1 = e1.step(act.clone())
     from formation_gym import _native
@@ -193,3 +193,122 @@ def test_comm_block_at_batch_sizes_and_launch_paths(N, B):
     tol = 4.5 * 0.25 / np.sqrt(d1.size)                      # 4.5 standard errors of the mean (std: / sqrt(2), well inside)
     assert abs(d1.std() - 0.25) < tol and abs(d1.mean()) < tol and np.abs(d1 - d2).max() > 0.1
     assert (_np(comm_c)[:, silent] == 0).all()
+
+
+def test_non_colliding_agents_ghosts_and_a_soft_wall_teacher_forced(golden):
+    """Entity.collide / Entity.ghost per agent (core.py:54-58, 292-293, 326-327) with hard walls and a soft one, agents of
+    different mass and size, through env.step: the reference's trajectory, teacher-forced at 1e-5; a K-step launch gives
+    the single steps' bits."""
+    from formation_gym.core import Wall
+    g = golden("hd_n9_flags")
+    T, B, N = g["acts"].shape[:3]
+    assert (~g["agent_collide"]).any() and g["agent_ghost"].any()
+
+    def build():
+        env = _make(N, B)
+        _apply_hetero(env, g, walls=True)
+        env.world.walls = env.world.walls + [Wall(o, ax, ep, w, hard=False) for (o, ax, ep, w) in O.GOLDEN_SOFT_WALLS]
+        for a, c, gh in zip(env.world.agents, g["agent_collide"], g["agent_ghost"]):
+            a.collide = bool(c); a.ghost = bool(gh)
+        return env
+    env = build()
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    felt_soft_wall = False
+    for t in range(T):
+        _load(env, prev_pos, prev_vel, g["ideal_shape"], g["ideal_vel"], np.full(B, t))
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
+        ok = g["cnt_margin"][t] > 1e-5
+        np.testing.assert_allclose(_np(info["individual_reward"])[ok], g["indiv"][t][ok], rtol=0, atol=ATOL)
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(_np(obs), g["obs_t%d" % (t + 1)], rtol=0, atol=ATOL)
+        # the fixture means something: without the flags the oracle's step differs from the reference's
+        plain, _ = O.step_hd(dict(pos=prev_pos, vel=prev_vel, ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"], step=np.full(B, t)),
+                             g["acts"][t].astype(np.float64), mass=g["agent_mass"], size=g["agent_size"], accel=g["agent_accel"],
+                             max_speed=g["agent_max_speed"], walls=O.GOLDEN_WALLS + [w + (False,) for w in O.GOLDEN_SOFT_WALLS])
+        felt_soft_wall = felt_soft_wall or np.abs(plain["pos"] - g["pos"][t]).max() > 1e-4
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    assert felt_soft_wall
+    # a non-colliding agent collects no collision penalties (formation_hd_env.py:71)
+    e1, e2 = build(), build()
+    for e in (e1, e2):
+        _load(e, g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], np.zeros(B))
+    acts = torch.as_tensor(g["acts"][:6]).cuda().contiguous()
+    o_seq, r_seq, _, i_seq = e1.rollout(acts)
+    for t in range(6):
+        o, r, _, i = e2.step(acts[t])
+        assert torch.equal(o, o_seq[t]) and torch.equal(r, r_seq[t]) and torch.equal(i["individual_reward"], i_seq["individual_reward"][t])
+
+
+def test_immovable_agent_through_the_world_api(golden):
+    """An immovable agent (core.py:231, 266-267, 294-295, 319-321) among agents of different mass, one of them not
+    colliding: agent.action.u set per agent, world.step(), scenario.observation / reward (the reference's env.step asserts
+    on a silent immovable agent, environment.py:236, and so does this one)."""
+    import formation_gym
+    g = golden("hd_n6_immovable")
+    T, N = g["acts"].shape[:2]
+    assert str(g["env_step_raises"]).startswith("AssertionError")
+    env = formation_gym.make_env("formation_hd_env", False, N, device="cuda:0")
+    world, sc = env.world, env.scenario
+    for a, mv, cl, m in zip(world.agents, g["movable"], g["collide"], g["mass"]):
+        a.movable = bool(mv); a.collide = bool(cl); a.initial_mass = float(m)
+    with pytest.raises(AssertionError):
+        env.step([np.zeros(2) for _ in range(N)])
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros((1, N, 2), device="cuda"))
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    frozen = int(np.flatnonzero(~g["movable"])[0])
+    for t in range(T):
+        _load(env, prev_pos[None], prev_vel[None], g["ideal_shape"][None], g["ideal_vel"][None], np.zeros(1))   # teacher-forced
+        for i, a in enumerate(world.agents):
+            a.action.u = torch.as_tensor(g["acts"][t, i])[None]            # RAW action: the x5 of _set_action happens in-kernel
+        world.step()
+        pos, vel = world.get_state()
+        np.testing.assert_allclose(_np(pos)[0], g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel)[0], g["vel"][t], rtol=0, atol=ATOL)
+        np.testing.assert_array_equal(_np(pos)[0, frozen], g["pos0"][frozen].astype(np.float32).astype(np.float64))   # never moves
+        obs = np.stack([_np(sc.observation(a, world))[0] for a in world.agents])
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=0, atol=ATOL)
+        rew = np.array([float(sc.reward(a, world)[0]) for a in world.agents])
+        np.testing.assert_allclose(rew, g["indiv"][t], rtol=0, atol=ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    assert np.abs(g["vel"][:, frozen] - g["vel0"][frozen]).max() == 0       # (the reference leaves its velocity alone too)
+
+
+@pytest.mark.parametrize("N,B", [(5, 60), (27, 33), (70, 7), (130, 4)])
+def test_random_entity_flags_against_oracle(N, B):
+    """Random movable / collide / ghost flags with soft and hard walls over lane-group and whole-workgroup agent counts:
+    one teacher-forced step vs the fp64 oracle on the same fp32 inputs."""
+    from formation_gym.core import Wall
+    rs = np.random.RandomState(77 + N)
+    env = _make(N, B)
+    movable = rs.uniform(size=N) > 0.25; collide = rs.uniform(size=N) > 0.25; ghost = rs.uniform(size=N) > 0.5
+    movable[0] = True
+    mass = rs.uniform(0.5, 3.0, N)
+    for a, mv, cl, gh, m in zip(env.world.agents, movable, collide, ghost, mass):
+        a.movable = bool(mv); a.collide = bool(cl); a.ghost = bool(gh); a.initial_mass = float(m)
+    walls = [("V", -0.3, (-1.0, 1.0), 0.1, True), ("H", 0.1, (-0.5, 0.5), 0.1, False)]
+    env.world.walls = [Wall(o, ax, ep, w, hard=h) for (o, ax, ep, w, h) in walls]
+    f32 = lambda x: np.asarray(x, dtype=np.float32).astype(np.float64)
+    spread = 0.4 * np.sqrt(N / 27.0)
+    pos = f32(rs.uniform(-spread, spread, (B, N, 2))); vel = f32(rs.uniform(-0.5, 0.5, (B, N, 2)))
+    shape = rs.uniform(-1, 1, (B, N, 2)); shape = f32(shape - shape.mean(1, keepdims=True))
+    ivel = f32(rs.uniform(-1, 1, (B, 2)))
+    act = rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)
+    _load(env, pos, vel, shape, ivel, np.zeros(B))
+    env.world.action_u.copy_(torch.as_tensor(act))
+    env.world.step()                                                     # the World API: immovable agents are allowed here
+    out_t = dict(obs=torch.empty((B, N, 6 * N), device="cuda"), reward=torch.empty((B, N), device="cuda"),
+                 indiv=torch.empty((B, N), device="cuda"))
+    env.scenario.observe_batch(env.world, out_t)
+    st = dict(pos=pos, vel=vel, ideal_shape=shape, ideal_vel=ivel, step=np.zeros(B, dtype=np.int32))
+    new, out = O.step_hd(st, act.astype(np.float64), mass=f32(mass), movable=movable, collide=collide, ghost=ghost, walls=walls)
+    p_, v_ = env.world.get_state()
+    np.testing.assert_allclose(_np(p_), new["pos"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(v_), new["vel"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(out_t["obs"]), out["obs"], rtol=0, atol=ATOL)
+    ok = out["cnt_margin"] > 1e-5
+    np.testing.assert_allclose(_np(out_t["indiv"])[ok], out["indiv"][ok], rtol=0, atol=ATOL)
+    assert (out["cnt"][:, ~collide] == 0).all() and out["cnt"].sum() > 0

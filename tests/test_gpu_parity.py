@@ -413,6 +413,59 @@ def test_remaining_scenarios_teacher_forced(golden, scenario, kind, name):
         np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
 
 
+@pytest.mark.parametrize("scenario,kind,name", [("formation_hd_obs_env", "obstacle", "obst_n5_masses"),
+                                                ("formation_hd_partial_env", "partial", "partial_n6_masses")])
+def test_landmark_scenarios_with_per_agent_tables(golden, scenario, kind, name):
+    """Agents of different mass / size / max_speed in the landmark scenarios (FgParams.agent_props through fg_step_scenario:
+    force ratio m_b / m_a core.py:314-317, contact and penalty distance size_a + size_b, per-agent speed clamp) among the
+    obstacles of formation_hd_obs_env (:36-42), teacher-forced against the reference; K-step launch == single steps."""
+    g = golden(name)
+    P = O.ScnParams(kind)
+    T, B, N = g["acts"].shape[:3]
+    L = P.num_landmarks
+
+    def build():
+        env = _make(N, B, scenario)
+        for a, m, s_, ms in zip(env.world.agents, g["agent_mass"], g["agent_size"], g["agent_max_speed"]):
+            a.initial_mass = float(m); a.size = float(s_); a.max_speed = None if np.isnan(ms) else float(ms)
+        return env
+
+    def load(env, pos, vel, lm, lmvel, step):
+        env.world.set_state(pos, vel)
+        env.world.landmark_pos.copy_(torch.as_tensor(lm[:, :L], dtype=torch.float32))
+        if P.num_obstacles:
+            env.world.obstacle_pos.copy_(torch.as_tensor(lm[:, L:], dtype=torch.float32))
+            env.world.obstacle_vel.copy_(torch.as_tensor(lmvel[:, L:], dtype=torch.float32))
+        env.world.step_count.fill_(step)
+    env = build()
+    penalties = 0
+    for t in range(T):
+        src = (lambda k: g[k + "0"]) if t == 0 else (lambda k: g[k][t - 1])
+        load(env, src("pos"), src("vel"), src("lm"), src("lmvel"), t)
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        pos, vel = env.world.get_state()
+        np.testing.assert_allclose(_np(pos), g["pos"][t], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(vel), g["vel"][t], rtol=0, atol=ATOL)
+        if P.num_obstacles:
+            np.testing.assert_allclose(_np(env.world.obstacle_pos), g["lm"][t][:, L:], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(obs), g["obs"][t], rtol=0, atol=ATOL)
+        bad = np.abs(_np(info["individual_reward"]) - g["indiv"][t]) > ATOL
+        if bad.any():                                        # integers: excuse only a pair sitting on its threshold
+            sz = g["agent_size"]
+            PD = np.sqrt(((g["pos"][t][:, :, None] - g["pos"][t][:, None]) ** 2).sum(-1)) + 10 * np.eye(N)
+            assert np.abs(PD - (sz[:, None] + sz[None, :])).min() < 1e-5, "individual reward mismatch away from a threshold"
+        penalties += int((g["indiv"][t] < -P.penalty + 0.5).sum())
+    assert penalties > 0
+    a, b = build(), build()
+    for e in (a, b):
+        load(e, g["pos0"], g["vel0"], g["lm0"], g["lmvel0"], 0)
+    acts = torch.as_tensor(g["acts"][:8]).cuda().contiguous()
+    o_seq, r_seq, d_seq, i_seq = b.rollout(acts)
+    for t in range(8):
+        o, r, d, i = a.step(acts[t])
+        assert torch.equal(o, o_seq[t]) and torch.equal(r, r_seq[t]) and torch.equal(i["individual_reward"], i_seq["individual_reward"][t])
+
+
 def test_remaining_scenarios_seeded_reset(golden):
     import formation_gym
     for scenario, name in [("formation_hd_partial_env", "partial_n5"), ("formation_hd_partial_range_env", "range_n4"),
@@ -929,8 +982,7 @@ def test_vec_env_device_mt_matches_host_reset_mode():
         v = FormationVecEnv(e, reset_mode=mode)
         v.reset()
         e.world.step_count.copy_(torch.tensor([97, 98, 99, 3, 98, 97], dtype=torch.int32))
-        if mode == "device_mt":
-            v._host_steps = np.array([97, 98, 99, 3, 98, 97], dtype=np.int64)
+        v.ts[:] = [97, 98, 99, 3, 98, 97]                      # the vec env's host mirror of the step counters just overwritten
         envs.append((e, v))
     rs = np.random.RandomState(5)
     for t in range(T):
@@ -957,8 +1009,7 @@ def test_vec_env_device_mt_single_launch_reset_at_other_sizes(N, B, L):
         v.reset()
         e.world.world_length = L
         e.world.step_count.copy_(torch.as_tensor(phase.astype(np.int32)))
-        if mode == "device_mt":
-            v._host_steps = phase.astype(np.int64).copy()
+        v.ts[:] = phase                                       # the vec env's host mirror of the step counters just overwritten
         envs.append((e, v))
     rs = np.random.RandomState(6)
     for t in range(3 * L + 1):
@@ -1261,3 +1312,45 @@ def test_rank_processes_on_the_hip_path_reproduce_the_one_process_batch(tmp_path
         np.testing.assert_array_equal(r["pos_x"], whole.world.pos_x.cpu().numpy())
         np.testing.assert_array_equal(r["shape"], whole.scenario.ideal_shape.cpu().numpy())
     assert done.any()
+
+
+def test_vec_env_surface_matches_the_reference_loop(golden):
+    """The vec-env surface an RL caller of the reference consumes (train/maddpg-v2/utils/env_wrappers.py:68-72, :113-122):
+    stacked NumPy obs / rews / dones, infos per env, `ts`, the RESET observation with the finished step's reward / done -
+    against fixture vec_env_n3, the reference's envs driven by DummyVecEnv.step_wait's loop body across an episode end.
+    'host' reset mode: the reference's own MT19937 streams (seed + 1000 rank), so the reset observation is the reference's."""
+    from formation_gym.vec_env import FormationVecEnv
+    g = golden("vec_env_n3")
+    T, B, N = g["acts"].shape[:3]
+    env = _make(N, B)
+    env.seed(int(g["seed"]))
+    v = FormationVecEnv(env, reset_mode="host", numpy=True, infos="tuple")
+    assert v.agent_types == list(g["agent_types"]) and v.get_spaces() == (env.observation_space, env.action_space)
+    with pytest.raises(AttributeError, match="reset_task"):
+        v.reset_task()
+    obs = v.reset()
+    assert isinstance(obs, np.ndarray) and obs.dtype == np.float64 and obs.shape == g["obs0"].shape
+    np.testing.assert_allclose(obs, g["obs0"], rtol=0, atol=ATOL)
+    W = int(g["world_length"])
+    for t in range(T):
+        obs, rews, dones, infos = v.step(g["acts"][t])           # NumPy in, NumPy out
+        assert obs.dtype == np.float64 and rews.shape == (B, N, 1) and dones.dtype == np.bool_ and dones.shape == (B, N)
+        assert isinstance(infos, tuple) and len(infos) == B and len(infos[0]) == N and sorted(infos[0][0]) == ["individual_reward"]
+        np.testing.assert_array_equal(v.ts, g["ts"][t])
+        np.testing.assert_array_equal(dones, g["dones"][t])
+        # free-running fp32 against the fp64 reference: sparse 3-agent envs stay close; the step after the reset is fresh again
+        tol = ATOL if (t % W) < 12 else 5e-4
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=0, atol=tol)
+        np.testing.assert_allclose(rews, g["rews"][t], rtol=0, atol=10 * tol)
+        np.testing.assert_allclose([[d["individual_reward"] for d in row] for row in infos], g["indiv"][t], rtol=0, atol=10 * tol)
+    assert g["dones"][W - 1].all() and (g["ts"][W - 1] == 0).all()            # the episode end is inside the fixture
+    # default return types: device tensors and one dict; `ts` also follows device-side resets without a read-back
+    e2 = _make(N, B); e2.seed(3)
+    v2 = FormationVecEnv(e2)
+    v2.reset()
+    e2.world.step_count.fill_(W - 2); v2.ts[:] = W - 2
+    for t in range(3):
+        o, r, d, i = v2.step(torch.zeros((B, N, 2), device="cuda"))
+        assert torch.is_tensor(o) and isinstance(i, dict)
+        np.testing.assert_array_equal(v2.ts, e2.world.step_count.cpu().numpy())
+    assert (v2.ts == 1).all()

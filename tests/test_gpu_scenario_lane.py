@@ -119,8 +119,8 @@ def test_lane_kernel_observation_only_and_world_options(shape):
         outs.append(o)
     _same(outs[0], outs[1], "%s observe-only" % kind)
     st, p, sc, D = _setup(*shape, B=B, crowd=0.3, seed=6, accel=3.0, max_speed=0.4, u_noise=0.2, num_walls=2)
-    p.walls[0] = _native.FgWall(vertical=0, axis_pos=0.2, end0=-0.5, end1=0.5, width=0.1, reserved=0)
-    p.walls[1] = _native.FgWall(vertical=1, axis_pos=-0.1, end0=-0.4, end1=0.6, width=0.05, reserved=0)
+    p.walls[0] = _native.FgWall(vertical=0, axis_pos=0.2, end0=-0.5, end1=0.5, width=0.1, soft=0)
+    p.walls[1] = _native.FgWall(vertical=1, axis_pos=-0.1, end0=-0.4, end1=0.6, width=0.05, soft=0)
     gen = torch.Generator(device="cuda"); gen.manual_seed(1)
     acts = (torch.rand((6, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
     s0, o0 = _rollout(st, p, sc, B, N, D, acts, 1, 0)

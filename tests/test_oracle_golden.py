@@ -426,3 +426,54 @@ def test_action_modes_match_reference(golden, name, mode):
         else:
             np.testing.assert_array_equal(g["acts_after"][t], g["acts"][t].astype(np.float64))
     assert int(g["action_space_n"]) == (5 if mode == O.ACT_ONEHOT5 else -1)
+
+
+def test_entity_flags_match_reference(golden):
+    """Entity.movable / collide / ghost (core.py:54-58) and a soft wall: the oracle free-runs on the reference's trajectory."""
+    g = golden("hd_n6_immovable")
+    assert str(g["env_step_raises"]).startswith("AssertionError")          # environment.py:236 for a silent immovable agent
+    P = O.HdParams()
+    pos, vel = g["pos0"][None], g["vel0"][None]
+    for t in range(g["acts"].shape[0]):
+        pos, vel = O.physics_step(pos, vel, g["acts"][t][None].astype(np.float64), P, mass=g["mass"], movable=g["movable"], collide=g["collide"])
+        np.testing.assert_allclose(pos[0], g["pos"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vel[0], g["vel"][t], rtol=0, atol=1e-12)
+        r = O.reward_hd(pos, vel, g["ideal_shape"][None], g["ideal_vel"][None], P, collide=g["collide"])
+        np.testing.assert_allclose(r["indiv"][0], g["indiv"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(O.observation_hd(pos, vel, g["ideal_shape"][None], g["ideal_vel"][None])[0], g["obs"][t], rtol=0, atol=1e-12)
+    g = golden("hd_n9_flags")
+    walls = O.GOLDEN_WALLS + [w + (False,) for w in O.GOLDEN_SOFT_WALLS]
+    T, B = g["acts"].shape[:2]
+    st = dict(pos=g["pos0"], vel=g["vel0"], ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"], step=np.zeros(B, dtype=np.int32))
+    opts = dict(mass=g["agent_mass"], size=g["agent_size"], accel=g["agent_accel"], max_speed=g["agent_max_speed"], walls=walls,
+                collide=g["agent_collide"], ghost=g["agent_ghost"])
+    P = O.HdParams(); P.agent_size = float(g["agent_size"][0])
+    for t in range(T):
+        st, out = O.step_hd(st, g["acts"][t].astype(np.float64), P, **opts)
+        np.testing.assert_allclose(st["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        if (t + 1) in g["obs_steps"]:
+            np.testing.assert_allclose(out["obs"], g["obs_t%d" % (t + 1)], rtol=0, atol=1e-10)
+    # the soft wall and the flags matter in this fixture: an oracle blind to them leaves the reference's trajectory
+    st2 = dict(pos=g["pos0"], vel=g["vel0"], ideal_shape=g["ideal_shape"], ideal_vel=g["ideal_vel"], step=np.zeros(B, dtype=np.int32))
+    blind = dict(opts); blind.pop("collide"); blind.pop("ghost")
+    for t in range(T):
+        st2, _ = O.step_hd(st2, g["acts"][t].astype(np.float64), P, **blind)
+    assert np.abs(st2["pos"] - g["pos"][-1]).max() > 1e-3
+
+
+@pytest.mark.parametrize("kind,name", [("obstacle", "obst_n5_masses"), ("partial", "partial_n6_masses")])
+def test_landmark_scenarios_with_per_agent_tables_match_reference(golden, kind, name):
+    g = golden(name)
+    P = O.ScnParams(kind)
+    T = g["acts"].shape[0]
+    st = _scn_state(g, P)
+    for t in range(T):
+        prev = _scn_state(g, P, t - 1) if t else st
+        new, out = O.step_scn(kind, prev, g["acts"][t].astype(np.float64), P, mass=g["agent_mass"], size=g["agent_size"],
+                              max_speed=g["agent_max_speed"])
+        np.testing.assert_allclose(new["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(new["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+    assert (g["indiv"] < -1.5).any()
