@@ -256,13 +256,14 @@ def config1(dev):
 
 
 def other_scenarios(dev):
-    """The landmark scenarios at 65536 envs: 20-step rollout launches (`fg_rollout_scenario`) with device
-    auto-reset, us per env step and observation bytes written per second (their observations are 70-400 B per agent:
-    these kernels are instruction-bound, profiles/r03_scenario_rollout.md); reported beside the headline, never as `value`."""
+    """The landmark scenarios at the reference's own shapes, 65536 envs: K-step rollout launches
+    (`fg_rollout_scenario`, the one-env-per-lane kernels of csrc/fg_scn_lane_kernel.hpp) with device auto-reset into a PLACED
+    buffer beyond the Infinity Cache (K chosen so that the observations of one launch exceed 1.1 GB): us per env step, the
+    observation bytes written per second and ALL bytes the launch has to move (observations + rewards + done flags written,
+    actions read: with 70-130 floats of observation per env these are 15-24 % on top).  Beside the headline, never `value`."""
     import torch
     import formation_gym
     lines = []
-    K = 20
     for scenario, n, b in (("basic_formation_env", 3, 65536), ("formation_hd_partial_env", 5, 65536),
                            ("formation_hd_partial_range_env", 4, 65536), ("formation_hd_obs_env", 4, 65536)):
         env = formation_gym.make_env(scenario, False, n, num_envs=b, device=dev)
@@ -270,28 +271,36 @@ def other_scenarios(dev):
         env.scenario.reset_device(env.world, rng_offset=999)
         env.auto_reset = True
         d = env._out["obs"].shape[-1]
+        K = 20
+        while K * b * n * d * 4 < 1.1e9:
+            K += 20
         gen = torch.Generator(device=dev); gen.manual_seed(0)
         acts = (torch.rand((K, b, n, 2), generator=gen, device=dev) * 2 - 1).contiguous()
-        f = dict(dtype=torch.float32, device=dev)
-        out = dict(obs=torch.empty((K, b, n, d), **f), reward=torch.empty((K, b, n), **f), indiv=torch.empty((K, b, n), **f),
-                   done=torch.zeros((K, b, n), dtype=torch.uint8, device=dev))
-        for _ in range(10):
+        out = env.alloc_rollout_buffers(K)
+        for _ in range(3):
             env.rollout(acts, out=out)
         torch.cuda.synchronize()
         blocks = []
         for _ in range(5):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(10):
+            for _ in range(3):
                 env.rollout(acts, out=out)
             e1.record()
             torch.cuda.synchronize()
-            blocks.append(e0.elapsed_time(e1) / 10 / K)
+            blocks.append(e0.elapsed_time(e1) / 3 / K)
         blocks.sort()
         ms = blocks[len(blocks) // 2]
+        obs_bytes = b * n * d * 4
+        all_bytes = obs_bytes + b * n * (8 + 4 + 4 + 1)
         lines.append({"workload": "%s, %d agents x %d envs, %d steps per launch, device auto-reset" % (scenario, n, b, K),
+                      "observation_buffer_MB": round(K * obs_bytes / 1e6, 1),
                       "ms_per_step": round(ms, 6), "env_steps_per_s": round(b / (ms * 1e-3), 1),
-                      "observation_GBps": round(b * n * d * 4 / (ms * 1e-3) / 1e9, 1),
+                      "observation_GBps": round(obs_bytes / (ms * 1e-3) / 1e9, 1),
+                      "observation_frac_of_hbm_peak": round(obs_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "all_bytes_GBps": round(all_bytes / (ms * 1e-3) / 1e9, 1),
+                      "frac_hbm": round(all_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                      "placement": {k: (env.placement or {}).get(k) for k in ("arena_GB", "kept", "probe_seconds")},
                       "state_finite": bool(torch.isfinite(env.world.pos_x).all())})
         del env, out, acts
         torch.cuda.empty_cache()
@@ -388,7 +397,8 @@ def main():
     sync_group, red_dev, sync_backend = None, None, "none"
     if world_size > 1:
         import datetime
-        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        # generous: rank 0 times the GLOBAL batches alone while the others wait in a broadcast on this group
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=3600))
         sync_backend = "gloo"
         if a.backend == "nccl" and ndev < world_size:
             # ranks share a GPU (fewer devices than ranks): RCCL cannot form a communicator over duplicate devices and
@@ -469,8 +479,9 @@ def main():
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
         placed = {}
-        if a.placement_candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
-            placed["step"] = env.place_step_buffers(candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
+        candidates = 1 if solo[0] else a.placement_candidates       # the solo leg of rank 0 skips the probe: the others are waiting
+        if candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
+            placed["step"] = env.place_step_buffers(candidates=candidates, mem_fraction=0.5 / gpu_share)
         out = env._out
         act_pool, launchers = None, []
         if not policy:
@@ -569,7 +580,7 @@ def main():
             if a.obs_every == 1:
                 # the observation buffer is PLACED: candidates timed with this env's own launch, the fastest kept
                 seq = env.alloc_rollout_buffers(chunk, obs_env_pitch=0 if pitch == 6 * N * N else pitch, policy=policy,
-                                                candidates=a.placement_candidates, mem_fraction=0.5 / gpu_share)
+                                                candidates=candidates, mem_fraction=0.5 / gpu_share)
                 placed["rollout"] = env.placement
             else:
                 obs_buf = torch.empty((chunk, B, pitch), **f)[:, :, :6 * N * N].view(chunk, B, N, 6 * N)

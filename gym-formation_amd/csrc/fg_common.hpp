@@ -12,13 +12,13 @@
 
 #include "formation_hip.h"
 
-#ifndef FG_PRODUCER_PRIO
-#define FG_PRODUCER_PRIO 2   // s_setprio level of the rollout producer waves: their dependent chain bounds small-N rollouts (9 x 4096: 1.68 -> 1.58 us/step; levels 1-3 alike; store-bound shapes unaffected)
-#endif
 
 namespace fg {
 
 #define FG_DEV __device__ __forceinline__
+// s_setprio level of the rollout producer waves: their dependent chain bounds small-N rollouts (9 x 4096: 1.68 -> 1.58 us/step;
+// levels 1-3 alike; store-bound shapes unaffected)
+constexpr int FG_PRODUCER_PRIO = 2;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -135,15 +135,7 @@ struct Args {
     real* act_out;            // [K][B][N][2] the actions taken
     real coll_scale;          // heterogeneous agents: collision-penalty distance of a pair = coll_scale * (size_a + size_b)
                                // (= collide_thresh / dist_min of the uniform description, divided on the host)
-#ifdef FG_TRACE
-    long long* trace;          // diagnostic build only (profiles/r02_trace.py): 8 realtime stamps (100 MHz) per workgroup
-#endif
 };
-#ifdef FG_TRACE
-#define FG_STAMP(slot) do { if (a.trace && threadIdx.x == 0) a.trace[(size_t)blockIdx.x * 8 + (slot)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FG_STAMP(slot) do { } while (0)
-#endif
 
 // ---------------------------------------------------------------------------
 // reductions over the lanes of one environment

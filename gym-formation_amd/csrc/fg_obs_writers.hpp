@@ -24,9 +24,7 @@ FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
     return make_float2(c ? t.x : 0.0f, c ? t.y : 0.0f);
 }
 
-#ifndef FG_ROWS_MERGED
-#define FG_ROWS_MERGED 1      // N > 64: rows as chunks of 64 consecutive units across the field boundary (below)
-#endif
+constexpr bool FG_ROWS_MERGED = true;      // N > 64: rows as chunks of 64 consecutive units across the field boundary (below)
 template <int NC, int NW, int E, int PACE = 0>
 FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
                            float2* __restrict__ out_env0, size_t env_units, int El, int parts,
@@ -327,11 +325,7 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
             for (unsigned c = 0; c < NFULL; ++c) {
                 const f32x4 v = src4[c * 64 + lane];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef FG_STREAM_NT
-                __builtin_nontemporal_store(v, &dst4[c * 64 + lane]);   // experiment: profiles/r03_wide/ab_27_nt_placed.txt
-#else
-                dst4[c * 64 + lane] = v;
-#endif
+                dst4[c * 64 + lane] = v;                                // (non-temporal stores: no gain, profiles/r03_wide/ab_27_nt_placed.txt)
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_sleep(1);
             }

@@ -8,10 +8,6 @@
 #include "fg_obs_writers.hpp"
 #include "fg_policy_kernels.hpp"
 
-#ifndef FG_WIDE_SPLIT_ROWS
-#define FG_WIDE_SPLIT_ROWS 0
-#endif
-
 namespace fg {
 
 // ---------------------------------------------------------------------------
@@ -187,9 +183,7 @@ void rollout_kernel(const Args a) {
         }
     };
 
-#if FG_PRODUCER_PRIO
     if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
-#endif
     if (producer) produce(0, u_even, u_odd);
     // every prologue load has landed before the loop: inside it the only loads in flight are the
     // action prefetches, and no leftover prologue dependency makes the compiler drain them early
@@ -488,12 +482,6 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 
     const bool per_step = a.K == 1;
     const int total = per_step ? NG : a.K;
-#ifdef FG_WIDE_WRITER_PRIO
-    if (!producer) __builtin_amdgcn_s_setprio(FG_WIDE_WRITER_PRIO);
-#endif
-#ifdef FG_WIDE_PRODUCER_PRIO
-    if (producer) __builtin_amdgcn_s_setprio(FG_WIDE_PRODUCER_PRIO);
-#endif
     if (producer) { load_group(0); produce(0, 0); if (per_step) store_group(); }
     __syncthreads();
     for (int it = 0; it < total; ++it) {
@@ -511,18 +499,9 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
-#if FG_WIDE_SPLIT_ROWS
-                // every env by ALL writer waves (contiguous row ranges), env after env: the waves of a workgroup finish a step
-                // together and write one compact window
-                for (int ee = 0; ee < El; ++ee)
-                    write_obs_rows<NC, NWW, 1>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N + (size_t)ee * (roll_block_floats(N) / 2),
-                                               roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                               reinterpret_cast<float2*>(a.obs) + unit0 + (size_t)ee * (size_t)a.obs_pitch, (size_t)a.obs_pitch, 1, 3);
-#else
                 write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, (tid - TP) >> 6,
                                            reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
-#endif
             }
         }
         __syncthreads();

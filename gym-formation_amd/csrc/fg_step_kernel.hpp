@@ -7,11 +7,10 @@
 #include "fg_pair_loops.hpp"
 #include "fg_obs_writers.hpp"
 
-#ifndef FG_STEP_WIDE_PACE
-#define FG_STEP_WIDE_PACE 1     // s_sleep after every row of the rows writer in single-step launches above 64 agents
-#endif
 
 namespace fg {
+
+constexpr int FG_STEP_WIDE_PACE = 1;     // s_sleep after every row of the rows writer in single-step launches above 64 agents
 
 // ---------------------------------------------------------------------------
 // the fused step / rollout kernel
@@ -85,8 +84,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     const real cutoff2 = cutoff * cutoff;
     const real thr2 = (real)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
     const real invN = NC ? 1.0f / (real)(NC ? NC : 1) : a.inv_n;      // compile-time N: folded to the same correctly rounded value
-
-    FG_STAMP(0);
     // ---- phase 1: state -> registers + LDS --------------------------------
     real2 p = make_real2(0.f, 0.f), v = make_real2(0.f, 0.f), s = make_real2(0.f, 0.f);
     int t_step = 0;
@@ -115,7 +112,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         if (comm && valid) CT[i] = reinterpret_cast<const real2*>(a.p.comm_state)[sidx];
     }
     __syncthreads();
-    FG_STAMP(1);
 
     // KONE: the single-step instantiation (K = 1, obs_every = 1 known at compile time: no step loop, no slot arithmetic)
     const int K = KONE ? 1 : a.K;
@@ -156,7 +152,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             // so the common no-reset step pays no extra barrier later.
             if (a.p.auto_reset && env_ok && i == 0 && t_step >= a.p.world_length) reset_flag[k & 1] = 1;
             __syncthreads();
-            FG_STAMP(2);
             // the other parity slot is re-armed every step (it was last read in step k-1, which the barrier above
             // closed, and is next written in step k+1, after the barrier that ends this step)
             if (tid == 0) reset_flag[(k + 1) & 1] = 0;
@@ -238,8 +233,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 }
                 __syncthreads();
             }
-
-            FG_STAMP(3);
           }
             // ---- phase 5: observations --------------------------------------
             if (want_obs && !FLAT) {
@@ -311,8 +304,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 }
             }
         }
-
-        FG_STAMP(4);
         if (k + 1 < K) {
             __syncthreads();            // obs phase done reading A/V before the next step writes them
             if (valid) { QX[i] = p.x; QY[i] = p.y; }
@@ -325,10 +316,6 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
         a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
     }
     if (a.do_phys && a.step && env_ok && i == 0) a.step[b] = t_step;
-#ifdef FG_TRACE
-    __builtin_amdgcn_s_waitcnt(0);      // every store of this wave has been acknowledged
-    FG_STAMP(5);
-#endif
 }
 
 }  // namespace fg

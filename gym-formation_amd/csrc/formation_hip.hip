@@ -291,14 +291,16 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
 }
 // 9 ... 16 agents: a batch of <= 4096 envs is bound by the producers' dependent chain and wants many small workgroups with
 // the row writer; larger batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
-// (The closed loop at 16 agents has the small geometry only.)
 template <int NC, int PER>
 static int launch_roll_16(const Args& a, hipStream_t st) {
     constexpr int WR = roll_writer(NC);
-    if constexpr (NC == 9 || PER == 0) {
-        if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
-        if (a.B > 4096) return launch_roll_v<NC, 16, 128, 128, 8, WR, PER>(a, st);
-    }
+    // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB): the 16-env workgroups with
+    // the tile writer stream it at 2.37 us/step against 2.58 (profiles/r04_r9_hbm.txt) - about half the HBM rate either way:
+    // a step moves 10 MB in bursts behind a 1.45 us producer chain; the cache-resident 20-step launch runs at that chain
+    if constexpr (NC == 9)
+        if ((double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+    if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+    if (a.B > 4096) return launch_roll_v<NC, 16, 128, 128, 8, WR, PER>(a, st);
     return launch_roll_v<NC, 16, 64, 128, 4, 0, PER>(a, st);
 }
 // 17 ... 32 agents (25, 27, 32).  Defaults from the MI355X sweeps at 27 agents (profiles/README.md): 16 envs per workgroup =
@@ -328,11 +330,11 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
             else return hbm ? launch_roll_v<NC, 32, 256, 512, 8, WR, 0, true>(a, st)
                             : launch_roll_v<NC, 32, 256, 512, 8, WR, 0, false>(a, st);
         }
-        if (POLICY && a.p.obs_placed && hbm)            // closed loop: 8 writer waves with the rows writer (no tiles in LDS):
-            return launch_roll_v<NC, 32, 512, 512, 16, 0, PER, false>(a, st);   // 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
     } else {
         if (a.B <= 1024) return launch_roll_v<NC, 32, 128, 256, 4, WR, PER, false>(a, st);
     }
+    if (POLICY && a.p.obs_placed && hbm)                // closed loop: 8 writer waves with the rows writer (no tiles in LDS):
+        return launch_roll_v<NC, 32, 512, 512, 16, 0, PER, false>(a, st);   // 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
     // ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (the memory system is not the
     // bound then, a workgroup's own store rate is): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072
     // 12.5 -> 10.7 (27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4: profiles/r03_wide/ab_27_mid_batches.txt)
@@ -826,9 +828,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
             return FG_OK;
         }
     }
-#ifndef FG_SCN_T
-#define FG_SCN_T 64           // threads per workgroup of the scenario kernel up to 64 entities per env
-#endif
+    constexpr int FG_SCN_T = 64;      // threads per workgroup of the scenario kernel up to 64 entities per env
     const int G = pow2ceil(N + M) < 4 ? 4 : pow2ceil(N + M);
     const int E = G <= 64 ? FG_SCN_T / G : 1;         // more than 64 entities: one env per workgroup of G threads
     const int grid = (B + E - 1) / E;

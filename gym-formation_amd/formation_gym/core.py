@@ -23,6 +23,21 @@ import torch
 from . import _native
 
 
+# Every attribute write on a World / Entity / Wall bumps this counter: what depends on them (the FgParams a launch is bound
+# with, MultiAgentEnv._bound_step) is re-derived when it has moved instead of being re-hashed on every step (ADVICE r3:
+# params_signature() cost 40-160 us per step at 243-1024 agents, more than a small batch's kernel).
+_version = [0]
+
+
+class _Tracked(object):
+    _UNTRACKED = frozenset()
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        if name not in self._UNTRACKED:
+            _version[0] += 1
+
+
 class EntityState(object):
     """Physical state of one entity across all B envs (core.py:4-9)."""
 
@@ -151,7 +166,7 @@ class Action(object):
         w.action_u[:, self._index] = torch.as_tensor(value, dtype=torch.float32, device=w.device)
 
 
-class Wall(object):
+class Wall(_Tracked):
     """Wall description (core.py:27-41).  No reference scenario creates walls
     (world.walls == []); when present (at most 4) they are simulated in-kernel
     (core.py:325-362); a soft wall (hard=False) lets ghost entities through (:326-327)."""
@@ -165,7 +180,7 @@ class Wall(object):
         self.color = np.array([0.0, 0.0, 0.0])
 
 
-class Entity(object):
+class Entity(_Tracked):
     """Properties of a physical world entity (core.py:45-75); identical for all B envs."""
 
     def __init__(self):
@@ -212,10 +227,11 @@ class Agent(Entity):
         self.goal = None
 
 
-class World(object):
+class World(_Tracked):
     """B independent multi-agent worlds stepped in lock-step on one GPU.
 
     Constants and their reference defaults: core.py:113-139."""
+    _UNTRACKED = frozenset(("world_step", "_props", "_sig_cache", "_silent_cache"))     # written on the hot path / caches
 
     def __init__(self, world_length=50, num_envs=1, device=None):
         self.agents = []
@@ -245,7 +261,9 @@ class World(object):
         self.obstacle_vel = None
         self.comm_c = None                # AgentState.c of all agents [B, N, dim_c]; allocated with the first non-silent agent
         self.action_c = None              # Action.c [B, N, dim_c]
-        self._props = None                # (signature, device table [N, 6]) of heterogeneous agents
+        self._props = None                # (signature, device table [N, 8]) of heterogeneous agents
+        self._sig_cache = None            # (key, params_signature()) - see _version
+        self._silent_cache = None
         self.scenario = None
 
     # ---- reference-compatible views --------------------------------------
@@ -306,7 +324,10 @@ class World(object):
         return self.comm_c, self.action_c
 
     def any_non_silent(self):
-        return any(not a.silent for a in self.agents)
+        key = (_version[0], len(self.agents))
+        if self._silent_cache is None or self._silent_cache[0] != key:
+            self._silent_cache = (key, any(not a.silent for a in self.agents))
+        return self._silent_cache[1]
 
     def agent_props(self):
         """Device table float [N, 8] = (mass, size, accel, max_speed, u_noise, c_noise, flags, 0) per agent for
@@ -382,8 +403,18 @@ class World(object):
         return p
 
     def params_signature(self):
-        """Cheap tuple of everything `native_params` reads from the world and from agent 0:
-        callers that cache an FgParams re-derive it when this changes."""
+        """Tuple of everything `native_params` reads from the world and its agents: callers that cache an FgParams re-derive
+        it when this changes.  Built again only after some attribute of the world, an entity or a wall was written (or the
+        agent / wall lists changed length); the per-step cost is one small key comparison."""
+        key = (_version[0], len(self.agents), len(self.walls), None if self.comm_c is None else self.comm_c.data_ptr(),
+               None if self.rng_counter is None else self.rng_counter.data_ptr())
+        if self._sig_cache is not None and self._sig_cache[0] == key:
+            return self._sig_cache[1]
+        sig = self._params_signature()
+        self._sig_cache = (key, sig)
+        return sig
+
+    def _params_signature(self):
         return (self.dt, self.damping, self.contact_force, self.contact_margin, self.world_length,
                 len(self.agents), tuple((a.size, a.initial_mass, a.accel, a.max_speed, a.u_noise, a.silent, a.c_noise,
                                          a.movable, a.collide, a.ghost, a.action_callback is not None) for a in self.agents),

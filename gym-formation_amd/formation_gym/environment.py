@@ -489,8 +489,8 @@ class MultiAgentEnv(object):
         FgParams struct once (`bind_step`), keyed by everything the binding depends on - action
         buffer, output buffers, stream, auto-reset flag and the world's physics constants - so a
         change of any of them simply binds again.  Scenarios without `bind_step` take the generic
-        path.  Per-agent attributes other than agent 0's are validated when a binding is made
-        (and at every reset), not on every step."""
+        path.  The world's signature covers every agent's attributes; it is cached behind a write counter
+        (core._version), so the per-step key costs a few comparisons whatever the agent count."""
         bind = getattr(self.scenario, "bind_step", None)
         if bind is None:
             return False

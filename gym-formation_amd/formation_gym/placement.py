@@ -194,7 +194,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     Candidates: the arena's first chunks in the order they were created (what a plain allocation gives) and selections of
     chunks SPREAD over the whole arena - one chunk per stratum, strata in shuffled or golden-stride order
     (profiles/r03_place/: the wider a buffer's chunks are spread over the device's memory, the faster the launch;
-    neighbouring memory is the slow case).  At least `trials` selections are timed, up to four times as many when
+    neighbouring memory is the slow case).  At least `trials` selections are timed, up to eight times as many when
     `budget_s` affords them (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
     once more, the winner is mapped for good and every other chunk goes back to the driver."""
@@ -274,7 +274,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         reps_c = int(min(15, max(reps, math.ceil(3.0 / max(ms[0], 1e-3)))))
         # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
         # and its selections differ by 1 %)
-        count = int(max(int(trials), min(4 * int(trials), budget_s / max(1e-6, (reps_c + 1) * ms[0] * 1e-3 + 4e-3))))
+        count = int(max(int(trials), min(8 * int(trials), budget_s / max(1e-6, (reps_c + 1) * ms[0] * 1e-3 + 4e-3))))
         for t in range(count):
             kind, idx = spread_selection(t)
             cands.append((kind, idx))

@@ -7,12 +7,13 @@ TAG="${1:-r01g}"
 R=$PWD
 export TMPDIR=/tmp
 rm -rf "$R/gpurun_out/shapes_${TAG}"
-for cfg in "27 4096 400 40" "9 4096 800 80" "81 2048 200 20" "243 8192 40 8"; do
+# (9 x 4096 moves 10 MB per step: 128 steps per launch make its rollout buffer 1 GB, i.e. an HBM stream; the other shapes 20 / 4)
+for cfg in "27 4096 400 40 20" "9 4096 1024 128 128" "81 2048 200 20 20" "243 8192 40 8 20"; do
   set -- $cfg
   for mode in rollout step; do
     O=$R/gpurun_out/shapes_${TAG}/n$1_$mode
     mkdir -p $O
-    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --agents $1 --envs $2 --steps $3 --warmup $4 --mode $mode --no-cpu-baseline --no-extra > $O/bench.json 2> $O/bench.err)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python3 $R/bench.py --agents $1 --envs $2 --steps $3 --warmup $4 --chunk $5 --mode $mode --no-cpu-baseline --no-extra > $O/bench.json 2> $O/bench.err)
     echo "profiled N=$1 B=$2 $mode"
   done
 done

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""In-kernel timeline of a single-step launch (diagnostic build: FG_EXTRA_FLAGS=-DFG_TRACE bash csrc/build.sh).
+"""HISTORICAL (round 2): the FG_TRACE stamps this script read were removed from the kernels in round 4 (the result is in
+profiles/r02_step/timeline_trace.txt and DESIGN notes); kept for the record, it no longer runs against the current library.
+In-kernel timeline of a single-step launch (diagnostic build: FG_EXTRA_FLAGS=-DFG_TRACE bash csrc/build.sh).
 Every workgroup of fg::step_kernel stamps the 100 MHz realtime counter at: 0 entry, 1 state loaded, 2 physics done,
 3 reward done / observation stream begins, 4 observation stores issued, 5 all stores acknowledged.
     python profiles/r02_trace.py N B        -> percentiles of each stamp relative to the earliest entry, in us"""
