@@ -72,6 +72,73 @@ __host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int
     return (scn_lane_double(kind, n, l, m, nbr) ? 2 : 1) * scn_lane_block_bytes(kind, n, l, m, nbr);
 }
 
+// The WRITER wave of a one-env-per-lane workgroup (the landmark scenarios here, formation_hd_env in fg_hd_lane_kernel.hpp):
+// block ks (published at barrier B) -> global memory, while the producer computes step ks + 1.  A block = the 64 envs'
+// [N][D] observation rows at an odd pitch of U | 1 float2 units, then reward / individual reward / done of the 64 x N agents
+// as three arrays of 64 N dwords; DB = two blocks taking turns (one barrier per step) instead of one (two barriers).
+template <int N, int D, bool DB>
+FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int El, int obs_every,
+                             float* __restrict__ obs, float* __restrict__ rew, float* __restrict__ indiv, uint8_t* __restrict__ done, int lane) {
+    constexpr int U = N * D / 2, SU = scn_lane_pitch(U);
+    constexpr int BLOCK_UNITS = 64 * SU + (3 * 64 * N) / 2;
+    for (int ks = 0; ks < KS; ++ks) {
+        if (!DB) __syncthreads();                   // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
+        __syncthreads();                            // B: the block of step ks is complete
+        const float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
+        const float* const s_rew = reinterpret_cast<const float*>(smem + 64 * SU);
+        const float* const s_ind = s_rew + 64 * N;
+        const uint32_t* const s_done = reinterpret_cast<const uint32_t*>(s_ind + 64 * N);
+        const size_t kb = (size_t)ks * B;
+        const bool want_obs = obs != nullptr && (obs_every <= 1 || (ks + 1) % obs_every == 0);
+        if (want_obs) {
+            // unit q of the wave's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
+            const size_t ob = (size_t)(obs_every > 1 ? ks / obs_every : ks) * B;
+            float2* const out = reinterpret_cast<float2*>(obs + (ob + (size_t)b0) * N * D);
+            constexpr int DR = 64 / U, DC = 64 - DR * U;
+            int row = lane / U, col = lane - row * U;
+            if (El == 64) {                         // a full wave: U instructions, 16 LDS reads in flight at a time
+#pragma unroll
+                for (int c0 = 0; c0 < U; c0 += 16) {
+                    float2 r[16];
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) {
+                        if (c0 + c < U) {
+                            r[c] = smem[row * SU + col];
+                            row += DR; col += DC;
+                            if (col >= U) { col -= U; row += 1; }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 16; ++c)
+                        if (c0 + c < U) out[(c0 + c) * 64 + lane] = r[c];
+                }
+            } else {
+                const int units = El * U;
+                for (int q = lane; q < units; q += 64) {
+                    out[q] = smem[row * SU + col];
+                    row += DR; col += DC;
+                    if (col >= U) { col -= U; row += 1; }
+                }
+            }
+        }
+        // reward, individual reward, done of the 64 x N agents: [K][B][N], the wave's slice is contiguous
+        const int cnt = El * N;
+        const size_t o0 = (kb + b0) * N + lane;
+        if (rew) {                                  // (one uniform branch per array, not per store)
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) rew[o0 + c * 64] = s_rew[c * 64 + lane];
+        }
+        if (indiv) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) indiv[o0 + c * 64] = s_ind[c * 64 + lane];
+        }
+        if (done) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) done[o0 + c * 64] = (uint8_t)s_done[c * 64 + lane];
+        }
+    }
+}
+
 template <int KIND, int N, int L, int M, int NBR>
 __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
     constexpr bool DB = scn_lane_double(KIND, N, L, M, NBR);
@@ -100,60 +167,7 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
     const int KS = a.K > 1 ? a.K : 1;
 
     if (threadIdx.x >= 64) {
-        // ---- WRITER wave: block ks (published at barrier B) -> global memory, while the producer computes step ks + 1 ----
-        for (int ks = 0; ks < KS; ++ks) {
-            if (!DB) __syncthreads();                   // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
-            __syncthreads();                            // B: the block of step ks is complete
-            const float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
-            const float* const s_rew = reinterpret_cast<const float*>(smem + 64 * SU);
-            const float* const s_ind = s_rew + 64 * N;
-            const uint32_t* const s_done = reinterpret_cast<const uint32_t*>(s_ind + 64 * N);
-            const size_t kb = (size_t)ks * a.B;
-            const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;
-            if (want_obs) {
-                // unit q of the wave's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
-                const size_t ob = (size_t)(a.obs_every > 1 ? ks / a.obs_every : ks) * a.B;
-                float2* const out = reinterpret_cast<float2*>(a.obs + (ob + (size_t)b0) * N * D);
-                constexpr int DR = 64 / U, DC = 64 - DR * U;
-                int row = lane / U, col = lane - row * U;
-                if (El == 64) {                         // a full wave: U instructions, 16 LDS reads in flight at a time
-#pragma unroll
-                    for (int c0 = 0; c0 < U; c0 += 16) {
-                        float2 r[16];
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) {
-                            if (c0 + c < U) {
-                                r[c] = smem[row * SU + col];
-                                row += DR; col += DC;
-                                if (col >= U) { col -= U; row += 1; }
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < 16; ++c)
-                            if (c0 + c < U) out[(c0 + c) * 64 + lane] = r[c];
-                    }
-                } else {
-                    const int units = El * U;
-                    for (int q = lane; q < units; q += 64) {
-                        out[q] = smem[row * SU + col];
-                        row += DR; col += DC;
-                        if (col >= U) { col -= U; row += 1; }
-                    }
-                }
-            }
-            // reward, individual reward, done of the 64 x N agents: [K][B][N], the wave's slice is contiguous
-            const int cnt = El * N;
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const int q = c * 64 + lane;
-                if (q < cnt) {
-                    const size_t o = (kb + b0) * N + q;
-                    if (a.rew) a.rew[o] = s_rew[q];
-                    if (a.indiv) a.indiv[o] = s_ind[q];
-                    if (a.done) a.done[o] = (uint8_t)s_done[q];
-                }
-            }
-        }
+        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane);
         return;
     }
 
@@ -222,13 +236,17 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
                 }
             }
 #pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u_now[i], (uint32_t)(b + a.p.env_index_base),
+                                               (uint32_t)i, off);
+                fx[i] += fa.x; fy[i] += fa.y;
+            }
+            if (a.p.num_walls > 0) {                    // (one uniform branch around all entities)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) wall_forces(a.p, p[i], i < N ? half_agent : half_obst, fx[i], fy[i]);
+            }
+#pragma unroll
             for (int i = 0; i < NE; ++i) {
-                if (i < N) {
-                    const float2 fa = action_force(a.p, agent_props_of(a.p, i, false), u_now[i], (uint32_t)(b + a.p.env_index_base),
-                                                   (uint32_t)i, off);
-                    fx[i] += fa.x; fy[i] += fa.y;
-                }
-                if (a.p.num_walls > 0) wall_forces(a.p, p[i], i < N ? half_agent : half_obst, fx[i], fy[i]);
                 v[i].x = v[i].x * (1.0f - a.p.damping) + (fx[i] / a.p.mass) * a.p.dt;
                 v[i].y = v[i].y * (1.0f - a.p.damping) + (fy[i] / a.p.mass) * a.p.dt;
                 if (i < N) v[i] = clamp_speed(a.p.max_speed, v[i]);

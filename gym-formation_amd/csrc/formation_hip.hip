@@ -37,6 +37,7 @@
 #include "fg_rollout_kernels.hpp"
 #include "fg_aux_kernels.hpp"
 #include "fg_scn_lane_kernel.hpp"
+#include "fg_hd_lane_kernel.hpp"
 #include "fg_policy_kernels.hpp"
 
 namespace fg {
@@ -358,8 +359,25 @@ static int launch_roll_64(const Args& a, hipStream_t st) {
 // 3^L (README.md:34-36) and the other `per_layer` values get_action_BFS takes (__init__.py:49-56: 2, 4, 5, 8).  per = 0: open
 // loop (actions from act_seq); else the closed loop of fg_rollout_hd_policy.  Returns false when (N, per) has no instantiation
 // (the caller then runs step_kernel's K-loop / chained launches).
+// 3 and 4 agents, open loop, contiguous observations, a batch that fills the chip: one env per lane (fg_hd_lane_kernel.hpp)
+template <int NC>
+static int launch_hd_lane(const Args& a, hipStream_t st) {
+    const int grid = 8 * (((a.B + 63) / 64 + 7) / 8);
+    hipLaunchKernelGGL((hd_lane_kernel<NC>), dim3(grid), dim3(128), hd_lane_lds_bytes(NC), st, a);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+// from 32768 envs (512 workgroups of 64 envs: two per CU) the one-env-per-lane kernel wins - 3 x 65536 6.3 -> 3.4 us/step, 4 x 65536
+// 9.2 -> 5.0; below, the lane-per-agent kernel spreads a batch over more waves (3 x 16384: 1.62 vs 1.89): profiles/r04_hd_lane_ab.txt
+constexpr int FG_HD_LANE_MIN_B = 32768;
+
 static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
 #define FG_ROLL(FN, NN, PP) if (a.N == NN && per == PP) { *rc = FN<NN, PP>(a, st); return true; }
+    if (per == 0 && a.B >= FG_HD_LANE_MIN_B && a.obs_pitch == 3LL * a.N * a.N) {
+        if (a.N == 3) { *rc = launch_hd_lane<3>(a, st); return true; }
+        if (a.N == 4) { *rc = launch_hd_lane<4>(a, st); return true; }
+    }
     FG_ROLL(launch_roll_8, 3, 0) FG_ROLL(launch_roll_8, 3, 3)
     FG_ROLL(launch_roll_8, 4, 0) FG_ROLL(launch_roll_8, 4, 2) FG_ROLL(launch_roll_8, 4, 4)
     FG_ROLL(launch_roll_8, 8, 0) FG_ROLL(launch_roll_8, 8, 2) FG_ROLL(launch_roll_8, 8, 8)
