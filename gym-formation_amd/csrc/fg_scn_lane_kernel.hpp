@@ -6,7 +6,7 @@
 // runs at 0.3-0.4 of the HBM rate (profiles/r03_scn_pmc.txt).  Here a lane owns a whole environment: agents, obstacles
 // and landmarks live in its registers, every pair loop is unrolled, nothing is reduced across lanes, and the 64
 // environments of a wave form ONE contiguous span of the [B][N][D] observation tensor - composed row by row in LDS
-// (conflict-free: odd row pitch) and streamed out with lane-consecutive 8-byte stores.
+// (conflict-free: odd row pitch) and streamed out with lane-consecutive 16-byte stores.
 // A workgroup is TWO waves sharing 64 environments: the PRODUCER wave (lane = env) runs World.step + reward of step k+1
 // while the WRITER wave streams step k's observations, rewards and done flags from LDS to global memory; two workgroup
 // barriers per step hand the LDS block back and forth.  The split also keeps the two kinds of memory traffic on
@@ -96,21 +96,32 @@ FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int 
             float2* const out = reinterpret_cast<float2*>(obs + (ob + (size_t)b0) * N * D);
             constexpr int DR = 64 / U, DC = 64 - DR * U;
             int row = lane / U, col = lane - row * U;
-            if (El == 64) {                         // a full wave: U instructions, 16 LDS reads in flight at a time
+            if (El == 64) {
+                // a full wave: 32 U pairs of units, one 16-byte store per lane and instruction (1 KiB per wave instruction; the
+                // two units of a pair may sit in different rows of the LDS image.  8-byte stores: basic 3.2-3.45 -> 3.1 us/step,
+                // partial 6.8-7.5 -> 6.5, profiles/r04_lane_x4_ab.txt)
+                constexpr int NP2 = 32 * U, IT = (NP2 + 63) / 64;
+                constexpr int DR2 = 128 / U, DC2 = 128 - DR2 * U;
+                int r0 = (2 * lane) / U, c0_ = 2 * lane - r0 * U;
+                f32x4* const out4 = reinterpret_cast<f32x4*>(out);
 #pragma unroll
-                for (int c0 = 0; c0 < U; c0 += 16) {
-                    float2 r[16];
+                for (int i0 = 0; i0 < IT; i0 += 8) {
+                    f32x4 r[8];
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        if (c0 + c < U) {
-                            r[c] = smem[row * SU + col];
-                            row += DR; col += DC;
-                            if (col >= U) { col -= U; row += 1; }
+                    for (int c = 0; c < 8; ++c) {
+                        if (i0 + c < IT) {
+                            int r1 = r0, c1 = c0_ + 1;
+                            if (c1 == U) { c1 = 0; r1 += 1; }
+                            const bool ok = (i0 + c) * 64 + lane < NP2;
+                            const float2 x0 = smem[ok ? r0 * SU + c0_ : 0], x1 = smem[ok ? r1 * SU + c1 : 0];
+                            r[c] = (f32x4){x0.x, x0.y, x1.x, x1.y};
+                            r0 += DR2; c0_ += DC2;
+                            if (c0_ >= U) { c0_ -= U; r0 += 1; }
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < 16; ++c)
-                        if (c0 + c < U) out[(c0 + c) * 64 + lane] = r[c];
+                    for (int c = 0; c < 8; ++c)
+                        if (i0 + c < IT && (i0 + c) * 64 + lane < NP2) out4[(i0 + c) * 64 + lane] = r[c];
                 }
             } else {
                 const int units = El * U;

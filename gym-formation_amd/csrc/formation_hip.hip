@@ -288,6 +288,11 @@ constexpr int roll_writer(int n) { return (n == 27 || n == 9) ? 10 : n == 25 ? 6
 template <int NC, int PER>
 static int launch_roll_8(const Args& a, hipStream_t st) {
     constexpr int G = NC <= 4 ? 4 : 8;
+    // 8 agents, a batch that fills the chip: the LDS-tile writer (an env's 1536 bytes as one contiguous span of 16-byte stores
+    // instead of rows in 64- / 128-byte pieces): 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; 8 x 1024 is bound by the
+    // producers' chain and keeps the rows writer (1.09 vs 1.48)
+    if constexpr (PER == 0 && NC == 8)
+        if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, 9, PER>(a, st);
     return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
 }
 // 9 ... 16 agents: a batch of <= 4096 envs is bound by the producers' dependent chain and wants many small workgroups with

@@ -39,6 +39,8 @@ class CallbackScenario(BaseScenario):
         self._rng_states = None
         self._cache = None
         self._step_host = None
+        self._uploads = 0                 # bumped by every host -> device copy: with the step counters it stamps a device state
+        self._downloaded = None
 
     # ---- construction -------------------------------------------------------
     def make_world(self, num_agents=3, num_envs=1, device=None, **kwargs):
@@ -100,13 +102,20 @@ class CallbackScenario(BaseScenario):
         world.set_state(pos, vel)
         world.landmark_pos.copy_(torch.as_tensor(lm, dtype=torch.float32))
         self._cache = None
+        self._uploads += 1
 
     def _host_entities(self, hw):
         """The host world's simulated entities in device order: its agents, then its colliding landmarks."""
         return list(hw.agents) + [hw.landmarks[i] for i in self._bodies]
 
     def _download(self, world):
-        """Device state -> the host worlds' entity states (float64 views of the fp32 values)."""
+        """Device state -> the host worlds' entity states (float64 views of the fp32 values).  Once per device state: the
+        per-agent wrappers (observation / reward / benchmark_data for one agent after the other) share the copy (ADVICE r3:
+        each of them used to download the whole state again)."""
+        stamp = (world.world_step, world.state_version, int(self._step_host.sum()) if self._step_host is not None else 0, self._uploads)
+        if self._downloaded == stamp:
+            return
+        self._downloaded = stamp
         pos, vel = world.get_state()
         pos = pos.double().cpu().numpy(); vel = vel.double().cpu().numpy()
         for b, hw in enumerate(self.host_worlds[:world.num_envs]):
@@ -133,6 +142,7 @@ class CallbackScenario(BaseScenario):
         dev = world.device
         world.pos_x[:, n0:] = torch.as_tensor(pos[..., 0]).to(dev); world.pos_y[:, n0:] = torch.as_tensor(pos[..., 1]).to(dev)
         world.vel_x[:, n0:] = torch.as_tensor(vel[..., 0]).to(dev); world.vel_y[:, n0:] = torch.as_tensor(vel[..., 1]).to(dev)
+        self._uploads += 1
 
     # ---- RNG: the reference draws from NumPy's global legacy generator -------
     def seed(self, seed=None):

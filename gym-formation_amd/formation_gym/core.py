@@ -67,6 +67,7 @@ class EntityState(object):
             self._host["p_pos"] = value
             return
         value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+        w.state_version += 1
         if self._kind == "agent":
             w.pos_x[:, i] = value[..., 0]
             w.pos_y[:, i] = value[..., 1]
@@ -93,6 +94,7 @@ class EntityState(object):
             self._host["p_vel"] = value
             return
         value = torch.as_tensor(value, dtype=torch.float32, device=w.device)
+        w.state_version += 1
         if self._kind == "obstacle":
             w.obstacle_vel[:, i] = value
             return
@@ -231,7 +233,7 @@ class World(_Tracked):
     """B independent multi-agent worlds stepped in lock-step on one GPU.
 
     Constants and their reference defaults: core.py:113-139."""
-    _UNTRACKED = frozenset(("world_step", "_props", "_sig_cache", "_silent_cache"))     # written on the hot path / caches
+    _UNTRACKED = frozenset(("world_step", "_props", "_sig_cache", "_silent_cache", "state_version"))   # hot path / caches
 
     def __init__(self, world_length=50, num_envs=1, device=None):
         self.agents = []
@@ -262,6 +264,7 @@ class World(_Tracked):
         self.comm_c = None                # AgentState.c of all agents [B, N, dim_c]; allocated with the first non-silent agent
         self.action_c = None              # Action.c [B, N, dim_c]
         self._props = None                # (signature, device table [N, 8]) of heterogeneous agents
+        self.state_version = 0            # bumped by every host-side write of the device state (set_state, entity.state setters)
         self._sig_cache = None            # (key, params_signature()) - see _version
         self._silent_cache = None
         self.scenario = None
@@ -355,6 +358,7 @@ class World(_Tracked):
             if not torch.is_tensor(x):
                 x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
             return x.to(device=self.device, dtype=torch.float32)
+        self.state_version += 1
         if pos is not None:
             pos = as_dev(pos)
             self.pos_x.copy_(pos[..., 0]); self.pos_y.copy_(pos[..., 1])
