@@ -337,7 +337,7 @@ class MultiAgentEnv(object):
                               max_arena_bytes=None):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
         the bytes - PLACED: when it is larger than the Infinity Cache, candidate buffers are composed of the chunks of a
-        small arena of device memory (6 x the buffer up to 12 GiB, at least 1.5 x the buffer, never more than
+        small arena of device memory (6 x the buffer up to 48 GiB, at least 1.5 x the buffer, never more than
         `mem_fraction` of the free memory; `max_arena_bytes` overrides), this env's own K-step launch is timed on
         `candidates` or more of them and the fastest is kept, every other chunk released (formation_gym/placement.py: the
         rate of a launch depends on which physical memory its buffer is composed of, by 10-20 %; ~0.2 s); where the arena

@@ -158,10 +158,11 @@ class Arena(object):
 
 
 def default_arena_bytes(nbytes):
-    """Arena size the probe takes by default: 6 x the buffer up to 12 GiB, at least 1.5 x the buffer
-    (profiles/r04_place/arena_size.txt: the 1.4 GB headline buffer runs at 11.8-12.1 us/step from an 8.6 GB arena, 11.7-12.0
-    from 206 GB, 12.2-13.0 from 4.3 GB; the 6.4 GB buffer of 81 x 2048 x 20 at 50.3-51.6 from 10 GB and 50.5-50.7 from 206)."""
-    return int(max(1.5 * nbytes, min(6 * nbytes, 12 << 30)))
+    """Arena size the probe starts with: 6 x the buffer up to 48 GiB, at least 1.5 x the buffer
+    (profiles/r04_place/: the 1.4 GB headline buffer runs at 11.8-12.1 us/step from an 8.6 GB arena, 11.7-12.0 from 206 GB,
+    12.2-13.0 from 4.3 GB; the 6.4 GB buffer of 81 x 2048 x 20 at 50.3-52.6 from 10 GB on four boxes and at 62.5 - nothing
+    gained - on a fifth, at 50.5-50.9 from 39, 69 and 206 GB: a multi-GB buffer needs its 6 x as well)."""
+    return int(max(1.5 * nbytes, min(6 * nbytes, 48 << 30)))
 
 
 def arena_geometry(nbytes, free_bytes, mem_fraction=0.5, max_arena_bytes=None):
@@ -197,7 +198,9 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     neighbouring memory is the slow case).  At least `trials` selections are timed, up to eight times as many when
     `budget_s` affords them (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
-    once more, the winner is mapped for good and every other chunk goes back to the driver."""
+    once more, the winner is mapped for good and every other chunk goes back to the driver.  An arena whose winner is not
+    3 % faster than its own first chunks is closed and followed by one four times as large (`next_arena_bytes`, at most
+    two such steps, report["stages"]); a caller that passes `max_arena_bytes` gets exactly that arena."""
     import math
     import random
     import time
@@ -210,6 +213,45 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     geometry = arena_geometry(nbytes, free, mem_fraction, max_arena_bytes)
     if geometry is None:
         return None
+    stages = []
+    while True:
+        placed = _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed + len(stages), budget_s, free, t_start)
+        if placed is None:
+            return None
+        flat, report, arena = placed
+        stages.append({"arena_GB": report["arena_GB"], "kept_ms": report["kept_ms"], "as_created_ms": report["as_created_ms"]})
+        report["stages"] = stages
+        # Some boxes hand out a first ~10 GB in which EVERY composition of a multi-GB buffer runs alike and slow
+        # (profiles/r04_place/README.md: 81 x 2048 x 20 at 62.5 us/step from a 10 GB arena, nothing gained over the plain
+        # allocation, where other boxes reach 50.5): when the arena offered nothing, look at four times as much memory, twice
+        # at most, within `mem_fraction` of what is free.  A caller that names the arena size gets that size.
+        bigger = next_arena_bytes(geometry[0], nbytes, free, mem_fraction)
+        if max_arena_bytes is not None or len(stages) >= 3 or bigger is None or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]:
+            return placed
+        del flat, placed
+        arena.close()
+        geometry = arena_geometry(nbytes, free, mem_fraction, bigger)
+        if geometry is None:                                     # cannot happen (bigger > what worked), but never loop on it
+            return None
+
+
+# a probe whose winner is not at least 3 % faster than the arena's first chunks has learnt nothing from this arena
+ESCALATE_BELOW_GAIN = 0.97
+
+
+def next_arena_bytes(total, nbytes, free_bytes, mem_fraction=0.5):
+    """Size of the next, larger arena to probe for a buffer of `nbytes` after an arena of `total` bytes gained nothing:
+    4 x as large, at most `mem_fraction` of the free memory; None when that is not at least twice what was tried."""
+    bigger = int(min(4 * total, mem_fraction * free_bytes))
+    return bigger if bigger >= 2 * total and bigger >= 2 * nbytes else None
+
+
+def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_s, free, t_start):
+    """One arena of probe_arena: (flat, report, arena) or None."""
+    import math
+    import random
+    import time
+    nbytes = int(nfloats) * 4
     total, chunk = geometry
     try:
         arena = Arena(total, device, chunk)

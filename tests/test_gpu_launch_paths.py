@@ -85,7 +85,7 @@ def test_bench_launches_equal_single_steps_and_oracle(N, B, K):
         # the launch bench.py times: a placed buffer, hence the 8-writer-wave streaming instantiation
         # rollout_kernel<27,32,512,512,16,10,0,true> - compared with the oracle directly below
         from formation_gym import placement
-        assert b.placement["probed"] and b.placement["arena_GB"] <= 13.0
+        assert b.placement["probed"] and b.placement["stages"][0]["arena_GB"] <= 13.0
         if b.placement["kept"] != "as created":
             assert placement.is_placed(obs.data_ptr()) and b.scenario.params(b.world, obs=obs).obs_placed == 1
     sample = torch.as_tensor(rs.choice(B, min(B, 32), replace=False)).cuda()
@@ -844,7 +844,7 @@ def test_default_rollout_places_its_buffer_cheaply_and_gives_the_memory_back():
     obs_b, rew_b, done_b, info_b = b.rollout(acts)                       # places (probe) and launches
     torch.cuda.synchronize()
     rep = b.placement
-    assert rep["probed"] and rep["arena_GB"] * 1e9 <= 6.1 * buffer_bytes and rep["probe_seconds"] < 3.0, rep
+    assert rep["probed"] and rep["stages"][0]["arena_GB"] * 1e9 <= 6.1 * buffer_bytes and rep["probe_seconds"] < 5.0, rep
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 <= 1.25 * buffer_bytes + (256 << 20), "the probe kept more than the buffer: %.2f GB" % ((free0 - free1) / 1e9)
     f = dict(dtype=torch.float32, device="cuda")
@@ -891,3 +891,35 @@ def test_default_rollout_places_its_buffer_cheaply_and_gives_the_memory_back():
     gc.collect(); torch.cuda.empty_cache()
     free2 = torch.cuda.mem_get_info()[0]
     assert free2 >= free0 - (64 << 20), "device memory not returned: %.2f GB missing" % ((free0 - free2) / 1e9)
+
+
+def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypatch):
+    """placement.probe_arena escalates - 4 x the arena, twice at most - when its winner is not 3 % faster than the arena's
+    first chunks (some boxes' first ~10 GB run every composition of a multi-GB buffer alike and slow: profiles/r04_place/).
+    Forced here by asking for an impossible gain: three stages, each arena closed before the next is made, the kept
+    buffer usable, every byte back afterwards."""
+    import gc
+    from formation_gym import placement
+    monkeypatch.setattr(placement, "ESCALATE_BELOW_GAIN", 0.0)
+    torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    n = (768 << 20) // 4
+    src = torch.ones(n, dtype=torch.float32, device="cuda")
+    flat, rep, arena = placement.probe_arena(n, lambda dst: dst.copy_(src), "cuda", trials=4, budget_s=0.1)
+    sizes = [s["arena_GB"] for s in rep["stages"]]
+    assert len(sizes) == 3 and sizes[1] >= 3.9 * sizes[0] and sizes[2] >= 3.9 * sizes[1], rep
+    assert rep["arena_GB"] == sizes[-1]
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 <= 2 * n * 4 + n * 4 // 4 + (256 << 20), "closed stages still hold memory: %.2f GB" % ((free0 - free1) / 1e9)
+    flat.copy_(src); torch.cuda.synchronize()
+    assert float(flat.sum()) == float(n)
+    del flat
+    arena.close()
+    del src
+    gc.collect(); torch.cuda.empty_cache()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    # and a caller that names the arena size gets that size, once
+    flat, rep, arena = placement.probe_arena(n, lambda dst: dst.zero_(), "cuda", trials=4, budget_s=0.1, max_arena_bytes=2 << 30)
+    assert len(rep["stages"]) == 1 and rep["arena_GB"] <= 2.2
+    del flat
+    arena.close()

@@ -59,7 +59,7 @@ def test_reference_style_scenario_files_take_the_callback_adapter():
 
 def test_arena_geometry_for_the_bench_shapes():
     """placement.arena_geometry: 8-16 chunks per buffer (32 MiB - 1 GiB each); the arena is SMALL - 6 x the buffer up to
-    12 GiB, at least 1.5 x the buffer (profiles/r04_place/arena_size.txt) - never more than `mem_fraction` of the free
+    48 GiB, at least 1.5 x the buffer (profiles/r04_place/) - never more than `mem_fraction` of the free
     memory, None when there is nothing to choose from (host arithmetic, no GPU)."""
     from formation_gym import placement
     free = 308 * 10 ** 9
@@ -68,7 +68,7 @@ def test_arena_geometry_for_the_bench_shapes():
         W = -(-nbytes // chunk)
         assert chunk & (chunk - 1) == 0 and (32 << 20) <= chunk <= (1 << 30)
         assert W <= 16 or chunk == (1 << 30)
-        assert 1.5 * nbytes - 1 <= total <= max(1.5 * nbytes, 12 << 30) + 1 and total <= 0.5 * free + 1 and total // chunk <= 2048
+        assert 1.5 * nbytes - 1 <= total <= max(1.5 * nbytes, 48 << 30) + 1 and total <= 0.5 * free + 1 and total // chunk <= 2048
         assert total >= nbytes + 2 * chunk
     assert placement.arena_geometry(1433 * 10 ** 6, free)[0] == 6 * 1433 * 10 ** 6          # the headline buffer: 8.6 GB
     assert placement.arena_geometry(1433 * 10 ** 6, free, max_arena_bytes=192 << 30)[0] == int(0.5 * free)   # the round-3 probe, on request
@@ -78,3 +78,9 @@ def test_arena_geometry_for_the_bench_shapes():
     assert placement.arena_geometry(10 ** 9, 10 ** 9) is None
     # two ranks sharing a device halve the fraction
     assert placement.arena_geometry(1433 * 10 ** 6, 10 ** 10, mem_fraction=0.25)[0] <= 0.25 * 10 ** 10 + 1
+    # an arena that gained nothing is followed by one four times as large, within mem_fraction of the free memory, or none
+    assert placement.next_arena_bytes(10 << 30, 6 << 30, 280 << 30) == 40 << 30
+    assert placement.next_arena_bytes(40 << 30, 6 << 30, 280 << 30) == 140 << 30
+    assert placement.next_arena_bytes(140 << 30, 6 << 30, 280 << 30) is None
+    assert placement.next_arena_bytes(87 << 30, 58 << 30, 280 << 30) is None        # 243 x 8192: already most of what is free
+    assert placement.next_arena_bytes(8 << 30, 1 << 30, 20 << 30) is None
