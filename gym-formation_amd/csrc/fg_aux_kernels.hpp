@@ -296,8 +296,9 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     if (a.do_phys && is_agent) u_next = reinterpret_cast<const float2*>(a.act)[sidx];
     // K steps in one launch (fg_rollout_scenario): the state stays in registers / LDS, every step's reward, done and (every
     // obs_every-th) observation go to their slab - the same arithmetic as K single-step launches, bit for bit
+    const uint64_t rbase = rng_base(a.p);               // read once: no load from the device counter inside the step loop
     for (int ks = 0; ks < KS; ++ks) {
-    const uint64_t off = rng_base(a.p) + (uint64_t)ks;
+    const uint64_t off = rbase + (uint64_t)ks;
     const size_t kb = (size_t)ks * a.B;                 // slab of step ks in the [K][B]... outputs
     const float2 u_now = u_next;
     if (a.do_phys && is_agent && ks + 1 < KS) u_next = reinterpret_cast<const float2*>(a.act)[(kb + a.B) * N + sidx];

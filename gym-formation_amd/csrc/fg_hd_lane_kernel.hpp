@@ -65,6 +65,7 @@ __global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
     const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
     const float invN = 1.0f / (float)N;
     const float kmargin = a.p.contact_margin, inv_k = 1.0f / kmargin, cf = a.p.contact_force, dmin = a.p.dist_min;
+    const uint64_t rbase = rng_base(a.p);               // read once: no load from the device counter inside the step loop
 
     float2 u_next[N];
 #pragma unroll
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
         for (int i = 0; i < N; ++i) indiv[i] = (-H - velterm) - (float)cnt[i];
         const uint32_t done_flag = is_done ? 1u : 0u;
         if (a.p.auto_reset && is_done) {                            // fg_reset_hd's draws (formation_hd_env.py:77-95)
-            const uint64_t off = rng_base(a.p) + (uint64_t)ks;
+            const uint64_t off = rbase + (uint64_t)ks;
             float rxs[G], rys[G], rx[N], ry[N];
 #pragma unroll
             for (int g = 0; g < G; ++g) { rxs[g] = 0.f; rys[g] = 0.f; }

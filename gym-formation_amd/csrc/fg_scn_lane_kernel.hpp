@@ -211,8 +211,9 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
         for (int i = 0; i < N; ++i) u_next[i] = reinterpret_cast<const float2*>(a.act)[(size_t)bl * N + i];
     }
 
+    const uint64_t rbase = rng_base(a.p);               // read once: no load from the device counter inside the step loop
     for (int ks = 0; ks < KS; ++ks) {
-        const uint64_t off = rng_base(a.p) + (uint64_t)ks;
+        const uint64_t off = rbase + (uint64_t)ks;
         const size_t kb = (size_t)ks * a.B;
         float2 u_now[N];
 #pragma unroll

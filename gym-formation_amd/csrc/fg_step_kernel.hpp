@@ -115,6 +115,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
 
     // KONE: the single-step instantiation (K = 1, obs_every = 1 known at compile time: no step loop, no slot arithmetic)
     const int K = KONE ? 1 : a.K;
+    const uint64_t rbase = rng_base(a.p);            // read once: no load from the device counter inside the step loop
     for (int k = 0; k < K; ++k) {
         int slot = k;
         bool want_obs = a.do_post && a.obs != nullptr;
@@ -128,7 +129,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 else f = contact_force_packed<NPS, UNR>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                         a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
-                    const real2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rng_base(a.p) + k);
+                    const real2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rbase + k);
                     f.x += fa.x; f.y += fa.y;
                     if (a.p.num_walls > 0) wall_forces(a.p, p, me.size, f.x, f.y, (me.flags & FG_AGENT_GHOST) != 0);
                 } else {
@@ -207,8 +208,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             if (a.p.auto_reset && reset_flag[k & 1] != 0) {          // workgroup-uniform
                 const bool mine = is_done && env_ok;
                 if (G > 64 ? mine : (__any(mine) != 0)) {
-                    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(rng_base(a.p) + k),
-                                     (uint32_t)((rng_base(a.p) + k) >> 32)};
+                    uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(rbase + k),
+                                     (uint32_t)((rbase + k) >> 32)};
                     philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                     real raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
                     const real rx = raw[0], ry = raw[1];
@@ -221,8 +222,8 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
                         reinterpret_cast<real2*>(a.shape)[sidx] = s;
                         if (i == 0) {
-                            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rng_base(a.p) + k),
-                                              (uint32_t)((rng_base(a.p) + k) >> 32)};
+                            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rbase + k),
+                                              (uint32_t)((rbase + k) >> 32)};
                             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                             const real2 niv = make_real2(u_pm1(c2[0]), u_pm1(c2[1]));
                             A[3 * N - 1] = niv;
