@@ -291,8 +291,13 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
     // 8 agents, a batch that fills the chip: the LDS-tile writer (an env's 1536 bytes as one contiguous span of 16-byte stores
     // instead of rows in 64- / 128-byte pieces): 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; 8 x 1024 is bound by the
     // producers' chain and keeps the rows writer (1.09 vs 1.48)
-    if constexpr (PER == 0 && NC == 8)
+    if constexpr (PER == 0 && NC == 8) {
+        // ... and with one workgroup per CU (4096 envs) into a buffer beyond the Infinity Cache, 16 envs and eight writer
+        // waves per workgroup: 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it: profiles/r04_writers_ab.txt)
+        if (a.B >= 4096 && a.B < 5120 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6)
+            return launch_roll_v<NC, G, 128, 512, 128 / G, 9, PER>(a, st);
         if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, 9, PER>(a, st);
+    }
     return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
 }
 // 9 ... 16 agents: a batch of <= 4096 envs is bound by the producers' dependent chain and wants many small workgroups with
@@ -300,11 +305,19 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
 template <int NC, int PER>
 static int launch_roll_16(const Args& a, hipStream_t st) {
     constexpr int WR = roll_writer(NC);
-    // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB): the 16-env workgroups with
-    // the tile writer stream it at 2.37 us/step against 2.58 (profiles/r04_r9_hbm.txt) - about half the HBM rate either way:
-    // a step moves 10 MB in bursts behind a 1.45 us producer chain; the cache-resident 20-step launch runs at that chain
-    if constexpr (NC == 9)
-        if ((double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+    // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB): 16-env workgroups with the
+    // tile writer (2.37 us/step against 2.58 for 4-env workgroups with the rows writer, profiles/r04_r9_hbm.txt).  Cycle
+    // stamps inside that kernel (profiles/r04_trace_ab.txt) show its four writer waves working 5400-5700 cycles per step
+    // against 2800 for the producers - neither the producers' chain nor the memory bounds it: with one workgroup per CU
+    // (<= 4096 envs) eight writer waves take it to 2.03 from 2.60 (profiles/r04_writers_ab.txt; from 8192 envs two
+    // workgroups share a CU and four waves each are faster)
+    if constexpr (NC == 9) {
+        if (a.B > 2048 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) {
+            if constexpr (PER == 0)
+                if (a.B <= 4096) return launch_roll_v<NC, 16, 256, 512, 16, WR, PER>(a, st);
+            return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+        }
+    }
     if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
     if (a.B > 4096) return launch_roll_v<NC, 16, 128, 128, 8, WR, PER>(a, st);
     return launch_roll_v<NC, 16, 64, 128, 4, 0, PER>(a, st);

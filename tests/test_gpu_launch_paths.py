@@ -67,6 +67,8 @@ def _snapshot(env):
                                     # the rows writer, pipelined rollouts in every batch-size class of launch_roll_* / launch_wide
                                     (4, 5000, 4), (8, 3000, 5), (8, 5000, 4), (16, 8192, 8), (16, 4100, 5), (16, 700, 6), (25, 4096, 20), (25, 600, 5),
                                     (4, 40000, 3), (3, 33000, 5),          # 3 / 4 agents from 32768 envs: one env per lane (fg_hd_lane_kernel.hpp)
+                                    # 9 and 8 agents, one workgroup per CU, rollout buffer beyond the Infinity Cache: eight writer waves
+                                    (9, 4096, 64), (9, 3000, 70), (8, 4096, 70), (8, 4100, 70),
                                     (32, 2048, 20), (32, 16400, 2), (64, 2048, 4), (64, 1000, 3), (125, 600, 3), (125, 40, 3)])
 def test_bench_launches_equal_single_steps_and_oracle(N, B, K):
     # the last seven: the batch-size classes that select other instantiations (3 agents: 32-env workgroups from 65 536 envs;
