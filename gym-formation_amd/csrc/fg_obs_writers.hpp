@@ -344,6 +344,76 @@ FG_DEV void write_obs_tiled(const float2* __restrict__ tables0, int env_stride, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Gather writer for small envs (N <= 9: the whole env is one span of 3 N^2 units): no LDS image.  Every unit of an env's
+// [N][6N] block is ONE subtraction of two entries of the env's tables - p_j - p_i, 0 - (-v_i), or entry - 0 for the static
+// units (the zeros of the table serve as the 0) - so a lane that stores 16 bytes needs four table reads and two packed
+// subtractions.  Which entries, and where the 16 bytes go, depends only on the lane, the pass and the 8-byte phase of the
+// env's first unit: a table of (operand offsets, destination, kind) per [phase][pass][lane], built once per workgroup in
+// LDS, replaces the tile writer's index arithmetic, its exec-mask regions and all but two of its LDS round trips per env
+// (write_obs_tiled at 9 agents: ~240 instructions and 11 dependent LDS waits per env, the bound of the 9-agent rollouts,
+// profiles/r04_trace_ab.txt).  Same subtractions on the same operands as the other writers: bit-identical output.
+// ---------------------------------------------------------------------------
+constexpr int FG_WR_GATHER = 64;                                        // rollout_kernel's WR value for this writer
+template <int NC> constexpr int gather_passes() { return (3 * NC * NC / 2 + 2 + 63) / 64; }
+template <int NC> constexpr int gather_lut_units() { return 2 * gather_passes<NC>() * 64 * 2; }   // float2 units (16 B per entry)
+
+// entry: x = a0 | b0 << 16, y = a1 | b1 << 16 (float2-unit offsets in the env's table buffer: unit = T[a] - T[b]),
+//        z = destination unit inside the env | kind << 16 (2 = two units, 16-byte store; 1 = the first unit only; 0 = idle)
+template <int NC>
+FG_DEV void build_gather_lut(uint4* __restrict__ lut, int t, int nthreads) {
+    constexpr int N = NC, ROWU = 3 * N, TU = ROWU * N, P = gather_passes<NC>() * 64;
+    static_assert(N >= 2 && 5 * N < 65536, "gather writer: table offsets are 16-bit, the table's zeros are the 0 operand");
+    auto operands = [&](int unit, unsigned& a, unsigned& b) {        // unit of the env block = T[a] - T[b]
+        const int r = unit / ROWU, u = unit - r * ROWU;
+        if (u == 0) { a = N; b = 4 * N + r; }                         // 0 - (-v_r): the operation the other writers do
+        else if (u < N) { a = (u - 1 >= r) ? u : u - 1; b = r; }      // p_j - p_r, j != r in order
+        else { a = u; b = N; }                                        // zeros | ideal shape | ideal velocity: entry - 0
+    };
+    for (int e = t; e < 2 * P; e += nthreads) {
+        const int par = e / P, q = e - par * P;
+        const int npair = (TU - par) >> 1;
+        const bool tail = ((TU - par) & 1) != 0;                      // a unit behind the last pair
+        int unit = -1, kind = 0;
+        if (q < npair) { unit = 2 * q + par; kind = 2; }
+        else if (par && q == npair) { unit = 0; kind = 1; }           // the unit in front of the first pair
+        else if (tail && q == npair + par) { unit = TU - 1; kind = 1; }
+        unsigned a0 = N, b0 = N, a1 = N, b1 = N;
+        if (kind >= 1) operands(unit, a0, b0);
+        if (kind == 2) operands(unit + 1, a1, b1);
+        lut[e] = make_uint4(a0 | (b0 << 16), a1 | (b1 << 16), (unsigned)(unit < 0 ? 0 : unit) | ((unsigned)kind << 16), 0u);
+    }
+}
+
+// wave w of NW writes the envs w, w + NW, ... of the workgroup's El envs
+template <int NC, int NW, int E>
+FG_DEV void write_obs_gather(const float2* __restrict__ tables0, int env_stride, int w, const uint4* __restrict__ lut,
+                             float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El) {
+    constexpr int PASSES = gather_passes<NC>(), P = PASSES * 64;
+    const int lane = threadIdx.x & 63;
+    for (int ee = w; ee < El; ee += NW) {
+        const float2* __restrict__ T = tables0 + (size_t)ee * env_stride;
+        const size_t first = unit0 + (size_t)ee * env_units;
+        const uint4* __restrict__ L = lut + (first & 1) * P + lane;
+        float2* __restrict__ out = out_env0 + (size_t)ee * env_units;
+        uint4 ent[PASSES];
+#pragma unroll
+        for (int c = 0; c < PASSES; ++c) ent[c] = L[c * 64];
+        f32x4 val[PASSES];
+#pragma unroll
+        for (int c = 0; c < PASSES; ++c) {
+            const float2 A0 = T[ent[c].x & 0xffffu], B0 = T[ent[c].x >> 16], A1 = T[ent[c].y & 0xffffu], B1 = T[ent[c].y >> 16];
+            val[c] = (f32x4){A0.x - B0.x, A0.y - B0.y, A1.x - B1.x, A1.y - B1.y};
+        }
+#pragma unroll
+        for (int c = 0; c < PASSES; ++c) {
+            const unsigned kind = ent[c].z >> 16, dst = ent[c].z & 0xffffu;
+            if (kind == 2) *reinterpret_cast<f32x4*>(out + dst) = val[c];
+            else if (kind == 1) out[dst] = make_float2(val[c].x, val[c].y);
+        }
+    }
+}
+
 }  // namespace fg
 
 #endif  // FG_OBS_WRITERS_HPP_

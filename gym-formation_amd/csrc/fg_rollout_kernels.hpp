@@ -24,6 +24,13 @@ namespace fg {
 // LDS per env (floats): tables[2][A[3N] | V[N] | NV[N]] (float2), then QX QY PX PY SX SY [NP].
 // ---------------------------------------------------------------------------
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
+// LDS of the writer waves behind the env blocks, in float2 units: two tiles per wave (WR = 1 + rows per tile), the gather
+// writer's table (WR = FG_WR_GATHER), nothing for the rows writer (WR = 0)
+template <int NC, int WR, int NWW> constexpr int roll_writer_units() {
+    if constexpr (WR == 0) return 0;
+    else if constexpr (WR == FG_WR_GATHER) return gather_lut_units<NC>();
+    else return 2 * NWW * tile_units<NC, WR - 1>();
+}
 
 // Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
 // workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.
@@ -92,8 +99,8 @@ void rollout_kernel(const Args a) {
     const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
     const float2* act_next = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0) + (a.K > 1 ? act_stride : 0);
     // closed loop: controller tables of this env behind the env blocks and the writers' tiles
-    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) +
-                            (WR > 0 ? 2 * NWW * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() : 0) + e * policy_block_units(N);
+    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW>() +
+                            e * policy_block_units(N);
 
     // one producer step: World.step + reward of step k into table buffer (k & 1);
     // u_cur = action of step k (loaded during step k-1), u_nxt receives the action of step k+1
@@ -187,6 +194,8 @@ void rollout_kernel(const Args a) {
         }
     };
 
+    if constexpr (WR == FG_WR_GATHER)                     // the writers' table of operands, while the producers run step 0
+        if (!producer) build_gather_lut<NC>(reinterpret_cast<uint4*>(smemf + E * roll_block_floats(N)), tid - TP, TW);
     if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
     if (producer) produce(0, u_even, u_odd);
     // every prologue load has landed before the loop: inside it the only loads in flight are the
@@ -208,6 +217,10 @@ void rollout_kernel(const Args a) {
                 if constexpr (WR == 0)
                     write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                reinterpret_cast<float2*>(a.obs) + unit0, env_units, El, 3);
+                else if constexpr (WR == FG_WR_GATHER)
+                    write_obs_gather<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                                 reinterpret_cast<const uint4*>(smemf + E * roll_block_floats(N)),
+                                                 reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1, STREAM>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                                 reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),

@@ -267,7 +267,7 @@ template <int NC, int G, int TP, int TW, int E, int WR, int PER, bool STREAM = f
 static int launch_roll_v(const Args& a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
-    if (WR > 0) lds += 2 * (TW / 64) * tile_units<NC, (WR > 0 ? WR - 1 : 1)>() * (int)sizeof(float2);
+    lds += roll_writer_units<NC, WR, TW / 64>() * (int)sizeof(float2);
     if (PER > 0) lds += E * policy_block_units(NC) * (int)sizeof(float2);
     static std::atomic<unsigned long long> raised{0};
     hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>, lds, &raised);
@@ -280,7 +280,7 @@ static int launch_roll_v(const Args& a, hipStream_t st) {
 }
 // writer of the pipelined kernels per agent count: 1 + rows per LDS tile (the rows must divide N: 9 of 27 and 9, 5 of 25,
 // 8 of 16 and 32), 0 = register-cached rows (few agents: a tile is too small to pay; 64 agents: a row is a wave)
-constexpr int roll_writer(int n) { return (n == 27 || n == 9) ? 10 : n == 25 ? 6 : (n == 16 || n == 32) ? 9 : 0; }
+constexpr int roll_writer(int n) { return n == 9 ? FG_WR_GATHER : n == 27 ? 10 : n == 25 ? 6 : (n == 16 || n == 32) ? 9 : 0; }
 
 // up to 8 agents (3, 4, 8): one wave of producers, two writer waves with the rows writer (rows of 9 units keep 9 of a wave's
 // 64 lanes busy; one writer wave was the bottleneck: 3 x 1024 x 20 2.28 -> 1.36 us/step, 3 x 16384 2.48 -> 1.63, 3 x 65536
@@ -288,15 +288,15 @@ constexpr int roll_writer(int n) { return (n == 27 || n == 9) ? 10 : n == 25 ? 6
 template <int NC, int PER>
 static int launch_roll_8(const Args& a, hipStream_t st) {
     constexpr int G = NC <= 4 ? 4 : 8;
-    // 8 agents, a batch that fills the chip: the LDS-tile writer (an env's 1536 bytes as one contiguous span of 16-byte stores
-    // instead of rows in 64- / 128-byte pieces): 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; 8 x 1024 is bound by the
-    // producers' chain and keeps the rows writer (1.09 vs 1.48)
+    // 8 agents, a batch that fills the chip: an env's 1536 bytes as one contiguous span of 16-byte stores instead of rows in
+    // 64- / 128-byte pieces (LDS tiles: 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; the gather writer since: 18.9 ->
+    // 18.6, equal at 8192); 8 x 1024 is bound by the producers' chain and keeps the rows writer (1.09 vs 1.48)
     if constexpr (PER == 0 && NC == 8) {
         // ... and with one workgroup per CU (4096 envs) into a buffer beyond the Infinity Cache, 16 envs and eight writer
         // waves per workgroup: 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it: profiles/r04_writers_ab.txt)
         if (a.B >= 4096 && a.B < 5120 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6)
             return launch_roll_v<NC, G, 128, 512, 128 / G, 9, PER>(a, st);
-        if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, 9, PER>(a, st);
+        if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, FG_WR_GATHER, PER>(a, st);
     }
     return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
 }
@@ -305,17 +305,18 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
 template <int NC, int PER>
 static int launch_roll_16(const Args& a, hipStream_t st) {
     constexpr int WR = roll_writer(NC);
-    // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB): 16-env workgroups with the
-    // tile writer (2.37 us/step against 2.58 for 4-env workgroups with the rows writer, profiles/r04_r9_hbm.txt).  Cycle
-    // stamps inside that kernel (profiles/r04_trace_ab.txt) show its four writer waves working 5400-5700 cycles per step
-    // against 2800 for the producers - neither the producers' chain nor the memory bounds it: with one workgroup per CU
-    // (<= 4096 envs) eight writer waves take it to 2.03 from 2.60 (profiles/r04_writers_ab.txt; from 8192 envs two
-    // workgroups share a CU and four waves each are faster)
+    // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB).  Cycle stamps inside the kernel
+    // (profiles/r04_trace_ab.txt) showed the writer waves, not the producers' chain and not the memory, bounding it: 5400-5700
+    // cycles per step for four waves with the tile writer against 2800 for the producers.  Hence the gather writer
+    // (fg_obs_writers.hpp; 9 x 8192 3.40 -> 3.10 us/step, 9 x 16384 6.8 -> 6.3, profiles/r04_gather_ab.txt) and, while a
+    // workgroup has a CU to itself, more writer waves per env (profiles/r04_writers_ab.txt, r04_gather_geom.txt):
+    // 9 x 4096 x 128 2.42 -> 1.83, 9 x 2048 x 250 1.47 -> 1.31
     if constexpr (NC == 9) {
-        if (a.B > 2048 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) {
-            if constexpr (PER == 0)
-                if (a.B <= 4096) return launch_roll_v<NC, 16, 256, 512, 16, WR, PER>(a, st);
-            return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
+        if ((double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) {
+            if constexpr (PER == 0) {
+                if (a.B > 1024 && a.B <= 2048) return launch_roll_v<NC, 16, 128, 256, 8, WR, PER>(a, st);
+                if (a.B > 2048 && a.B <= 4096) return launch_roll_v<NC, 16, 256, 512, 16, WR, PER>(a, st);
+            } else if (a.B > 2048 && a.B <= 4096) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
         }
     }
     if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
