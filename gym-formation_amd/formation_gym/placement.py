@@ -200,7 +200,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
     once more, the winner is mapped for good and every other chunk goes back to the driver.  An arena whose winner is not
     3 % faster than its own first chunks is closed and followed by one four times as large (`next_arena_bytes`, at most
-    two such steps, report["stages"]); a caller that passes `max_arena_bytes` gets exactly that arena."""
+    two such steps, buffers of 2 GiB and more only, report["stages"]); a caller that passes `max_arena_bytes` gets exactly
+    that arena."""
     import math
     import random
     import time
@@ -226,7 +227,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         # allocation, where other boxes reach 50.5): when the arena offered nothing, look at four times as much memory, twice
         # at most, within `mem_fraction` of what is free.  A caller that names the arena size gets that size.
         bigger = next_arena_bytes(geometry[0], nbytes, free, mem_fraction)
-        if max_arena_bytes is not None or len(stages) >= 3 or bigger is None or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]:
+        if (max_arena_bytes is not None or nbytes < ESCALATE_MIN_BYTES or len(stages) >= 3 or bigger is None
+                or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]):
             return placed
         del flat, placed
         arena.close()
@@ -237,6 +239,9 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
 
 # a probe whose winner is not at least 3 % faster than the arena's first chunks has learnt nothing from this arena
 ESCALATE_BELOW_GAIN = 0.97
+# ... and only a multi-GB buffer is worth a second look (a 1 GB buffer whose launch is bound by its dependent chain gains
+# nothing from any arena: 9 x 4096 x 128 went through 6 / 24 / 98 GB for 0.2339 / 0.2317 / 0.2334 ms)
+ESCALATE_MIN_BYTES = 2 << 30
 
 
 def next_arena_bytes(total, nbytes, free_bytes, mem_fraction=0.5):

@@ -907,6 +907,7 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     import gc
     from formation_gym import placement
     monkeypatch.setattr(placement, "ESCALATE_BELOW_GAIN", 0.0)
+    monkeypatch.setattr(placement, "ESCALATE_MIN_BYTES", 0)
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     n = (768 << 20) // 4
