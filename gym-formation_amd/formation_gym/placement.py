@@ -200,8 +200,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
     once more, the winner is mapped for good and every other chunk goes back to the driver.  An arena whose winner is not
     3 % faster than its own first chunks is closed and followed by one four times as large (`next_arena_bytes`, at most
-    two such steps, buffers of 2 GiB and more only, report["stages"]); a caller that passes `max_arena_bytes` gets exactly
-    that arena."""
+    two such steps, report["stages"]); a caller that passes `max_arena_bytes` gets exactly that arena."""
     import math
     import random
     import time
@@ -239,9 +238,11 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
 
 # a probe whose winner is not at least 3 % faster than the arena's first chunks has learnt nothing from this arena
 ESCALATE_BELOW_GAIN = 0.97
-# ... and only a multi-GB buffer is worth a second look (a 1 GB buffer whose launch is bound by its dependent chain gains
-# nothing from any arena: 9 x 4096 x 128 went through 6 / 24 / 98 GB for 0.2339 / 0.2317 / 0.2334 ms)
-ESCALATE_MIN_BYTES = 2 << 30
+# Every probed buffer gets the second look: on one fresh box the first 8.7 GB ran ALL 65 spread compositions of the 1.4 GB
+# headline buffer slower than its first chunks (0.283-0.290 ms against 0.267; a normal arena: 0.236-0.243), 0.73 instead of
+# 0.82 of peak.  The price is paid by launches that placement cannot help: 9 x 4096 x 128, bound by its dependent chain, goes
+# through 6 / 24 / 98 GB for 0.2339 / 0.2317 / 0.2334 ms, ~1.2 s once per buffer shape.
+ESCALATE_MIN_BYTES = 0
 
 
 def next_arena_bytes(total, nbytes, free_bytes, mem_fraction=0.5):
