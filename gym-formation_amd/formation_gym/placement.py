@@ -15,8 +15,10 @@ the host places the buffer:
                       candidate's chunks are kept, all others go back to the driver.  Nothing is wasted afterwards.
                       The arena need not be large (round 4, profiles/r04_place/arena_size.txt): what pays is the TIMED
                       choice among compositions, not the distance - 6 x the buffer (8.6 GB for the 1.4 GB headline
-                      buffer) gives what 206 GB gave, 1.5 x gives it for buffers of several GB; placing chunks by rule
-                      without timing does not work (the driver decides where a chunk lies: spread_rule*.txt).
+                      buffer) gives what 206 GB gave on most boxes; where an arena gains nothing (some boxes' first
+                      10 GB run every composition alike and slow) a second one, four times as large, is probed;
+                      placing chunks by rule without timing does not work (the driver decides where a chunk lies:
+                      spread_rule*.txt).
   `probe_allocation`  the fallback where the arena cannot be made: a few whole allocations held side by side, the
                       fastest kept (coarser: an allocation is one sample of the pattern).
 
