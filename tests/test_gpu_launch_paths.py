@@ -208,13 +208,15 @@ def _strided_obs(shape_prefix, N, pitch, fill):
 
 
 @pytest.mark.parametrize("N,B,K", [(27, 70, 5), (9, 130, 6), (3, 40, 4), (81, 7, 4), (243, 5, 3), (10, 33, 4), (100, 3, 3),
-                                    (27, 4100, 8)])          # the last: large enough for the HBM-streaming tile writer
+                                    (27, 4100, 8),           # large enough for the HBM-streaming tile writer
+                                    (9, 5000, 4), (8, 4100, 4)])   # the gather writer (8 agents: a pitch of an odd number of 8-byte
+                                                                   # units, so that env blocks alternate between the two 16-byte phases)
 def test_padded_observation_env_pitch(N, B, K):
     """FgParams.obs_env_pitch: env blocks on their own 128-byte lines (a strided [B, N, 6N] view).  Every entry point
     that writes observations gives the bits of the contiguous layout, the pad is left alone (rollout launches may
     zero-fill it up to the env's last 128-byte line), and the controller reads the strided rows."""
     from formation_gym.policy_bfs import bfs_actions
-    pitch = -(-6 * N * N // 32) * 32 + (32 if N == 9 else 0)
+    pitch = 6 * N * N + 2 if N == 8 else -(-6 * N * N // 32) * 32 + (32 if N == 9 else 0)
     rs = np.random.RandomState(N)
     step0 = np.where(np.arange(B) % 2 == 0, 100 - 2, 9)
     a, b = _pair(N, B, seed=4, crowd=0.5, step0=step0)
