@@ -1,4 +1,4 @@
-// fg_obs_writers.hpp - Observation writers: register-cached rows and LDS tiles.
+// fg_obs_writers.hpp - Observation writers: register-cached rows, LDS tiles, and the table-driven gather writer (8 / 9 agents).
 // Part of libformation_hip (gfx950); included by formation_hip.hip, one translation unit.
 #ifndef FG_OBS_WRITERS_HPP_
 #define FG_OBS_WRITERS_HPP_
