@@ -216,10 +216,19 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     if geometry is None:
         return None
     stages = []
+    previous = None
     while True:
         placed = _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed + len(stages), budget_s, free, t_start)
         if placed is None:
-            return None
+            if previous is None:
+                return None
+            # the larger arena could not be made or used: the size that worked, once more, and no further stage
+            placed = _probe_stage(previous, nfloats, time_fn, device, trials, reps, seed, budget_s, free, t_start)
+            if placed is None:
+                return None
+            placed[1]["stages"] = stages + [{"arena_GB": placed[1]["arena_GB"], "kept_ms": placed[1]["kept_ms"],
+                                             "as_created_ms": placed[1]["as_created_ms"], "after_failed_stage": True}]
+            return placed
         flat, report, arena = placed
         stages.append({"arena_GB": report["arena_GB"], "kept_ms": report["kept_ms"], "as_created_ms": report["as_created_ms"]})
         report["stages"] = stages
@@ -233,6 +242,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
             return placed
         del flat, placed
         arena.close()
+        previous = geometry
         geometry = arena_geometry(nbytes, free, mem_fraction, bigger)
         if geometry is None:                                     # cannot happen (bigger > what worked), but never loop on it
             return None

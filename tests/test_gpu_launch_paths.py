@@ -927,6 +927,20 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     del src
     gc.collect(); torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
+    # a larger arena that cannot be made: the size that worked is probed once more and kept
+    real_stage, calls = placement._probe_stage, []
+
+    def failing_second(geometry, *args):
+        calls.append(geometry[0])
+        return None if len(calls) == 2 else real_stage(geometry, *args)
+    monkeypatch.setattr(placement, "_probe_stage", failing_second)
+    flat, rep, arena = placement.probe_arena(n, lambda dst: dst.zero_(), "cuda", trials=4, budget_s=0.1)
+    assert len(calls) == 3 and calls[2] == calls[0] and calls[1] > 3.9 * calls[0]
+    assert len(rep["stages"]) == 2 and rep["stages"][1].get("after_failed_stage")
+    flat.fill_(2.0); torch.cuda.synchronize()
+    del flat
+    arena.close()
+    monkeypatch.setattr(placement, "_probe_stage", real_stage)
     # and a caller that names the arena size gets that size, once
     flat, rep, arena = placement.probe_arena(n, lambda dst: dst.zero_(), "cuda", trials=4, budget_s=0.1, max_arena_bytes=2 << 30)
     assert len(rep["stages"]) == 1 and rep["arena_GB"] <= 2.2
