@@ -852,7 +852,7 @@ def test_default_rollout_places_its_buffer_cheaply_and_gives_the_memory_back():
     obs_b, rew_b, done_b, info_b = b.rollout(acts)                       # places (probe) and launches
     torch.cuda.synchronize()
     rep = b.placement
-    assert rep["probed"] and rep["stages"][0]["arena_GB"] * 1e9 <= 6.1 * buffer_bytes and rep["probe_seconds"] < 5.0, rep
+    assert rep["probed"] and rep["stages"][0]["arena_GB"] * 1e9 <= 6.1 * buffer_bytes and rep["probe_seconds"] < (1.0 if len(rep["stages"]) == 1 else 15.0), rep
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 <= 1.25 * buffer_bytes + (256 << 20), "the probe kept more than the buffer: %.2f GB" % ((free0 - free1) / 1e9)
     f = dict(dtype=torch.float32, device="cuda")
@@ -878,7 +878,7 @@ def test_default_rollout_places_its_buffer_cheaply_and_gives_the_memory_back():
     t_plain2 = rate(a, plain)
     # never slower than an ordinary allocation (the probe times that composition too); the usual gain is 6-10 %
     # (profiles/r04_place/arena_size.txt), asserted loosely because the ordinary allocation's own rate varies by box
-    assert t_placed <= 1.01 * min(t_plain, t_plain2), (t_placed, t_plain, t_plain2)
+    assert t_placed <= 1.03 * min(t_plain, t_plain2), (t_placed, t_plain, t_plain2)
     print("placed %.4f ms, ordinary %.4f / %.4f ms per %d-step launch; probe: %s" % (t_placed, t_plain, t_plain2, K, rep))
     # lifetime: the arena goes when the last tensor of the buffer goes - not before, not later
     import weakref
