@@ -516,6 +516,8 @@ def main():
             for t in range(start, start + n):
                 obs = env.step(formation_gym.get_action_BFS(formation_gym.ezpolicy, obs, 3))[0]
 
+        last_group = [1]                                       # blocks per event pair of the latest series
+
         def timed_once(fn, n, w, cursor, prewarm):
             # untimed: bring the GPU to its running clocks first (a short --steps/--warmup pair would otherwise
             # be measured during the DVFS ramp), then the W warm-up steps the caller asked for
@@ -527,6 +529,10 @@ def main():
                     torch.cuda.synchronize()
             fn(w, cursor)
             cursor += w
+            # the cursor only selects the slice of the pre-staged action pool: continue on a launch boundary, so that a
+            # block of `chunk` steps is ONE launch (a --warmup that is no multiple of it left every third block of the
+            # driver's 20-step blocks split into a 15- and a 5-step launch)
+            cursor = -(-cursor // chunk) * chunk
             # calibration (not reported): 4 consecutive blocks, the first one (which starts on an idle GPU) left out
             cal = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
             barrier()
@@ -540,26 +546,33 @@ def main():
             if not solo[0]:
                 t1 = sharding.max_over_ranks(t1, red_dev, sync_group)   # same value on every rank
             R = int(min(4000, max(1, -(-1.25 * a.min_timed_ms // max(t1, 1e-3)))))   # 25 % margin: the calibration blocks run cold-ish
-            # the timed series: R consecutive blocks of exactly n steps, each delimited by HIP events on the launch
-            # stream, the series bracketed by barrier + device synchronize.  The stream never idles between blocks
-            # (the host queues ahead), which is how a rollout loop runs; a block that started on an idle GPU would
-            # add the launch latency of its first kernel to every sample.
-            evs = [torch.cuda.Event(enable_timing=True) for _ in range(R + 1)]
+            # the timed series: R consecutive blocks of exactly n steps delimited by HIP events on the launch stream, the
+            # series bracketed by barrier + device synchronize.  The stream never idles between blocks (the host queues
+            # ahead), which is how a rollout loop runs; a block that started on an idle GPU would add the launch latency
+            # of its first kernel to every sample.  An event between two launches costs the stream ~5 us (the barrier
+            # packet and its signal: 27 x 4096 x 20 measured 2.4 % slower with an event after every 0.24 ms launch than with
+            # one per 50 launches, host wall clock over the series included) - a cost of the measurement, not of the loop -
+            # so blocks shorter than 5 ms share an event pair: G consecutive blocks per pair, each sample = pair / G.
+            G = int(max(1, min(64, 5.0 // max(t1, 1e-3))))
+            last_group[0] = G
+            Rg = -(-R // G)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(Rg + 1)]
             barrier()
             t0 = time.perf_counter()
             evs[0].record()
-            for r_ in range(R):
-                fn(n, cursor)
-                cursor += n
+            for r_ in range(Rg):
+                for _ in range(G):
+                    fn(n, cursor)
+                    cursor += n
                 evs[r_ + 1].record()
-            while not evs[R].query():                          # completion seen by polling the closing event
+            while not evs[Rg].query():                         # completion seen by polling the closing event
                 pass
             wall = time.perf_counter() - t0
             torch.cuda.synchronize()
             barrier()
-            local_blocks = [evs[r_].elapsed_time(evs[r_ + 1]) for r_ in range(R)]
+            local_blocks = [evs[r_].elapsed_time(evs[r_ + 1]) / G for r_ in range(Rg)]
             dev_blocks = max_vec(local_blocks)                 # per block: the slowest rank
-            wall_blocks = [(wall if solo[0] else sharding.max_over_ranks(wall, red_dev, sync_group)) * 1e3 / R] * R
+            wall_blocks = [(wall if solo[0] else sharding.max_over_ranks(wall, red_dev, sync_group)) * 1e3 / (Rg * G)] * Rg
             return dev_blocks, wall_blocks, local_blocks, cursor
 
         def timed(fn, n, w):
@@ -569,7 +582,7 @@ def main():
             start = 0
             for attempt in range(3):
                 dev_blocks, wall_blocks, local_blocks, start = timed_once(fn, n, w if attempt == 0 else 0, start, attempt == 0)
-                if sum(dev_blocks) >= 0.8 * a.min_timed_ms or len(dev_blocks) >= 4000:
+                if sum(dev_blocks) * last_group[0] >= 0.8 * a.min_timed_ms or len(dev_blocks) * last_group[0] >= 4000:
                     break
             return dev_blocks, wall_blocks, local_blocks
 
@@ -595,21 +608,23 @@ def main():
         else:
             fns = {"step": run_steps, "rollout": run_rollout}
         dev_blocks, wall_blocks, local_blocks = timed(fns[mode], steps, warmup)
+        blocks_per_event = last_group[0]
         side = {}
         if mode == "rollout" and not policy and a.obs_every == 1 and placed.get("rollout", {}).get("probed") and chunk <= P:
             # beside the timed series (never `value`): the same launch (a) into an ORDINARY allocation - what the round-3
             # default API gave - and (b) through the documented default API, env.rollout(action_seq) with no buffers passed,
             # which places its own buffer on first use
-            def quick(fn, reps=30):
+            def quick(fn, reps=5, per=8):                             # `per` launches per event pair, as the timed series
                 for _ in range(5):
                     fn()
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
                 ev[0].record()
                 for r_ in range(reps):
-                    fn()
+                    for _ in range(per):
+                        fn()
                     ev[r_ + 1].record()
                 torch.cuda.synchronize()
-                ts = sorted(ev[r_].elapsed_time(ev[r_ + 1]) for r_ in range(reps))
+                ts = sorted(ev[r_].elapsed_time(ev[r_ + 1]) / per for r_ in range(reps))
                 return ts[len(ts) // 2] / chunk
             f = dict(dtype=torch.float32, device=dev)
             plain = dict(obs=torch.empty((chunk, B, N, 6 * N), **f), reward=torch.empty((chunk, B, N), **f),
@@ -624,7 +639,7 @@ def main():
             env.close()
         bytes_per_env_step = _native.step_hd_bytes(N)
         med = median(dev_blocks)                                     # every block is already the MAX over ranks
-        r = {"ms": med, "blocks": dev_blocks, "wall_blocks": wall_blocks, "local_ms": median(local_blocks),
+        r = {"ms": med, "blocks": dev_blocks, "blocks_per_event": blocks_per_event, "wall_blocks": wall_blocks, "local_ms": median(local_blocks),
              "chunk": chunk, "B": B, "placement": placed, "side": side,
              "bytes_per_env_step": bytes_per_env_step, "extra": None,
              "GBps": bytes_per_env_step * B * steps / (med * 1e-3) / 1e9}
@@ -826,9 +841,12 @@ def main():
                        "kernel": ("fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"]))
                        if a.mode == "step" else "fg::rollout_kernel<%d> (producer/writer pipelined)" % N},
             "timing": {"clock": "HIP events on the launch stream delimiting consecutive blocks of --steps steps (the series "
-                                "bracketed by barrier + device synchronize, MAX over ranks per block); value, ms_per_step "
-                                "and roofline.achieved all come from the MEDIAN block",
-                       "blocks": len(blocks), "timed_ms_total": round(sum(blocks), 3),
+                                "bracketed by barrier + device synchronize, MAX over ranks per block); blocks shorter than "
+                                "5 ms share an event pair (blocks_per_event consecutive blocks, sample = pair / that: an event "
+                                "after every launch costs the stream ~5 us); value, ms_per_step and roofline.achieved all "
+                                "come from the MEDIAN sample",
+                       "blocks": len(blocks) * m.get("blocks_per_event", 1), "blocks_per_event": m.get("blocks_per_event", 1),
+                       "timed_ms_total": round(sum(blocks) * m.get("blocks_per_event", 1), 3),
                        "block_ms_median": round(ms_block, 5), "block_ms_min": round(min(blocks), 5),
                        "block_ms_max": round(max(blocks), 5),
                        "wall_block_ms_median": round(median(walls), 5),
