@@ -52,7 +52,7 @@ for item in sys.argv[1:]:
         blocks.append(e0.elapsed_time(e1) / reps / K * 1e3)
     blocks.sort()
     us = blocks[len(blocks) // 2]
-    gbs = (24 * N * N + 53 * N + 16) * B / us / 1e3
+    gbs = (24 * N * N + 53 * N + 16) * B / us / 1e3   # SURVEY formula (charges the state round trip per step: > 100 % possible at 3-4 agents)
     pl = env.placement or {}
     print("%d x %d, %d steps per launch: %.2f us/step (min %.2f max %.2f)  %.0f GB/s  %.1f %%  probe %s%s" % (
         N, B, K, us, blocks[0], blocks[-1], gbs, gbs / 80, [pl.get("arena_GB"), pl.get("kept"), pl.get("probe_seconds")] + pl.get("spread_ms_min_median_max", []), digest), flush=True)

@@ -15,8 +15,10 @@ import formation_gym                                      # noqa: E402
 dev = "cuda:0"
 K = 20
 print("# Rollout launches (%d steps, every observation written, device auto-reset) at agent counts other than 3^L, one MI355X\n" % K)
-print("| agents x envs | obs MB/step | buffer | open loop us/step | of 8 TB/s | closed loop (per_layer) us/step | of 8 TB/s | single-step launches us/step |")
-print("|---|---|---|---|---|---|---|---|")
+print("`of 8 TB/s` = the SURVEY formula (24 N^2 + 53 N + 16 bytes per env-step, which charges the state's round trip to every step: it")
+print("passes 1 at 4 agents); `real` = the bytes a K-step launch moves, (24 N^2 + 17 N) per env-step + the state once.\n")
+print("| agents x envs | obs MB/step | buffer | open loop us/step | of 8 TB/s | real | closed loop (per_layer) us/step | of 8 TB/s | real | single-step launches us/step |")
+print("|---|---|---|---|---|---|---|---|---|---|")
 for N, B, per in ((4, 65536, 2), (8, 65536, 2), (16, 8192, 4), (16, 32768, 2), (25, 4096, 5), (25, 16384, 5), (32, 4096, 2),
                   (64, 2048, 4), (64, 4096, 8), (125, 1024, 5), (125, 4096, 5)):
     env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
@@ -24,6 +26,7 @@ for N, B, per in ((4, 65536, 2), (8, 65536, 2), (16, 8192, 4), (16, 32768, 2), (
     env.auto_reset = True
     acts = (torch.rand((K, B, N, 2), device=dev) * 2 - 1).contiguous()
     byts = (24 * N * N + 53 * N + 16) * B
+    real = ((24 * N * N + 17 * N) + (40 * N + 16) / K) * B
 
     def rate(fn, reps=None):
         t_end = time.perf_counter() + 0.2
@@ -46,7 +49,8 @@ for N, B, per in ((4, 65536, 2), (8, 65536, 2), (16, 8192, 4), (16, 32768, 2), (
     env.close()
     step = lambda: [env.step(acts[k]) for k in range(K)]
     t_step = rate(step, reps=3) / K * 1e3
-    print("| %d x %d | %.1f | %s | %.2f | %.3f | %.2f (%d) | %.3f | %.2f |" % (
-        N, B, byts / 1e6, kept, t_open, byts / t_open / 8e6, t_closed, per, byts / t_closed / 8e6, t_step), flush=True)
+    print("| %d x %d | %.1f | %s | %.2f | %.3f | %.3f | %.2f (%d) | %.3f | %.3f | %.2f |" % (
+        N, B, byts / 1e6, kept, t_open, byts / t_open / 8e6, real / t_open / 8e6, t_closed, per, byts / t_closed / 8e6,
+        real / t_closed / 8e6, t_step), flush=True)
     del env, acts
     torch.cuda.empty_cache()
