@@ -1,0 +1,105 @@
+"""Loose rate gates on the launches whose kernel is chosen by a threshold in `launch_roll_*` / `launch_scenario` /
+`fg_rollout_hd` (csrc/formation_hip.hip): a dispatch that falls to the wrong instantiation is 1.5-2.5 x slower and
+passes every bit-identity test.  Bounds are 1.2-1.4 x what this short in-process measurement gives on a good box (rates
+of the long runs: profiles/r04_all_shapes.md, r04_generic_n.md, r04_scenario_rollout.md, r04_gather_ab.txt), so a pass
+says "no gross regression, the intended class of kernel ran", not "the rate is at its best".  Run with `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _us_per_step(fn, K, reps=6, per=4):
+    import time
+    fn()                                                     # first use: buffers placed
+    t_end = time.perf_counter() + 0.2                        # clocks up
+    while time.perf_counter() < t_end:
+        fn()
+        torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for r in range(reps):
+        for _ in range(per):
+            fn()
+        ev[r + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[r].elapsed_time(ev[r + 1]) / per for r in range(reps))
+    return ts[len(ts) // 2] / K * 1e3
+
+
+# (agents, envs, steps per launch, bound us/step, what the slow alternative measures)
+ROLLOUTS = [
+    (27, 4096, 20, 14.6, "headline: 11.6-12.2 placed (13.2-13.6 un-placed; the 4-writer kernel on a placed buffer 12.9)"),
+    (9, 4096, 20, 1.95, "1.46-1.55 with 4-env workgroups and the rows writer; 16-env workgroups 2.1-3.0"),
+    (9, 8192, 64, 4.0, "3.1 with the gather writer, 16-env workgroups; 8-env 3.4-4.9"),
+    (9, 4096, 128, 2.35, "1.78-1.84 with eight writer waves; four 2.0-2.6"),
+    (16, 8192, 20, 11.0, "8.7; the flat-decode K-loop of round 3 12-13"),
+    (64, 2048, 20, 40.0, "30.6-31.2; K-loop 45"),
+    (81, 2048, 8, 68.0, "50-55; un-placed 55-62"),
+    (3, 65536, 40, 4.4, "3.3 one env per lane; a lane per agent 6.3"),
+    (4, 40000, 40, 5.0, "3.9 one env per lane (a lane per agent: 5.6)"),
+]
+
+
+@pytest.mark.parametrize("N,B,K,bound,note", ROLLOUTS, ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_rollout_launch_rate(N, B, K, bound, note):
+    import formation_gym
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    env.scenario.seed(3)
+    env.scenario.reset_device(env.world, rng_offset=5)
+    env.auto_reset = True
+    acts = (torch.rand((K, B, N, 2), device="cuda") * 2 - 1).contiguous()
+    us = _us_per_step(lambda: env.rollout(acts), K)          # the default API: the env's own (placed) buffers
+    env.close()
+    print("%d x %d x %d: %.2f us/step (gate %.2f)" % (N, B, K, us, bound))
+    assert us <= bound, "%d x %d x %d: %.2f us/step, gate %.2f (%s)" % (N, B, K, us, bound, note)
+
+
+def test_single_step_rate():
+    """One launch per env.step at the headline shape: 15.1-15.3 us (its structural floor)."""
+    import formation_gym
+    N, B = 27, 4096
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    env.scenario.reset_device(env.world, rng_offset=5)
+    env.auto_reset = True
+    acts = (torch.rand((8, B, N, 2), device="cuda") * 2 - 1).contiguous()
+    us = _us_per_step(lambda: [env.step(acts[k]) for k in range(8)], 8)
+    print("27 x 4096 single steps: %.2f us (gate 19.5)" % us)
+    assert us <= 19.5, "27 x 4096 single steps: %.2f us" % us
+
+
+@pytest.mark.parametrize("scenario,N,K,bound", [("basic_formation_env", 3, 40, 4.4), ("formation_hd_partial_env", 5, 20, 8.8),
+                                                ("formation_hd_partial_range_env", 4, 20, 6.2), ("formation_hd_obs_env", 4, 20, 7.6)])
+def test_landmark_scenario_rollout_rate(scenario, N, K, bound):
+    """65536 envs at the reference's shapes take the one-env-per-lane kernels: 3.1-3.4 / 6.5-6.9 / 4.5-4.8 / 5.6-5.8 us/step
+    (the run-time-count kernel: 7.6 / 18 / 9.6 / 15.7)."""
+    import formation_gym
+    B = 65536
+    env = formation_gym.make_env(scenario, False, N, num_envs=B, device="cuda:0")
+    env.seed(1)
+    env.scenario.reset_device(env.world, rng_offset=9)
+    env.auto_reset = True
+    acts = (torch.rand((K, B, N, 2), device="cuda") * 2 - 1).contiguous()
+    us = _us_per_step(lambda: env.rollout(acts), K)
+    env.close()
+    print("%s: %.2f us/step (gate %.2f)" % (scenario, us, bound))
+    assert us <= bound, "%s: %.2f us/step, gate %.2f" % (scenario, us, bound)
+
+
+def test_bench_quick_is_a_gate():
+    """`bench.py --quick --max-ms-per-step X`: the headline only, exit status 3 when slower than X."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--max-ms-per-step", "0.0146"],
+                        capture_output=True, text=True, env=env, timeout=300)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert line["roofline"]["frac"] >= 0.66 and line["roofline"]["frac_hbm"] <= line["roofline"]["frac"]
+    slow = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--quick", "--max-ms-per-step", "0.001"],
+                          capture_output=True, text=True, env=env, timeout=300)
+    assert slow.returncode == 3, (slow.returncode, slow.stderr[-500:])
