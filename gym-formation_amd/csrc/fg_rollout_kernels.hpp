@@ -91,13 +91,32 @@ void rollout_kernel(const Args a) {
     }
     if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
 
-    // Actions are fetched one step ahead (small N leaves too little work between the load and its
-    // use to cover an HBM round trip inside one step).  Two registers alternate roles over a loop
-    // unrolled by two, so that no copy (and with it the load's wait) lands inside the issuing step.
+    // Actions are fetched ahead of their step (small N leaves too little work between the load and its use to cover an HBM
+    // round trip inside one step), in one of two forms:
+    //  ACT4  four steps' actions back to back once per four steps (cur = produce calls 4 m ... 4 m + 3, nxt = the next four):
+    //        fewer, larger read events between the store streams of a launch that streams to HBM - 27 x 4096 x 20 11.76 ->
+    //        11.52 us/step, 9 x 4096 x 128 1.85 -> 1.60, 8 x 8192 2.43 -> 2.33, 32 x 4096 15.9 -> 15.5, 64 x 2048 30.8 -> 30.0
+    //        (profiles/r04_batch4_ab.txt).  Eight more live registers: taken where the workgroup's register budget is 168
+    //        (more than 512 threads) and by the gather-writer instantiations; the small chain-bound workgroups lose with it
+    //        (9 x 4096 x 20 1.51 -> 1.59, 16 x 4096 4.18 -> 4.33) and keep
+    //  else  one step ahead, two registers alternating roles over a loop unrolled by two, so that no copy (and with it the
+    //        load's wait) lands inside the issuing step.
+    constexpr bool ACT4 = !POLICY && ((TP + TW) > 512 || WR == FG_WR_GATHER);
     float2 u_even = make_float2(0.f, 0.f), u_odd = u_even;
-    if (!POLICY && valid) u_even = reinterpret_cast<const float2*>(a.act)[sidx];
     const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
-    const float2* act_next = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0) + (a.K > 1 ? act_stride : 0);
+    const float2* const act0 = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0);
+    const float2* act_next = act0 + (a.K > 1 ? act_stride : 0);
+    float2 cur[4], nxt[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { cur[t] = make_float2(0.f, 0.f); nxt[t] = cur[t]; }
+    auto load_batch = [&](float2 (&dst)[4], int j0) {          // actions of steps j0 ... j0 + 3 (clamped to the last step)
+        if (valid) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dst[t] = act0[(size_t)min(j0 + t, a.K - 1) * act_stride];
+        }
+    };
+    if constexpr (ACT4) load_batch(cur, 0);
+    else if (!POLICY && valid) u_even = *act0;
     // closed loop: controller tables of this env behind the env blocks and the writers' tiles
     float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW>() +
                             e * policy_block_units(N);
@@ -122,7 +141,7 @@ void rollout_kernel(const Args a) {
         if (valid) {
             // always issued (clamped to the last step): with a known number of younger loads the
             // wait for u_cur can leave this prefetch in flight
-            if constexpr (!POLICY) {
+            if constexpr (!POLICY && !ACT4) {
                 u_nxt = *act_next;
                 act_next += (k + 2 < a.K) ? act_stride : 0;
             }
@@ -197,7 +216,7 @@ void rollout_kernel(const Args a) {
     if constexpr (WR == FG_WR_GATHER)                     // the writers' table of operands, while the producers run step 0
         if (!producer) build_gather_lut<NC>(reinterpret_cast<uint4*>(smemf + E * roll_block_floats(N)), tid - TP, TW);
     if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
-    if (producer) produce(0, u_even, u_odd);
+    if (producer) produce(0, ACT4 ? cur[0] : u_even, u_odd);
     // every prologue load has landed before the loop: inside it the only loads in flight are the
     // action prefetches, and no leftover prologue dependency makes the compiler drain them early
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
@@ -229,9 +248,21 @@ void rollout_kernel(const Args a) {
         }
         __syncthreads();
     };
-    for (int k = 0; k < a.K; k += 2) {
-        pipeline_step(k, u_odd, u_even);
-        if (k + 1 < a.K) pipeline_step(k + 1, u_even, u_odd);
+    if constexpr (ACT4) {
+        for (int k = 0; k < a.K; k += 4) {
+            if (producer && k + 4 < a.K) load_batch(nxt, k + 4);   // first needed three steps from now
+            pipeline_step(k, cur[1], u_odd);
+            if (k + 1 < a.K) pipeline_step(k + 1, cur[2], u_odd);
+            if (k + 2 < a.K) pipeline_step(k + 2, cur[3], u_odd);
+            if (k + 3 < a.K) pipeline_step(k + 3, nxt[0], u_odd);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+        }
+    } else {
+        for (int k = 0; k < a.K; k += 2) {
+            pipeline_step(k, u_odd, u_even);
+            if (k + 1 < a.K) pipeline_step(k + 1, u_even, u_odd);
+        }
     }
     if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
     if (a.step && env_ok && i == 0) a.step[b] = t_step;
