@@ -479,7 +479,10 @@ def main():
         P = 3 * chunk if chunk >= 8 else (64 if B * N <= 4096 * 81 else 8)   # pre-staged action pool, cycled
         gen = torch.Generator(device=dev); gen.manual_seed(0 + rank)
         placed = {}
-        candidates = 1 if solo[0] else a.placement_candidates       # the solo leg of rank 0 skips the probe: the others are waiting
+        # the solo leg of rank 0 (the N = 1 denominator of the scaling efficiency) places its buffer exactly as the sharded legs
+        # do - same candidates, same memory fraction: an un-placed denominator against placed shards inflated the efficiency by
+        # the placement gain, 5 % at 81 x 16384 and 10-20 % at 2048 envs per GPU; the probe takes 0.2-1 s
+        candidates = a.placement_candidates
         if candidates > 1 and (mode == "step" or other_steps > 0) and not policy:
             placed["step"] = env.place_step_buffers(candidates=candidates, mem_fraction=0.5 / gpu_share)
         out = env._out
@@ -796,6 +799,11 @@ def main():
                     try:
                         m1 = measure(n2, g2, a.mode, st2, max(2, st2 // 10), a.chunk, 0, global_envs=g2)
                         ref_t[0] = g2 * st2 / (m1["ms"] * 1e-3)
+                        n1_placement = (m1.get("placement") or {}).get("rollout" if a.mode == "rollout" else "step") or {}
+                        line["n1_placement"] = {k: n1_placement.get(k) for k in ("probed", "kept", "arena_GB", "kept_ms", "as_created_ms")}
+                        if n1_placement.get("probed") and n1_placement.get("kept_ms") and n1_placement.get("as_created_ms"):
+                            # what the same N = 1 run would have given on an ordinary allocation (the probe's own two timings)
+                            line["n1_unplaced_over_placed"] = round(n1_placement["as_created_ms"] / n1_placement["kept_ms"], 4)
                     except Exception as exc:          # noqa: BLE001 - e.g. out of memory on a shared GPU: no denominator
                         print("bench: N = 1 run of %d x %d failed: %r" % (n2, g2, exc), file=sys.stderr, flush=True)
                     finally:
@@ -805,6 +813,9 @@ def main():
             line["n1_env_steps_per_s"] = round(ref, 1) if ref else None
             line["n1_same_run"] = True
             line["scaling_efficiency_vs_n1"] = round(line["env_steps_per_s"] / (world_size * ref), 4) if ref else None
+            line["scaling_denominator"] = "the same global batch on ONE GPU in this run, its buffer placed like the shards' (round 4: un-placed)"
+            if ref and line.get("n1_unplaced_over_placed"):
+                line["scaling_efficiency_vs_n1_unplaced"] = round(line["scaling_efficiency_vs_n1"] * line["n1_unplaced_over_placed"], 4)
             line["n1_other_box_r02"] = n1_reference("%dx%d" % (n2, g2))
             global_cfgs.append(line)
         if world_size == 1 and headline:
@@ -836,7 +847,7 @@ def main():
                                           if headline else "custom shape",
                        "agents": N, "envs_per_gpu": B, "global_envs": B * world_size, "mode": a.mode,
                        "parallelism": "env-batch sharded over %d GPU(s), no collective" % world_size,
-                       "timing_barrier": sync_backend,
+                       "timing_barrier": sync_backend, "ranks_per_gpu": gpu_share,
                        "steps_per_launch": spl,
                        "kernel": ("fg::step_kernel<%d> T=%d E=%d" % (N, cfg["threads"], cfg["envs_per_wg"]))
                        if a.mode == "step" else "fg::rollout_kernel<%d> (producer/writer pipelined)" % N},

@@ -236,7 +236,7 @@ FG_DEV float u_pm1(uint32_t x) {           // uniform in [-1, 1)
 // ---------------------------------------------------------------------------
 // core.py:325-362 get_wall_collision_force, summed over the walls; a ghost entity passes through soft walls (:326-327)
 FG_DEV void wall_forces(const KParams& P, real2 p, real size, real& fx, real& fy, bool ghost = false) {
-#pragma unroll
+#pragma unroll 1
     for (int w = 0; w < FG_MAX_WALLS; ++w) {                                   // static indices: no scratch copy
         if (w >= P.num_walls) break;
         const FgWall wl = P.walls[w];

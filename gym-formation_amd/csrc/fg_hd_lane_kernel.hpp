@@ -24,7 +24,7 @@ __host__ __device__ constexpr bool hd_lane_double(int n) { return 2 * hd_lane_bl
 __host__ __device__ constexpr int hd_lane_lds_bytes(int n) { return (hd_lane_double(n) ? 2 : 1) * hd_lane_block_bytes(n); }
 
 template <int N>
-__global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
+__global__ __launch_bounds__(64 + 64 * FG_LANE_NWW) void hd_lane_kernel(const Args a) {
     static_assert(N >= 3 && N <= 4, "one env per lane: the LDS block of 64 envs must leave room for four workgroups per CU");
     constexpr int G = 4;                                // the lane group of step_kernel / rollout_kernel at 3 and 4 agents
     constexpr int D = 6 * N, U = 3 * N * N, SU = scn_lane_pitch(U);
@@ -42,7 +42,8 @@ __global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
     const int El = min(64, a.B - b0);
     const int KS = a.K;
     if (threadIdx.x >= 64) {
-        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane);
+        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane,
+                                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1);
         return;
     }
     // ---- PRODUCER wave: lane = env ----

@@ -155,16 +155,23 @@ FG_DEV void reward_pass_packed(const real* __restrict__ PX, const real* __restri
         }
     };
     if constexpr (NPC > 0 && NPC <= 16) {
-        realx2 qx[NPC / 2], qy[NPC / 2], sx[NPC / 2], sy[NPC / 2];
+        // up to 12 partners per fetch: 16 at once held 64 registers of operands and made every 16-agent rollout kernel spill
+        // (128-VGPR budget); two fetches of 8 cost one more LDS round trip, same order of operations
+        constexpr int CH = NPC <= 12 ? NPC / 2 : NPC / 4;            // realx2 pairs per fetch
+        static_assert(NPC % 4 == 0, "padded partner counts are multiples of 4");
 #pragma unroll
-        for (int h = 0; h < NPC / 2; ++h) {
-            qx[h] = *reinterpret_cast<const realx2*>(PX + 2 * h);
-            qy[h] = *reinterpret_cast<const realx2*>(PY + 2 * h);
-            sx[h] = *reinterpret_cast<const realx2*>(SX + 2 * h);
-            sy[h] = *reinterpret_cast<const realx2*>(SY + 2 * h);
+        for (int h0 = 0; h0 < NPC / 2; h0 += CH) {
+            realx2 qx[CH], qy[CH], sx[CH], sy[CH];
+#pragma unroll
+            for (int h = 0; h < CH; ++h) {
+                qx[h] = *reinterpret_cast<const realx2*>(PX + 2 * (h0 + h));
+                qy[h] = *reinterpret_cast<const realx2*>(PY + 2 * (h0 + h));
+                sx[h] = *reinterpret_cast<const realx2*>(SX + 2 * (h0 + h));
+                sy[h] = *reinterpret_cast<const realx2*>(SY + 2 * (h0 + h));
+            }
+#pragma unroll
+            for (int h = 0; h < CH; ++h) pair(2 * (h0 + h), qx[h], qy[h], sx[h], sy[h]);
         }
-#pragma unroll
-        for (int h = 0; h < NPC / 2; ++h) pair(2 * h, qx[h], qy[h], sx[h], sy[h]);
     } else {
 #pragma unroll UNR
         for (int j = 0; j < NP; j += 2)

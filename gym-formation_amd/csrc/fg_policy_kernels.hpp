@@ -158,7 +158,12 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
         const int sg = p - start, l = lev - 1;
         const int g = sg / PER, i = sg - g * PER;
         float w;
-        BA[p] = ez_policy<PER>(l ? SR + off_l : R, l ? SS + off_l : S, g * PER, i, pl.inv_sub[l], pl.inv_per, w);
+        // pl.inv_sub[l] by value selects: `l` differs between lanes, and a per-lane index into the kernel-argument struct
+        // would make the compiler copy the table into scratch memory (every policy kernel carried a 16-byte private segment)
+        float inv_sub = pl.inv_sub[0];
+#pragma unroll
+        for (int t = 1; t < FG_POLICY_MAX_LEVELS; ++t) inv_sub = (t == l) ? pl.inv_sub[t] : inv_sub;
+        BA[p] = ez_policy<PER>(l ? SR + off_l : R, l ? SS + off_l : S, g * PER, i, inv_sub, pl.inv_per, w);
         BW[p] = w;
     }
     sync();
@@ -167,7 +172,11 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     for (int lev = pl.L; lev >= 1; --lev) {
         const float flev = (float)lev;
         for (int sg = lane; sg < n; sg += lanes) {
-            const float2 tv = (lev == pl.L) ? iv : BA[pstart + sg / PER];
+            // value select, never a pointer select (that puts `iv` into scratch memory); at the top level the entry read is
+            // a valid one of this table whose value is not used
+            const float2 up = BA[pstart + sg / PER];
+            const bool top = lev == pl.L;
+            const float2 tv = make_float2(top ? iv.x : up.x, top ? iv.y : up.y);
             float2 a = BA[start + sg];
             const float w = BW[start + sg];
             a.x += tv.x * w; a.y += tv.y * w;

@@ -33,9 +33,10 @@ template <int NC, int WR, int NWW> constexpr int roll_writer_units() {
 }
 
 // Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
-// workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.
+// workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.  (The 8-ary controller
+// holds three 8-entry float2 tables per lane: its instantiations get the 168-register budget instead of spilling 57.)
 template <int NC, int G, int TP, int TW, int E, int WR, int PER = 0, bool STREAM = false>
-__global__ __launch_bounds__(TP + TW) __attribute__((amdgpu_waves_per_eu((TP + TW) <= 512 ? 4 : 3)))
+__global__ __launch_bounds__(TP + TW) __attribute__((amdgpu_waves_per_eu((TP + TW) <= 512 && PER < 8 ? 4 : 3)))
 void rollout_kernel(const Args a) {
     constexpr bool POLICY = PER > 0;
     // WR: observation writer of the writer waves, 0 = register-cached rows, 1 + RT = LDS tiles of RT rows
@@ -274,19 +275,23 @@ void rollout_kernel(const Args a) {
 // that every reduction stays inside the wave and producers still need no barrier of their own.
 // The partner loops load each partner pair once and update all A agents of the lane.
 // ---------------------------------------------------------------------------
-template <int NC, int A, int E, int TW, int PER = 0>
+// BATCHES: the single-step form (a.K == 1) - the workgroup owns a.groups consecutive batches of E envs and pipelines over the
+// batches instead of over the steps (open loop only).
+template <int NC, int A, int E, int TW, int PER = 0, bool BATCHES = false>
 __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a) {
     constexpr bool POLICY = PER > 0;
+    static_assert(!(BATCHES && POLICY), "the batch-pipelined single step takes its actions from the caller");
     static_assert(A * 64 >= NC && (A - 1) * 64 < NC && TW % 64 == 0, "bad wide rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64, TP = E * 64;
     extern __shared__ __attribute__((aligned(16))) float2 smem[];
     float* const smemf = reinterpret_cast<float*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
-    const bool producer = tid < TP;
-    const int e = producer ? tid >> 6 : 0;
-    // K > 1: the workgroup owns E envs for K steps.  K == 1 (`groups` > 1): it owns `groups`
-    // consecutive batches of E envs and pipelines over the batches instead of over the steps.
-    const int NG = (a.K > 1) ? 1 : max(1, a.groups);
+    // the wave index as a scalar: the env, its validity and every branch on them are wave-uniform (s_cbranch, no exec masks
+    // held in SGPR pairs across the step loop - the kernel sat at the 102-SGPR limit and spilled 20-46 of them)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < E;
+    const int e = producer ? wave : 0;
+    const int NG = BATCHES ? max(1, a.groups) : 1;
     const int wg0 = blockIdx.x * E * NG;
     int b = wg0 + e;
     bool env_ok = producer && (b < a.B);
@@ -303,9 +308,15 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
     const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
     const float invN = 1.0f / (float)N;
     const float inv_k = 1.0f / a.p.contact_margin;
+    const uint64_t rbase = rng_base(a.p);               // read once, not inside the step loop (see rollout_kernel)
 
     float2 p[A], v[A], s[A];
-    bool valid[A];
+    // The action of the NEXT produce call, loaded one call ahead and in front of the current call's reward stores: a load at
+    // the point of use queues up behind the workgroup's observation stream (round 4: open loop slower than closed loop,
+    // 125 x 4096 260.7 vs 231.9 us/step), and its wait must not include stores issued after it (one counter on gfx9).
+    float2 u_pre[A];
+    // agent lane + 64 q of the wave's env exists: slices below the last one are full, so their test is the scalar env_ok
+    auto valid = [&](int q) { return env_ok && (q < A - 1 || lane < N - 64 * (A - 1)); };
     float2 iv = make_float2(0.f, 0.f);
     int t_step = 0;
     if (producer) {                                     // row-independent table entries and loop sentinels: once
@@ -324,9 +335,8 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             const int i = lane + 64 * q;
-            valid[q] = env_ok && i < N;
             p[q] = v[q] = s[q] = make_float2(0.f, 0.f);
-            if (valid[q]) {
+            if (valid(q)) {
                 const size_t o = (size_t)b * N + i;
                 p[q] = make_float2(a.px[o], a.py[o]);
                 v[q] = make_float2(a.vx[o], a.vy[o]);
@@ -337,10 +347,17 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         iv = make_float2(0.f, 0.f); t_step = 0;
         if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
     };
+    auto load_actions = [&](int k) {                    // of step k -> u_pre
+#pragma unroll
+        for (int q = 0; q < A; ++q) {
+            u_pre[q] = make_float2(0.f, 0.f);
+            if (valid(q)) u_pre[q] = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + lane + 64 * q];
+        }
+    };
     auto store_group = [&]() {
 #pragma unroll
         for (int q = 0; q < A; ++q) {
-            if (valid[q]) {
+            if (valid(q)) {
                 const size_t o = (size_t)b * N + lane + 64 * q;
                 a.px[o] = p[q].x; a.py[o] = p[q].y; a.vx[o] = v[q].x; a.vy[o] = v[q].y;
             }
@@ -357,10 +374,16 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 #pragma unroll
             for (int q = 0; q < A; ++q) {
                 const int i = lane + 64 * q;
-                if (valid[q]) { pol_tab[i] = make_float2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
+                if (valid(q)) { pol_tab[i] = make_float2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
             }
             WaveSync()();
             pol_res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
+        }
+        float2 u_cur[A];
+        if constexpr (!POLICY) {
+#pragma unroll
+            for (int q = 0; q < A; ++q) u_cur[q] = u_pre[q];
+            if constexpr (!BATCHES) load_actions(min(k + 1, a.K - 1));   // always issued (clamped): a known number of younger loads
         }
         // ---- World.step: all A agents of the lane against each partner pair ----
         float fx[A], fy[A];
@@ -375,8 +398,8 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                     const int i = lane + 64 * q;
                     const f32x2 dx = (f32x2){p[q].x, p[q].x} - qx, dy = (f32x2){p[q].y, p[q].y} - qy;
                     const f32x2 d2 = dx * dx + dy * dy;
-                    const bool n0 = (d2.x < cutoff2) && (j != i) && valid[q];
-                    const bool n1 = (d2.y < cutoff2) && (j + 1 != i) && valid[q];
+                    const bool n0 = (d2.x < cutoff2) && (j != i) && valid(q);
+                    const bool n1 = (d2.y < cutoff2) && (j + 1 != i) && valid(q);
                     if (n0 || n1) {
                         auto add = [&](float ddx, float ddy, float dd2) {
                             const float d = __builtin_amdgcn_sqrtf(dd2);
@@ -398,14 +421,14 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             part[q][0] = part[q][1] = part[q][2] = part[q][3] = 0.f;
-            if (valid[q]) {
+            if (valid(q)) {
                 const int i = lane + 64 * q;
                 float2 u;
                 if constexpr (POLICY) {
                     u = pol_res[i];
                     if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u;
                 } else {
-                    u = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + i];
+                    u = u_cur[q];
                 }
                 const float ffx = fx[q] + a.p.mass * (a.p.sensitivity * u.x);
                 const float ffy = fy[q] + a.p.mass * (a.p.sensitivity * u.y);
@@ -458,7 +481,7 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         float red[3] = {-INFINITY, -INFINITY, 0.f};
 #pragma unroll
         for (int q = 0; q < A; ++q) {
-            if (valid[q]) {
+            if (valid(q)) {
                 cnt[q] += (thr2 > 0.0f ? 0 : 1);
                 red[0] = fmaxf(red[0], rowmin[q]); red[1] = fmaxf(red[1], colmin[q]); red[2] += (float)cnt[q];
             }
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
 #pragma unroll
         for (int q = 0; q < A; ++q) {
-            if (valid[q]) {
+            if (valid(q)) {
                 const size_t o = ((size_t)k * a.B + b) * N + lane + 64 * q;
                 if (a.rew) a.rew[o] = shared;
                 if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt[q];
@@ -485,11 +508,11 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             uint32_t c0[A], c1[A];
 #pragma unroll
             for (int q = 0; q < A; ++q) {
-                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)(lane + 64 * q), (uint32_t)(rng_base(a.p) + k),
-                                 (uint32_t)((rng_base(a.p) + k) >> 32)};
+                uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)(lane + 64 * q), (uint32_t)(rbase + k),
+                                 (uint32_t)((rbase + k) >> 32)};
                 philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                 c0[q] = c[0]; c1[q] = c[1];
-                rx[q] = valid[q] ? u_pm1(c[2]) : 0.f; ry[q] = valid[q] ? u_pm1(c[3]) : 0.f;
+                rx[q] = valid(q) ? u_pm1(c[2]) : 0.f; ry[q] = valid(q) ? u_pm1(c[3]) : 0.f;
                 rawp[q][0] = rx[q]; rawp[q][1] = ry[q];
             }
 #pragma unroll
@@ -497,14 +520,14 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 env_reduce<64, 64, 2, R_SUM, R_SUM, R_SUM, R_SUM>(rawp[q], nullptr);
                 if (q == 0) { raw[0] = rawp[0][0]; raw[1] = rawp[0][1]; } else { raw[0] += rawp[q][0]; raw[1] += rawp[q][1]; }
             }
-            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rng_base(a.p) + k),
-                              (uint32_t)((rng_base(a.p) + k) >> 32)};
+            uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rbase + k),
+                              (uint32_t)((rbase + k) >> 32)};
             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
             iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
             t_step = 0;
 #pragma unroll
             for (int q = 0; q < A; ++q) {
-                if (valid[q]) {
+                if (valid(q)) {
                     const int i = lane + 64 * q;
                     const size_t o = (size_t)b * N + i;
                     p[q] = make_float2(u_pm1(c0[q]), u_pm1(c1[q]));
@@ -518,7 +541,7 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         }
 #pragma unroll
         for (int q = 0; q < A; ++q) {
-            if (valid[q]) {
+            if (valid(q)) {
                 const int i = lane + 64 * q;
                 T[i] = p[q]; T[3 * N + i] = v[q]; T[4 * N + i] = make_float2(-v[q].x, -v[q].y);
                 T[2 * N - 1 + i] = s[q];
@@ -528,17 +551,27 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         if (env_ok && lane == 0) T[3 * N - 1] = iv;
     };
 
-    const bool per_step = a.K == 1;
+    constexpr bool per_step = BATCHES;
     const int total = per_step ? NG : a.K;
-    if (producer) { load_group(0); produce(0, 0); if (per_step) store_group(); }
-    __syncthreads();
-    for (int it = 0; it < total; ++it) {
-        if (producer) {
+    // Two loops, one per role, meeting at the same 1 + total workgroup barriers: the branch is wave-uniform (scalar), and
+    // each loop keeps only its own role's pointers and constants in SGPRs (one common loop held both sets live and spilled).
+    if (producer) {
+        load_group(0);
+        if constexpr (!POLICY) load_actions(0);
+        produce(0, 0); if (per_step) store_group();
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
             if (it + 1 < total) {
-                if (per_step) { load_group(it + 1); produce(0, (it + 1) & 1); store_group(); }
+                if (per_step) { load_group(it + 1); load_actions(0); produce(0, (it + 1) & 1); store_group(); }
                 else produce(it + 1, (it + 1) & 1);
             }
-        } else {
+            __syncthreads();
+        }
+        if (!per_step) store_group();
+    } else {
+        const int w = wave - E;
+        __syncthreads();
+        for (int it = 0; it < total; ++it) {
             const int k = per_step ? 0 : it;
             const int b0 = wg0 + (per_step ? it * E : 0);
             const int El = min(E, a.B - b0);
@@ -548,13 +581,12 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
                 write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
-                                           roll_block_floats(N) / 2, (tid - TP) >> 6,
+                                           roll_block_floats(N) / 2, w,
                                            reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (!per_step && producer) store_group();
 }
 
 }  // namespace fg

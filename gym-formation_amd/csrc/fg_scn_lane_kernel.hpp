@@ -76,9 +76,17 @@ __host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int
 // block ks (published at barrier B) -> global memory, while the producer computes step ks + 1.  A block = the 64 envs'
 // [N][D] observation rows at an odd pitch of U | 1 float2 units, then reward / individual reward / done of the 64 x N agents
 // as three arrays of 64 N dwords; DB = two blocks taking turns (one barrier per step) instead of one (two barriers).
-template <int N, int D, bool DB>
+// NWW writer waves share the block: wave w takes the store instructions w, w + NWW, ... of the span (and of the reward /
+// done arrays), so that NWW times as many stores of a workgroup are in flight (one writer wave per 64 envs at 2 waves per SIMD
+// could not cover the 325-475 cycles of write latency: profiles/r04_scn_pmc.txt, r04_store_path_pmc.txt).
+#ifndef FG_LANE_WRITERS
+#define FG_LANE_WRITERS 2
+#endif
+constexpr int FG_LANE_NWW = FG_LANE_WRITERS;
+template <int N, int D, bool DB, int NWW = FG_LANE_NWW>
 FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int El, int obs_every,
-                             float* __restrict__ obs, float* __restrict__ rew, float* __restrict__ indiv, uint8_t* __restrict__ done, int lane) {
+                             float* __restrict__ obs, float* __restrict__ rew, float* __restrict__ indiv, uint8_t* __restrict__ done, int lane,
+                             int w = 0) {
     constexpr int U = N * D / 2, SU = scn_lane_pitch(U);
     constexpr int BLOCK_UNITS = 64 * SU + (3 * 64 * N) / 2;
     for (int ks = 0; ks < KS; ++ks) {
@@ -91,67 +99,74 @@ FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int 
         const size_t kb = (size_t)ks * B;
         const bool want_obs = obs != nullptr && (obs_every <= 1 || (ks + 1) % obs_every == 0);
         if (want_obs) {
-            // unit q of the wave's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
+            // unit q of the workgroup's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
             const size_t ob = (size_t)(obs_every > 1 ? ks / obs_every : ks) * B;
             float2* const out = reinterpret_cast<float2*>(obs + (ob + (size_t)b0) * N * D);
-            constexpr int DR = 64 / U, DC = 64 - DR * U;
-            int row = lane / U, col = lane - row * U;
             if (El == 64) {
-                // a full wave: 32 U pairs of units, one 16-byte store per lane and instruction (1 KiB per wave instruction; the
+                // a full block: 32 U pairs of units, one 16-byte store per lane and instruction (1 KiB per wave instruction; the
                 // two units of a pair may sit in different rows of the LDS image.  8-byte stores: basic 3.2-3.45 -> 3.1 us/step,
-                // partial 6.8-7.5 -> 6.5, profiles/r04_lane_x4_ab.txt)
+                // partial 6.8-7.5 -> 6.5, profiles/r04_lane_x4_ab.txt).  An odd U makes the image contiguous (pitch U | 1 = U):
+                // the pair is ONE 16-byte LDS read, lanes consecutive, no bank conflicts (the two 8-byte reads at a 16-byte lane
+                // stride met two-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21 in profiles/r04_scn_pmc.txt).
                 constexpr int NP2 = 32 * U, IT = (NP2 + 63) / 64;
-                constexpr int DR2 = 128 / U, DC2 = 128 - DR2 * U;
-                int r0 = (2 * lane) / U, c0_ = 2 * lane - r0 * U;
+                constexpr int MINE = (IT + NWW - 1) / NWW;          // store instructions of one writer wave
                 f32x4* const out4 = reinterpret_cast<f32x4*>(out);
+                const f32x4* const img4 = reinterpret_cast<const f32x4*>(smem);
 #pragma unroll
-                for (int i0 = 0; i0 < IT; i0 += 8) {
+                for (int t0 = 0; t0 < MINE; t0 += 8) {
                     f32x4 r[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        if (i0 + c < IT) {
-                            int r1 = r0, c1 = c0_ + 1;
-                            if (c1 == U) { c1 = 0; r1 += 1; }
-                            const bool ok = (i0 + c) * 64 + lane < NP2;
-                            const float2 x0 = smem[ok ? r0 * SU + c0_ : 0], x1 = smem[ok ? r1 * SU + c1 : 0];
-                            r[c] = (f32x4){x0.x, x0.y, x1.x, x1.y};
-                            r0 += DR2; c0_ += DC2;
-                            if (c0_ >= U) { c0_ -= U; r0 += 1; }
+                        if (t0 + c < MINE) {
+                            const int pair = (w + NWW * (t0 + c)) * 64 + lane;
+                            const bool ok = pair < NP2;
+                            if constexpr (SU == U) {
+                                r[c] = img4[ok ? pair : 0];
+                            } else {
+                                const int q = 2 * pair;
+                                const int r0 = q / U, c0 = q - r0 * U;
+                                int r1 = r0, c1 = c0 + 1;
+                                if (c1 == U) { c1 = 0; r1 += 1; }
+                                const float2 x0 = smem[ok ? r0 * SU + c0 : 0], x1 = smem[ok ? r1 * SU + c1 : 0];
+                                r[c] = (f32x4){x0.x, x0.y, x1.x, x1.y};
+                            }
                         }
                     }
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        if (i0 + c < IT && (i0 + c) * 64 + lane < NP2) out4[(i0 + c) * 64 + lane] = r[c];
+                    for (int c = 0; c < 8; ++c) {
+                        const int pair = (w + NWW * (t0 + c)) * 64 + lane;
+                        if (t0 + c < MINE && pair < NP2) out4[pair] = r[c];
+                    }
                 }
             } else {
                 const int units = El * U;
-                for (int q = lane; q < units; q += 64) {
+                for (int q = w * 64 + lane; q < units; q += 64 * NWW) {
+                    const int row = q / U, col = q - row * U;
                     out[q] = smem[row * SU + col];
-                    row += DR; col += DC;
-                    if (col >= U) { col -= U; row += 1; }
                 }
             }
         }
-        // reward, individual reward, done of the 64 x N agents: [K][B][N], the wave's slice is contiguous
+        // reward, individual reward, done of the 64 x N agents: [K][B][N], the workgroup's slice is contiguous; the 3 N store
+        // instructions are dealt over the writer waves
         const int cnt = El * N;
         const size_t o0 = (kb + b0) * N + lane;
         if (rew) {                                  // (one uniform branch per array, not per store)
 #pragma unroll
-            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) rew[o0 + c * 64] = s_rew[c * 64 + lane];
+            for (int c = 0; c < N; ++c) if (c % NWW == w && c * 64 + lane < cnt) rew[o0 + c * 64] = s_rew[c * 64 + lane];
         }
         if (indiv) {
 #pragma unroll
-            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) indiv[o0 + c * 64] = s_ind[c * 64 + lane];
+            for (int c = 0; c < N; ++c) if ((c + 1) % NWW == w && c * 64 + lane < cnt) indiv[o0 + c * 64] = s_ind[c * 64 + lane];
         }
         if (done) {
 #pragma unroll
-            for (int c = 0; c < N; ++c) if (c * 64 + lane < cnt) done[o0 + c * 64] = (uint8_t)s_done[c * 64 + lane];
+            for (int c = 0; c < N; ++c) if ((c + 2) % NWW == w && c * 64 + lane < cnt) done[o0 + c * 64] = (uint8_t)s_done[c * 64 + lane];
         }
     }
 }
 
 template <int KIND, int N, int L, int M, int NBR>
-__global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
+__global__ __launch_bounds__(64 + 64 * FG_LANE_NWW) void scn_lane_kernel(const ScnArgs a) {
     constexpr bool DB = scn_lane_double(KIND, N, L, M, NBR);
     constexpr int BLOCK_UNITS = scn_lane_block_bytes(KIND, N, L, M, NBR) / 8;   // float2 units from one block to the next
     constexpr int NE = N + M;
@@ -178,7 +193,8 @@ __global__ __launch_bounds__(128) void scn_lane_kernel(const ScnArgs a) {
     const int KS = a.K > 1 ? a.K : 1;
 
     if (threadIdx.x >= 64) {
-        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane);
+        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane,
+                                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1);
         return;
     }
 

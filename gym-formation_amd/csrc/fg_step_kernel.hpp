@@ -117,6 +117,14 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
     const int K = KONE ? 1 : a.K;
     const uint64_t rbase = rng_base(a.p);            // read once: no load from the device counter inside the step loop
     for (int k = 0; k < K; ++k) {
+        // the agent's own properties as the step loop reads them: the 1024-thread instantiations (128-VGPR budget) fetch them
+        // again in every step instead of holding seven registers across the loop (they spilled to scratch memory)
+        AgentProps mk = me;
+        if constexpr (OPTS && T >= 1024) {
+            int io = i;
+            asm volatile("" : "+v"(io));
+            mk = agent_props_of(a.p, io, io < N);
+        }
         int slot = k;
         bool want_obs = a.do_post && a.obs != nullptr;
         if (!KONE && a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
@@ -125,22 +133,22 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             if (valid) {
                 const real2 u = reinterpret_cast<const real2*>(a.act)[((size_t)k * pre_B + b) * N + i];
                 real2 f;
-                if (het) f = contact_force_het(QX, QY, MS, SZ, FL, N, i, p, me.mass, me.size, me.flags, a.p.contact_force, a.p.contact_margin);
+                if (het) f = contact_force_het(QX, QY, MS, SZ, FL, N, i, p, mk.mass, mk.size, mk.flags, a.p.contact_force, a.p.contact_margin);
                 else f = contact_force_packed<NPS, UNR>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                         a.p.dist_min, cutoff2);
                 if constexpr (OPTS) {
                     const real2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, rbase + k);
                     f.x += fa.x; f.y += fa.y;
-                    if (a.p.num_walls > 0) wall_forces(a.p, p, me.size, f.x, f.y, (me.flags & FG_AGENT_GHOST) != 0);
+                    if (a.p.num_walls > 0) wall_forces(a.p, p, mk.size, f.x, f.y, (mk.flags & FG_AGENT_GHOST) != 0);
                 } else {
                     f.x += a.p.mass * (a.p.sensitivity * u.x);
                     f.y += a.p.mass * (a.p.sensitivity * u.y);
                 }
-                const real m_own = OPTS ? me.mass : a.p.mass;
-                if (!(OPTS && (me.flags & FG_AGENT_IMMOVABLE))) {        // core.py:266-267: an immovable entity keeps its state
+                const real m_own = OPTS ? mk.mass : a.p.mass;
+                if (!(OPTS && (mk.flags & FG_AGENT_IMMOVABLE))) {        // core.py:266-267: an immovable entity keeps its state
                     v.x = v.x * one_minus_damp + (f.x / m_own) * dt;
                     v.y = v.y * one_minus_damp + (f.y / m_own) * dt;
-                    if constexpr (OPTS) v = clamp_speed(me.max_speed, v);
+                    if constexpr (OPTS) v = clamp_speed(mk.max_speed, v);
                     p.x += v.x * dt;
                     p.y += v.y * dt;
                 }
@@ -173,7 +181,7 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                 reward_pass_packed<IDX, NPS, UNR>(PX, PY, SX, SY, NP, p, ptx, pty, tx, ty, thr2,
                                         rowmin, colmin, cnt, arg_lm, arg_ag);
             if (het && valid)                                // per-pair penalty distance; `if agent.collide:` (formation_hd_env.py:71)
-                cnt = (me.flags & FG_AGENT_NO_COLLIDE) ? 0 : collision_count_het(PX, PY, SZ, N, i, p, me.size, a.coll_scale);
+                cnt = (mk.flags & FG_AGENT_NO_COLLIDE) ? 0 : collision_count_het(PX, PY, SZ, N, i, p, mk.size, a.coll_scale);
             real red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (real)cnt};
             env_reduce<G, T, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, scratch);
             const real H = rsqrt_(rmax(red[0], red[1]));
@@ -184,7 +192,9 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
             const real shared = (real)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
             const bool is_done = t_step >= a.p.world_length;
             if (valid) {
-                const size_t o = ((size_t)k * pre_B + b) * N + i;
+                int io = i;
+                if constexpr (T >= 1024) asm volatile("" : "+v"(io));   // 128-VGPR budget: no per-output base addresses kept across the step loop
+                const size_t o = ((size_t)k * pre_B + b) * N + io;
                 if (a.rew) a.rew[o] = shared;
                 if (a.indiv) a.indiv[o] = indiv;
                 if (a.done) a.done[o] = is_done ? 1 : 0;
@@ -218,9 +228,15 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         p = make_real2(u_pm1(c[0]), u_pm1(c[1]));
                         v = make_real2(0.f, 0.f);
                         s = make_real2(rfma(-raw[0], invN, rx), rfma(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
-                        A[i] = p; V[i] = v; NV[i] = v; A[2 * N - 1 + i] = s;
-                        PX[i] = p.x; PY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
-                        reinterpret_cast<real2*>(a.shape)[sidx] = s;
+                        // The agent index as this rarely taken branch sees it is opaque: the ten LDS / global addresses below are
+                        // then computed here, not hoisted out of the step loop into registers that live (and, in the 1024-thread
+                        // instantiations with their 128-VGPR budget, spill to scratch memory) for the whole kernel.
+                        int ir = i;
+                        asm volatile("" : "+v"(ir));
+                        const size_t sr = (size_t)b * N + ir;
+                        A[ir] = p; V[ir] = v; NV[ir] = v; A[2 * N - 1 + ir] = s;
+                        PX[ir] = p.x; PY[ir] = p.y; SX[ir] = s.x; SY[ir] = s.y;
+                        reinterpret_cast<real2*>(a.shape)[sr] = s;
                         if (i == 0) {
                             uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rbase + k),
                                               (uint32_t)((rbase + k) >> 32)};
@@ -272,7 +288,9 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
                         if constexpr (OPTS) {                  // communication block: c_j of the other agents, j ascending
                             const unsigned jc = u - (unsigned)N;
                             if (comm && jc < (unsigned)(N - 1)) {
-                                const real2* C = reinterpret_cast<const real2*>(FL + NP) + ee * N;
+                                unsigned eo = ee * N;
+                                if constexpr (T >= 1024) asm volatile("" : "+v"(eo));   // 128-VGPR budget: the table's address is made here
+                                const real2* C = reinterpret_cast<const real2*>(FL + NP) + eo;
                                 val = C[jc + (jc >= row ? 1u : 0u)];
                             }
                         }

@@ -225,25 +225,24 @@ static int launch_step(Args a, hipStream_t st) {
 
 // 64 < N <= 256: producer / writer pipelined kernel (rollout: over steps; single step: over env batches)
 // PER > 0: closed loop with the PER-ary demo controller inside the kernel (fg_rollout_hd_policy)
-template <int NC, int A, int E, int TW, int PER>
+template <int NC, int A, int E, int TW, int PER, bool BATCHES = false>
 static int launch_wide_v(Args a, hipStream_t st) {
-    if (a.K == 1) {
+    a.groups = 1;
+    if constexpr (BATCHES) {
         // env batches per workgroup: enough to overlap batch g+1's pair loops with batch g's store
         // stream, few enough to keep every CU busy (one workgroup per CU; MI355X sweep, profiles/README.md)
         const int batches = (a.B + E - 1) / E;
         a.groups = batches / 256;
         if (a.groups < 1) a.groups = 1;
         if (a.groups > 64) a.groups = 64;
-    } else {
-        a.groups = 1;
     }
     const int grid = (a.B + E * a.groups - 1) / (E * a.groups);
     const int lds = E * roll_block_floats(NC) * (int)sizeof(float) +
                     (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
     static std::atomic<unsigned long long> raised{0};
-    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, PER>, lds, &raised);
+    hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, PER, BATCHES>, lds, &raised);
     if (err == hipSuccess) {
-        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, PER>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
+        hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, PER, BATCHES>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
         err = hipGetLastError();
     }
     if (err != hipSuccess) return fail(FG_ERR_HIP, "pipelined launch failed: %s", hipGetErrorString(err));
@@ -257,6 +256,9 @@ static int launch_wide(const Args& a, hipStream_t st) {
     // 243 agents, at most 256 envs: one env per workgroup spreads the batch over more CUs (243 x 256 x 8: 103 -> 82 us/step,
     // 243 x 64: 90 -> 78; at 81 agents the producer wave's own chain, ~15 us per step, is the bound whatever the geometry:
     // profiles/r03_wide/ab_wide_small_batches.txt)
+    // a single step (K == 1) of the open loop pipelines over env batches inside the workgroup (fg_step_hd at 81 / 243 agents)
+    if constexpr (PER == 0 && (NC == 81 || NC == 243))
+        if (a.K == 1) return launch_wide_v<NC, A, 4, 256, 0, true>(a, st);
     if constexpr (NC == 243)
         if (a.K > 1 && a.B <= 256) return launch_wide_v<243, 4, 1, 256, PER>(a, st);
     return launch_wide_v<NC, A, 4, 256, PER>(a, st);
@@ -382,7 +384,7 @@ static int launch_roll_64(const Args& a, hipStream_t st) {
 template <int NC>
 static int launch_hd_lane(const Args& a, hipStream_t st) {
     const int grid = 8 * (((a.B + 63) / 64 + 7) / 8);
-    hipLaunchKernelGGL((hd_lane_kernel<NC>), dim3(grid), dim3(128), hd_lane_lds_bytes(NC), st, a);
+    hipLaunchKernelGGL((hd_lane_kernel<NC>), dim3(grid), dim3(64 + 64 * FG_LANE_NWW), hd_lane_lds_bytes(NC), st, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
@@ -847,7 +849,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
 #define FG_SCN_LANE(KIND, NN, LL, MM, NBR)                                                                              \
         if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
             constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
-            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)), dim3(128),    \
+            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)),               \
+                               dim3(64 + 64 * FG_LANE_NWW),                                                                 \
                                lds, st, a);                                                                                 \
             launched = true;                                                                                                \
         }

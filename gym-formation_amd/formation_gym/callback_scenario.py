@@ -198,22 +198,26 @@ class CallbackScenario(BaseScenario):
         D = out["obs"].shape[-1]
         obs = np.zeros((B, N, D), dtype=np.float32)
         indiv = np.zeros((B, N), dtype=np.float32)
+        first = np.zeros((B, N), dtype=np.float32)
         for b in range(B):
             u, hw = self.users[b], self.host_worlds[b]
             for i, a in enumerate(hw.agents):
                 # environment.py:127-130: observation, reward for reward_n, and the reward AGAIN for info['individual_reward']
                 obs[b, i] = np.asarray(u.observation(a, hw), dtype=np.float64)
                 if rewards:
-                    u.reward(a, hw)
-                    indiv[b, i] = float(u.reward(a, hw))
+                    first[b, i] = float(u.reward(a, hw))        # :128 reward_n, :136 its sum = the shared reward
+                    indiv[b, i] = float(u.reward(a, hw))        # :130 info['individual_reward'] - a second call
         if rewards:
             self._upload_bodies(world)
         out["obs"].copy_(torch.as_tensor(obs))
         if out.get("indiv") is not None:
             out["indiv"].copy_(torch.as_tensor(indiv))
-        if out.get("reward") is not None:       # environment.py:136-138: the shared reward is the sum over agents
-            shared = indiv.astype(np.float64).sum(1, keepdims=True).astype(np.float32)
+        if out.get("reward") is not None:       # environment.py:136-138: the shared reward is the sum over agents' FIRST values
+            shared = first.astype(np.float64).sum(1, keepdims=True).astype(np.float32)
             out["reward"].copy_(torch.as_tensor(np.repeat(shared, N, 1)))
+        # what reward_n holds when the reward is not shared: the first call's values (a reward callback that is not idempotent
+        # returns something else the second time; MultiAgentEnv reads this instead of out["indiv"] then)
+        self.first_reward = torch.as_tensor(first).to(out["obs"].device) if rewards else None
         if out.get("done") is not None:         # environment.py:172-178
             done = (self._step_host[:B] >= int(world.world_length)).astype(np.uint8)
             out["done"].copy_(torch.as_tensor(np.repeat(done[:, None], N, 1)))

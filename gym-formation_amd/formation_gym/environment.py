@@ -103,6 +103,7 @@ class MultiAgentEnv(object):
         self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
         self.placement = None             # report of the last buffer placement probe (alloc_rollout_buffers)
         self._auto_out = {}               # (K, obs_every, policy) -> placed output buffers of rollout(out=None), see _default_out
+        self.default_placed = True        # rollout(out=None): env-owned, placed, re-used buffers (False: fresh tensors per call)
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -129,7 +130,7 @@ class MultiAgentEnv(object):
     def step(self, action_n):
         self.current_step += 1
         self.agents = self.world.policy_agents
-        if any(not a.movable and a.silent for a in self.agents):
+        if self.world.any_frozen_silent():
             # environment.py:191-236: `_set_action` consumes the action only `if agent.movable` (or as the communication of
             # a non-silent agent) and then asserts that nothing is left - a silent immovable agent trips that assertion
             # (fixture hd_n6_immovable records it).  Such agents are driven through the World API: world.step().
@@ -175,9 +176,12 @@ class MultiAgentEnv(object):
             reward [K, B, N, 1], done [K, B, N] bool, info {'individual_reward': [K, B, N]}
         `out` may hold pre-allocated buffers (keys obs, reward, indiv, done with those shapes, done as
         uint8), so that a training loop re-uses them.  out=None (the default): the env's own buffers for this (K,
-        obs_every), made on first use with the observation buffer PLACED (`alloc_rollout_buffers`: a 0.2 s probe once, then
-        every launch streams at the placed rate) and re-used by every later call - like `step`, the results are views that
-        the next `rollout` of the same shape overwrites.  out=False: fresh, ordinary tensors on every call."""
+        obs_every), made on first use with the observation buffer PLACED (`alloc_rollout_buffers`: one probe per shape,
+        0.2-0.4 s and transiently up to 6 x the buffer of device memory - the implicit path never escalates to larger
+        arenas) and re-used by every later call.  LIKE `step`, THE RESULTS ARE VIEWS OF ENV-OWNED BUFFERS THAT THE NEXT
+        `rollout` OF THE SAME SHAPE OVERWRITES: `traj.append(env.rollout(a))` aliases - clone what must outlive the next
+        call, or pass out=False (fresh, ordinary tensors on every call) or your own `out`.  The four most recently used
+        (K, obs_every, policy) shapes keep their buffers; `env.default_placed = False` makes out=None mean out=False."""
         roll = getattr(self.scenario, "rollout_batch", None)
         if roll is None:
             raise NotImplementedError("%s has no multi-step launch; call step()" % type(self.scenario).__name__)
@@ -197,7 +201,7 @@ class MultiAgentEnv(object):
         B, N = self.num_envs, self.num_agents
         D = self._out["obs"].shape[-1]
         if out is None:
-            out = self._default_out(K, obs_every, False)
+            out = self._default_out(K, obs_every, False) if self.default_placed else False
         own_buffers = out is not False
         if out is False:
             f = dict(dtype=torch.float32, device=self._act.device)
@@ -257,7 +261,7 @@ class MultiAgentEnv(object):
         f = dict(dtype=torch.float32, device=self._act.device)
         want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N), act=(K, B, N, 2))
         if out is None:
-            out = self._default_out(K, obs_every, True)
+            out = self._default_out(K, obs_every, True) if self.default_placed else False
         own_buffers = out is not False
         if out is False:
             out = {k: (torch.zeros(shp, dtype=torch.uint8, device=self._act.device) if k == "done"
@@ -297,17 +301,18 @@ class MultiAgentEnv(object):
     # ------------------------------------------------------------ buffers
     def _default_out(self, K, obs_every, policy):
         """The env's own output buffers of `rollout(out=None)` / `rollout_policy(out=None)` for this shape: placed on
-        first use, kept for the next call (two shapes at most: a third evicts the least recently used, whose arena goes
-        back to the driver with its last tensor)."""
+        first use, kept for the next call (four shapes at most: a fifth evicts the least recently used, whose arena goes
+        back to the driver with its last tensor).  The implicit probe looks at ONE arena (6 x the buffer): it never takes
+        the escalation stages a caller of `alloc_rollout_buffers` may ask for (up to half of the free memory, seconds)."""
         key = (int(K), int(obs_every), bool(policy))
         out = self._auto_out.pop(key, None)
         if out is None:
             if getattr(self, "_placing", False):       # the probe's own timing launches bring their buffers
                 raise RuntimeError("rollout(out=None) inside a placement probe")
-            while len(self._auto_out) >= 2:
+            while len(self._auto_out) >= 4:
                 self._auto_out.pop(next(iter(self._auto_out)))
             self._roll_launchers.clear()               # bindings keep evicted buffers alive
-            out = self.alloc_rollout_buffers(K, obs_every=obs_every, policy=policy)
+            out = self.alloc_rollout_buffers(K, obs_every=obs_every, policy=policy, escalate=False)
         self._auto_out[key] = out                      # most recently used last
         return out
 
@@ -334,7 +339,7 @@ class MultiAgentEnv(object):
         sc._cache = None
 
     def alloc_rollout_buffers(self, K, obs_every=1, obs_env_pitch=0, policy=False, candidates=8, mem_fraction=0.5,
-                              max_arena_bytes=None):
+                              max_arena_bytes=None, escalate=True):
         """Output buffers for `rollout` / `rollout_policy` launches of K steps, with the observation buffer - 99 % of
         the bytes - PLACED: when it is larger than the Infinity Cache, candidate buffers are composed of the chunks of a
         small arena of device memory (6 x the buffer up to 48 GiB, at least 1.5 x the buffer, never more than
@@ -342,7 +347,8 @@ class MultiAgentEnv(object):
         `candidates` or more of them and the fastest is kept, every other chunk released (formation_gym/placement.py: the
         rate of a launch depends on which physical memory its buffer is composed of, by 10-20 %; ~0.2 s); where the arena
         cannot be made, on up to `candidates` whole allocations.  candidates < 2 switches the probe off.  The env's state
-        is restored afterwards.  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report
+        is restored afterwards, also when the probe fails.  escalate=False: one arena only (an arena whose winner gains
+        nothing is otherwise followed by up to two four times larger ones).  `obs_env_pitch` (floats, 0 = contiguous) asks for padded env blocks.  The probe's report
         is left in `self.placement`.  Returns the `out` dict to pass to `rollout(..., out=out)`.  The arena lives exactly
         as long as the observation tensor (or any view of it): dropping the tensors gives the memory back."""
         from . import placement
@@ -385,17 +391,20 @@ class MultiAgentEnv(object):
 
         arena = None
         self._placing = True
-        placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, trials=candidates, mem_fraction=mem_fraction,
-                                       max_arena_bytes=max_arena_bytes)
-        if placed is not None:
-            flat, report, arena = placed
-            obs = shaped(flat)
-        else:
-            obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
-        self._placing = False
-        self._roll_launchers.clear()                   # bindings made on the candidates keep them alive: drop them,
-        torch.cuda.empty_cache()                       # then hand the losers back to the driver
-        self._restore(snap)
+        try:
+            placed = placement.probe_arena(slots * B * pitch, lambda flat: time_fn(shaped(flat)), dev, trials=candidates,
+                                           mem_fraction=mem_fraction, max_arena_bytes=max_arena_bytes, escalate=escalate)
+            if placed is not None:
+                flat, report, arena = placed
+                obs = shaped(flat)
+            else:
+                obs, report = placement.probe_allocation(alloc, time_fn, nbytes, dev, candidates=candidates, mem_fraction=mem_fraction)
+        finally:
+            # whatever happened inside the probe (out of memory, a failed launch): the env is usable and unchanged afterwards
+            self._placing = False
+            self._roll_launchers.clear()               # bindings made on the candidates keep them alive: drop them,
+            torch.cuda.empty_cache()                   # then hand the losers back to the driver
+            self._restore(snap)
         report["buffer_MB"] = round(nbytes / 1e6, 1)
         if report.get("probed") and D == 6 * N:
             alg = _native.step_hd_bytes(N) * B * K
@@ -578,7 +587,8 @@ class MultiAgentEnv(object):
         o = self._out
         rew = o["reward"].unsqueeze(-1)
         if not self.shared_reward:
-            rew = o["indiv"].unsqueeze(-1)
+            first = getattr(self.scenario, "first_reward", None)      # a reference-style Scenario file: environment.py:128 vs :130
+            rew = (o["indiv"] if first is None else first).unsqueeze(-1)
         return o["obs"], rew, o["done"].view(torch.bool), {"individual_reward": o["indiv"]}   # 0/1 bytes: a view, no kernel
 
     def _reference_result(self):
@@ -602,7 +612,9 @@ class MultiAgentEnv(object):
         if self.shared_reward:
             reward_n = [[shared]] * N                     # :136-138
         else:
-            reward_n = [[float(indiv[i])] for i in range(N)]
+            first = getattr(self.scenario, "first_reward", None)      # see _batched_result
+            per_agent = indiv if first is None else first[0].double().cpu().numpy()
+            reward_n = [[float(per_agent[i])] for i in range(N)]
         done_n = [done] * N
         info_n = [{'individual_reward': float(indiv[i])} for i in range(N)]
         return obs_n, reward_n, done_n, info_n

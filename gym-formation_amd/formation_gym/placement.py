@@ -81,6 +81,11 @@ def probe_allocation(alloc, time_fn, nbytes, device, candidates=8, mem_fraction=
                   "worst_over_kept": round(max(ms) / ms[best], 4)}
 
 
+class _LaunchError(Exception):
+    """Wraps an exception raised by the caller's own launch (`time_fn`) inside a probe, so that it is not mistaken for an
+    arena / mapping failure (which falls back to whole allocations with a warning)."""
+
+
 _live_arenas = []          # weak references to the arenas of this process: `is_placed` answers from them
 
 
@@ -189,7 +194,7 @@ def arena_geometry(nbytes, free_bytes, mem_fraction=0.5, max_arena_bytes=None):
 
 
 def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_bytes=None, reps=3,
-                min_bytes=MIN_PROBE_BYTES, seed=0, budget_s=1.0):
+                min_bytes=MIN_PROBE_BYTES, seed=0, budget_s=1.0, escalate=True):
     """Returns (flat float32 tensor of `nfloats`, report, arena) - the tensor lives in the arena, which the caller keeps
     alive - or None when the buffer is too small to matter or the arena cannot be made (the caller then falls back to
     `probe_allocation`).  time_fn(flat_tensor) enqueues ONE launch that streams into the candidate buffer.
@@ -202,7 +207,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
     once more, the winner is mapped for good and every other chunk goes back to the driver.  An arena whose winner is not
     3 % faster than its own first chunks is closed and followed by one four times as large (`next_arena_bytes`, at most
-    two such steps, report["stages"]); a caller that passes `max_arena_bytes` gets exactly that arena."""
+    two such steps, report["stages"]); a caller that passes `max_arena_bytes` or escalate=False gets exactly one arena.
+    An error of the launch itself (`time_fn` raising) propagates: only arena / mapping failures fall back."""
     import math
     import random
     import time
@@ -237,7 +243,7 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         # allocation, where other boxes reach 50.5): when the arena offered nothing, look at four times as much memory, twice
         # at most, within `mem_fraction` of what is free.  A caller that names the arena size gets that size.
         bigger = next_arena_bytes(geometry[0], nbytes, free, mem_fraction)
-        if (max_arena_bytes is not None or nbytes < ESCALATE_MIN_BYTES or len(stages) >= 3 or bigger is None
+        if (max_arena_bytes is not None or not escalate or nbytes < ESCALATE_MIN_BYTES or len(stages) >= 3 or bigger is None
                 or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]):
             return placed
         del flat, placed
@@ -273,7 +279,7 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
     total, chunk = geometry
     try:
         arena = Arena(total, device, chunk)
-    except Exception:                                            # noqa: BLE001 - no arena (driver, address space): whole allocations
+    except _native.FormationHipError:                            # no arena (driver, address space): whole allocations
         return None
 
     def probe():
@@ -286,7 +292,11 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
             addr = arena.map(idx)
             arena.kept_range = (addr, addr + W * chunk) if placed else (0, 0)   # a spread candidate is timed as what it will be
             try:
-                return _time_launch(time_fn, arena.floats(addr, nfloats), stream, r)
+                flat = arena.floats(addr, nfloats)
+                try:
+                    return _time_launch(time_fn, flat, stream, r)
+                except Exception as exc:                             # noqa: BLE001 - the CALLER's launch failed: not a placement problem
+                    raise _LaunchError(exc) from exc
             finally:
                 stream.synchronize()
                 arena.kept_range = (0, 0)
@@ -322,10 +332,17 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
         first = list(range(W))
         t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
         addr = arena.map(first)                                      # probe measured 5-8 % slow
-        while time.perf_counter() - t_warm < 0.05:
-            _time_launch(time_fn, arena.floats(addr, nfloats), stream, 2)
-        stream.synchronize()
-        arena.unmap(addr)
+        try:
+            flat0 = arena.floats(addr, nfloats)
+            while time.perf_counter() - t_warm < 0.05:
+                try:
+                    _time_launch(time_fn, flat0, stream, 2)
+                except Exception as exc:                             # noqa: BLE001 - see timed()
+                    raise _LaunchError(exc) from exc
+        finally:
+            flat0 = None
+            stream.synchronize()
+            arena.unmap(addr)
         cands = [("as created", first)]
         ms = [timed(first, reps, False)]
         # a short launch is timed more often: the median of 3 launches of 0.24 ms is good to ~1.5 %, which is what separates
@@ -362,6 +379,9 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
 
     try:
         return probe()
+    except _LaunchError as exc:                                  # a genuine kernel / launch failure inside time_fn: the caller's
+        arena.close()                                            # to see, not to be reported as "arena placement failed"
+        raise exc.args[0]
     except Exception as exc:                                     # noqa: BLE001 - a mapping could not be made (address space,
         # driver), or the mapped range could not be used as a tensor on this device: placement is an optimisation, the
         # caller falls back to whole allocations

@@ -142,3 +142,51 @@ def test_plugin_with_colliding_landmarks_matches_the_reference(golden):
         np.testing.assert_allclose(np.array(obs_n), g["obs"][t], rtol=0, atol=ATOL)
         np.testing.assert_allclose([i["individual_reward"] for i in info_n], g["indiv"][t], rtol=0, atol=ATOL)
         prev = dict(pos=g["pos"][t], vel=g["vel"][t], lp=g["lm_pos"][t], lv=g["lm_vel"][t])
+
+
+def test_a_reward_callback_that_counts_its_calls(tmp_path):
+    """environment.py:127-137 calls `reward` twice per agent and step: the first value goes to reward_n (and its sum is the
+    shared reward), the second only to info['individual_reward'].  A callback that is not idempotent tells them apart."""
+    import formation_gym
+    src = '''
+import numpy as np
+from formation_gym.core import World, Agent
+from formation_gym.scenario import BaseScenario
+
+
+class Scenario(BaseScenario):
+    def make_world(self, num_agents=3, world_length=25):
+        world = World()
+        world.world_length = world_length
+        world.collaborative = COLLAB
+        world.agents = [Agent() for _ in range(num_agents)]
+        for i, a in enumerate(world.agents):
+            a.name = 'agent %d' % i
+            a.silent = True
+        self.calls = 0
+        self.reset_world(world)
+        return world
+
+    def reset_world(self, world):
+        for i, a in enumerate(world.agents):
+            a.state.p_pos = np.array([0.3 * i, 0.0])
+            a.state.p_vel = np.zeros(2)
+
+    def reward(self, agent, world):
+        self.calls += 1
+        return float(self.calls)
+
+    def observation(self, agent, world):
+        return np.concatenate([agent.state.p_vel, agent.state.p_pos])
+'''
+    for collab in (False, True):
+        path = tmp_path / ("counting_%d_env.py" % collab)
+        path.write_text(src.replace("COLLAB", str(collab)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            env = formation_gym.make_env(str(path), False, 3, device="cuda:0")
+        env.seed(0); env.reset()
+        obs_n, rew_n, done_n, info_n = env.step([np.zeros(2) for _ in range(3)])
+        # calls 1, 3, 5 are the first per agent; 2, 4, 6 the second
+        assert [i["individual_reward"] for i in info_n] == [2.0, 4.0, 6.0]
+        assert rew_n == ([[9.0]] * 3 if collab else [[1.0], [3.0], [5.0]])

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 import torch
 
+import formation_gym
 from oracle import formation_oracle as O
 from tests.test_gpu_parity import ATOL, _load, _make, _np
 
@@ -312,3 +313,20 @@ def test_random_entity_flags_against_oracle(N, B):
     ok = out["cnt_margin"] > 1e-5
     np.testing.assert_allclose(_np(out_t["indiv"])[ok], out["indiv"][ok], rtol=0, atol=ATOL)
     assert (out["cnt"][:, ~collide] == 0).all() and out["cnt"].sum() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["basic_formation_env", "formation_hd_partial_env", "formation_hd_obs_env"])
+def test_landmark_scenarios_refuse_flagged_agents(name):
+    """The landmark-scenario kernels read only mass / size / accel / max_speed / u_noise of the per-agent table: an immovable,
+    non-colliding or ghost agent must be refused, not silently stepped like an ordinary one."""
+    env = formation_gym.make_env(name, False, 3, num_envs=4, device="cuda:0")
+    env.seed(0); env.reset()
+    act = torch.zeros((4, 3, 2), device="cuda:0")
+    env.step(act)                                                        # ordinary agents: fine
+    for attr, val in (("movable", False), ("collide", False), ("ghost", True)):
+        setattr(env.world.agents[1], attr, val)
+        with pytest.raises((NotImplementedError, AssertionError)):
+            env.step(act)
+        setattr(env.world.agents[1], attr, not val)
+    env.step(act)

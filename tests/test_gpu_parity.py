@@ -577,6 +577,33 @@ def test_bench_json_contract_single_and_two_ranks():
     assert len(line) == 1 and json.loads(line[0])["n_gpus"] == 2
 
 
+def test_bench_many_ranks_share_the_gpu():
+    """A rehearsal of the multi-GPU launch with as many ranks as this pool lets one GPU carry (its process guard allows six
+    GPU processes of ours at once: this test's own + 4 ranks; the 8-rank case is the driver's to run on an 8-GPU node):
+    `--gpus 4 --backend gloo --global-div 64` - four concurrent placement probes inside a quarter of the memory budget each
+    (ranks_per_gpu = 4), four per-rank times, the global env counts, the solo N = 1 leg PLACED like the shards, no rank out of
+    memory or timed out."""
+    import json
+    out = _run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                "--master-port", _free_port(), "bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5", "--envs", "256",
+                "--agents", "27", "--backend", "gloo", "--no-cpu-baseline", "--global-div", "64", "--min-timed-ms", "5"],
+               timeout=600)
+    line = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 4 and d["config"]["global_envs"] == 1024 and d["config"]["ranks_per_gpu"] == -(-4 // torch.cuda.device_count())
+    assert d["state_finite"] and d["value"] > 0
+    gc = d["global_configs"]
+    assert len(gc) == 2
+    for g, n_env in zip(gc, (256, 1024)):
+        assert "skipped" not in g, g
+        assert g["envs_per_gpu"] == n_env // 4 and len(g["per_rank_ms_per_step"]) == 4 and all(x > 0 for x in g["per_rank_ms_per_step"])
+        assert g["state_finite"] and g["n1_same_run"] and g["n1_env_steps_per_s"] > 0
+        assert "n1_placement" in g and "scaling_denominator" in g         # the denominator is placed like the numerator
+        if g["n1_placement"].get("probed"):
+            assert g["scaling_efficiency_vs_n1_unplaced"] > 0
+
+
 def test_c_abi_from_plain_cpp_without_python_or_torch(tmp_path):
     """examples/c_abi_rollout.cpp: hipMalloc'd buffers, the caller's stream, fg_reset_hd / fg_observe_hd /
     fg_rollout_hd / fg_step_hd through the header alone; checks its own results and prints throughput."""
