@@ -62,6 +62,34 @@ __global__ __launch_bounds__(256) void update_comm_kernel(const FgParams p, int 
     comm[t] = c;
 }
 
+// The same for any dim_c (core.py:279-286 takes whatever World.dim_c is; every scenario file of the reference sets 2): one
+// thread per (env, agent, pair of components); pair 0 draws the very noise update_comm_kernel draws, pair q > 0 its own
+// counter stream (agent index | 0x40000000 | q << 12).
+__global__ __launch_bounds__(256) void update_comm_dim_kernel(const FgParams p, int B, int N, int dim_c,
+                                                              const float* __restrict__ action_c, float* __restrict__ comm) {
+    const int pairs = (dim_c + 1) >> 1;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * N * pairs) return;
+    const long long bi = t / pairs;
+    const int q = (int)(t - bi * pairs);
+    const int b = (int)(bi / N), i = (int)(bi - (long long)b * N);
+    const float c_noise = p.agent_props ? p.agent_props[(size_t)i * FG_AGENT_PROPS + 5] : 0.0f;
+    const size_t o = (size_t)bi * dim_c + 2 * q;
+    const bool two = 2 * q + 1 < dim_c;
+    float c0 = 0.f, c1 = 0.f;
+    if (c_noise >= 0.0f) {
+        c0 = action_c[o];
+        if (two) c1 = action_c[o + 1];
+        if (c_noise > 0.0f) {
+            const real2 n = motor_noise(p.seed, (uint32_t)(b + p.env_index_base), (uint32_t)i | 0x40000000u | ((uint32_t)q << 12),
+                                        rng_base(p));
+            c0 += c_noise * n.x; c1 += c_noise * n.y;
+        }
+    }
+    comm[o] = c0;
+    if (two) comm[o + 1] = c1;
+}
+
 // ---------------------------------------------------------------------------
 // Bit-exact reset on device: Scenario.reset_world (formation_hd_env.py:77-95) drawing from the
 // env's own legacy NumPy MT19937 stream (environment.py:106-110 seeds it), so that multi-episode
@@ -71,6 +99,53 @@ __global__ __launch_bounds__(256) void update_comm_kernel(const FgParams p, int 
 //   double = ((a >> 5) * 2^26 + (b >> 6)) / 2^53 from two 32-bit outputs; U(-1,1) = -1 + 2 d.
 // mt_state: uint32 [B][626] = key[624], pos, unused.
 // ---------------------------------------------------------------------------
+// The next `count` tempered 32-bit outputs of the env's MT19937 stream -> outs[0 .. count) (LDS), by the 256 threads of the
+// workgroup: `mt` (LDS, 624 words) is loaded from gstate[0 .. 624), regenerated as often as needed; returns the new position
+// (the caller writes `mt` and the position back).  NumPy's legacy generator word for word (randomkit.c: genrand).
+__device__ __forceinline__ int mt_generate_words(uint32_t* mt, uint32_t* outs, const uint32_t* gstate, int count, int tid) {
+    for (int q = tid; q < 624; q += 256) mt[q] = gstate[q];
+    int pos = (int)gstate[624];
+    __syncthreads();
+    int produced = 0;
+    auto mix = [](uint32_t a, uint32_t b2) -> uint32_t {
+        const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu);
+        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    };
+    while (produced < count) {
+        if (pos >= 624) {                              // regenerate the 624 words (three dependent thirds)
+            uint32_t nv = 0;
+            if (tid < 227) nv = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
+            __syncthreads();
+            if (tid < 227) mt[tid] = nv;
+            __syncthreads();
+            if (tid < 227) nv = mt[tid] ^ mix(mt[tid + 227], mt[tid + 228]);            // kk = tid + 227
+            __syncthreads();
+            if (tid < 227) mt[tid + 227] = nv;
+            __syncthreads();
+            if (tid < 169) nv = mt[tid + 227] ^ mix(mt[tid + 454], mt[tid + 455]);      // kk = tid + 454 .. 622
+            const uint32_t old623 = mt[623];
+            __syncthreads();
+            if (tid < 169) mt[tid + 454] = nv;
+            __syncthreads();
+            if (tid == 0) mt[623] = mt[396] ^ mix(old623, mt[0]);
+            __syncthreads();
+            pos = 0;
+        }
+        const int take = min(624 - pos, count - produced);
+        for (int q = tid; q < take; q += 256) {
+            uint32_t y = mt[pos + q];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            outs[produced + q] = y;
+        }
+        produced += take; pos += take;
+        __syncthreads();
+    }
+    return pos;
+}
+
 // Which envs reset: those whose mask byte is set (mask != NULL), every env (mask NULL, world_length <= 0), or - the
 // vec-env worker's rule, decided on the device without a mask upload or a host read-back - those whose episode is over,
 // step[b] >= world_length (mask NULL, world_length > 0; env_wrappers.py:14-18).  With `obs` the workgroup also writes the
@@ -92,47 +167,8 @@ __global__ __launch_bounds__(256) void mt_reset_kernel(int B, int N, const uint8
     float2* const S = P + N;
     float2* const IV = S + N;
     uint32_t* const gstate = mt_state + (size_t)b * 626;
-    for (int q = tid; q < 624; q += 256) mt[q] = gstate[q];
-    int pos = (int)gstate[624];
-    __syncthreads();
     const int M = 8 * N + 4;
-    int produced = 0;
-    auto mix = [](uint32_t a, uint32_t b2) -> uint32_t {
-        const uint32_t y = (a & 0x80000000u) | (b2 & 0x7fffffffu);
-        return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-    };
-    while (produced < M) {
-        if (pos >= 624) {                              // regenerate the 624 words (three dependent thirds)
-            uint32_t nv = 0;
-            if (tid < 227) nv = mt[tid + 397] ^ mix(mt[tid], mt[tid + 1]);
-            __syncthreads();
-            if (tid < 227) mt[tid] = nv;
-            __syncthreads();
-            if (tid < 227) nv = mt[tid] ^ mix(mt[tid + 227], mt[tid + 228]);            // kk = tid + 227
-            __syncthreads();
-            if (tid < 227) mt[tid + 227] = nv;
-            __syncthreads();
-            if (tid < 169) nv = mt[tid + 227] ^ mix(mt[tid + 454], mt[tid + 455]);      // kk = tid + 454 .. 622
-            const uint32_t old623 = mt[623];
-            __syncthreads();
-            if (tid < 169) mt[tid + 454] = nv;
-            __syncthreads();
-            if (tid == 0) mt[623] = mt[396] ^ mix(old623, mt[0]);
-            __syncthreads();
-            pos = 0;
-        }
-        const int take = min(624 - pos, M - produced);
-        for (int q = tid; q < take; q += 256) {
-            uint32_t y = mt[pos + q];
-            y ^= (y >> 11);
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= (y >> 18);
-            outs[produced + q] = y;
-        }
-        produced += take; pos += take;
-        __syncthreads();
-    }
+    int pos = mt_generate_words(mt, outs, gstate, M, tid);
     auto draw = [&](int m) -> double {                 // m-th double of this reset
         const double a = (double)(outs[2 * m] >> 5), c = (double)(outs[2 * m + 1] >> 6);
         return -1.0 + 2.0 * ((a * 67108864.0 + c) / 9007199254740992.0);
@@ -250,6 +286,54 @@ __global__ __launch_bounds__(256) void scn_reset_kernel(const FgParams P, const 
         opos[(size_t)b * M + k] = scn_fresh_obstacle(P, b, k, M, off);
         ovel[(size_t)b * M + k] = make_float2(sc.obstacle_vx, sc.obstacle_vy);
     }
+}
+
+// Scenario.reset_world of the landmark scenarios from the env's own legacy MT19937 stream, bit-exact with the host path
+// (basic_formation_env.py:54-65, formation_hd_partial_env.py:88-99, formation_hd_partial_range_env.py:76-87,
+// formation_hd_obs_env.py:101-120): N agent positions, L landmark positions, each -1 + 2 u; then M obstacles from
+// np.random.uniform([s_k, 2.0], [s_k+1, 2.5]) = low + (high - low) u with s = np.linspace(-1.8, 1.8, M + 1), velocity (ovx, ovy);
+// agent velocities zero, step counter zero.  Which envs: mt_reset_kernel's rule (mask / everybody / step >= world_length).
+__global__ __launch_bounds__(256) void mt_reset_scn_kernel(int B, int N, int L, int M, const uint8_t* __restrict__ mask,
+                                                           uint32_t* __restrict__ mt_state,
+                                                           float* px, float* py, float* vx, float* vy,
+                                                           float2* lm, float2* opos, float2* ovel, int32_t* step,
+                                                           int world_length, float ovx, float ovy) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (b >= B || (mask && !mask[b])) return;
+    if (!mask && world_length > 0 && step[b] < world_length) return;
+    uint32_t* const mt = lds_u32;                      // [624]
+    uint32_t* const outs = lds_u32 + 624;              // [4 (N + L + M)] tempered outputs
+    uint32_t* const gstate = mt_state + (size_t)b * 626;
+    const int words = 4 * (N + L + M);
+    const int pos = mt_generate_words(mt, outs, gstate, words, tid);
+    auto unit = [&](int m) -> double {                 // m-th double of this reset, in [0, 1)
+        const double a = (double)(outs[2 * m] >> 5), c = (double)(outs[2 * m + 1] >> 6);
+        return (a * 67108864.0 + c) / 9007199254740992.0;
+    };
+    for (int i = tid; i < N; i += 256) {
+        const size_t o = (size_t)b * N + i;
+        px[o] = (float)(-1.0 + 2.0 * unit(2 * i)); py[o] = (float)(-1.0 + 2.0 * unit(2 * i + 1));
+        vx[o] = 0.f; vy[o] = 0.f;
+    }
+    for (int l = tid; l < L; l += 256)
+        lm[(size_t)b * L + l] = make_float2((float)(-1.0 + 2.0 * unit(2 * (N + l))), (float)(-1.0 + 2.0 * unit(2 * (N + l) + 1)));
+    for (int k = tid; k < M; k += 256) {
+        // np.linspace(-1.8, 1.8, M + 1): arange(M + 1) * (3.6 / M) + (-1.8), the last point set to the stop value
+        // (every product rounded before its sum, as NumPy's C code does: no fused multiply-add here)
+        const double dstep = (1.8 - (-1.8)) / (double)M;
+        const double lo = __dadd_rn(__dmul_rn((double)k, dstep), -1.8);
+        const double hi = (k + 1 == M) ? 1.8 : __dadd_rn(__dmul_rn((double)(k + 1), dstep), -1.8);
+        const double x = __dadd_rn(lo, __dmul_rn(hi - lo, unit(2 * (N + L + k))));
+        const double y = __dadd_rn(2.0, __dmul_rn(2.5 - 2.0, unit(2 * (N + L + k) + 1)));
+        opos[(size_t)b * M + k] = make_float2((float)x, (float)y);
+        ovel[(size_t)b * M + k] = make_float2(ovx, ovy);
+    }
+    if (tid == 0) {
+        if (step) step[b] = 0;
+        gstate[624] = (uint32_t)pos;
+    }
+    for (int q = tid; q < 624; q += 256) gstate[q] = mt[q];
 }
 
 template <int G, int T>

@@ -272,7 +272,7 @@ FG_DEV real2 motor_noise(uint64_t seed, uint32_t b, uint32_t i, uint64_t offset)
 // One agent's own properties (core.py:45-109): the World-wide scalars of FgParams, or its row of FgParams.agent_props
 struct AgentProps {
     real mass, size, accel, max_speed, u_noise, sens;
-    int flags;                 // FG_AGENT_IMMOVABLE | FG_AGENT_NO_COLLIDE | FG_AGENT_GHOST (core.py:54-58); 0 = an ordinary agent
+    int flags;                 // FG_AGENT_IMMOVABLE | FG_AGENT_NO_COLLIDE | FG_AGENT_GHOST (core.py:54-58) | FG_AGENT_SCRIPTED; 0 = an ordinary agent
 };
 FG_DEV AgentProps agent_props_of(const KParams& P, int i, bool in_range) {
     AgentProps q = {P.mass, real(0.5f) * P.dist_min, P.accel, P.max_speed, P.u_noise, P.sensitivity, 0};
@@ -281,6 +281,7 @@ FG_DEV AgentProps agent_props_of(const KParams& P, int i, bool in_range) {
         q.mass = r[0]; q.size = r[1]; q.accel = r[2]; q.max_speed = r[3]; q.u_noise = r[4];
         q.flags = (int)r[6];
         q.sens = (q.accel > 0.0f) ? q.accel : P.sensitivity;               // environment.py:218-220
+        if (q.flags & FG_AGENT_SCRIPTED) q.sens = 1.0f;                    // core.py:210-211: a scripted agent's action.u is used as it is
     }
     return q;
 }

@@ -188,6 +188,76 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     return BA + pstart;                       // the leaf level: N actions
 }
 
+// The same hierarchy for ONE LANE that holds a whole env in registers (fg_hd_lane_kernel.hpp: 3 and 4 agents): N, PER and with
+// them the number of levels are compile-time constants, every table below is a register array with static indices.  The
+// operations and their order are bfs_policy_env's - level sums child by child, `ez_policy` per (level, sub-group), the
+// top-down combine `(act + w * target velocity) * level` - so the two give the same bits.
+template <int N, int PER> constexpr int policy_levels_ct() {
+    int l = 0, n = 1;
+    while (n < N) { n *= PER; ++l; }
+    return l;
+}
+template <int N, int PER>
+FG_DEV void bfs_policy_lane(const float2 (&R)[N], const float2 (&S)[N], const FgPolicyLevels& pl, float2 iv, float2 (&act)[N]) {
+    constexpr int L = policy_levels_ct<N, PER>();
+    static_assert(L >= 1 && L <= 3, "one env per lane: a handful of agents");
+    float2 SR[L][N], SS[L][N];                          // level l: sums over PER^l consecutive agents (level 0: R, S)
+#pragma unroll
+    for (int j = 0; j < N; ++j) { SR[0][j] = R[j]; SS[0][j] = S[j]; }
+    int n_l = N;
+#pragma unroll
+    for (int l = 1; l < L; ++l) {
+        n_l /= PER;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (j < n_l) {
+                float2 a = SR[l - 1][j * PER < N ? j * PER : 0], b = SS[l - 1][j * PER < N ? j * PER : 0];
+#pragma unroll
+                for (int c = 1; c < PER; ++c) {
+                    const float2 x = SR[l - 1][j * PER + c < N ? j * PER + c : 0], y = SS[l - 1][j * PER + c < N ? j * PER + c : 0];
+                    a.x += x.x; a.y += x.y; b.x += y.x; b.y += y.y;
+                }
+                SR[l][j] = a; SS[l][j] = b;
+            }
+        }
+    }
+    float2 BA[L][N];                                    // per level (index lev - 1) and sub-group: act, then the target velocity
+    float BW[L][N];
+    int n = N;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {                       // the problems of level lev = l + 1 read the child sums of level l
+#pragma unroll
+        for (int sg = 0; sg < N; ++sg) {
+            if (sg < n) {
+                const int g = sg / PER, i = sg - g * PER;
+                float w;
+                BA[l][sg] = ez_policy<PER>(SR[l], SS[l], g * PER, i, pl.inv_sub[l], pl.inv_per, w);
+                BW[l][sg] = w;
+            }
+        }
+        n /= PER;
+    }
+    n = PER;
+#pragma unroll
+    for (int lev = L; lev >= 1; --lev) {                // top-down (:43-46, :78-79)
+        const float flev = (float)lev;
+#pragma unroll
+        for (int sg = 0; sg < N; ++sg) {
+            if (sg < n) {
+                const float2 up = BA[lev < L ? lev : L - 1][sg / PER];
+                const float2 tv = make_float2(lev == L ? iv.x : up.x, lev == L ? iv.y : up.y);
+                float2 a = BA[lev - 1][sg];
+                const float w = BW[lev - 1][sg];
+                a.x += tv.x * w; a.y += tv.y * w;
+                BA[lev - 1][sg] = make_float2(a.x * flev, a.y * flev);
+            }
+        }
+        n *= PER;
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) act[j] = BA[0][j];
+}
+
 // Stand-alone launch: one env per `lpe` lanes (power of two >= min(N, 256)), tables from observation row 0.
 template <int PER>
 __global__ __launch_bounds__(256) void policy_bfs_kernel(const int B, const int N, const int lpe, const FgPolicyLevels pl,

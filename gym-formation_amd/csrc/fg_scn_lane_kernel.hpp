@@ -77,13 +77,12 @@ __host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int
 // [N][D] observation rows at an odd pitch of U | 1 float2 units, then reward / individual reward / done of the 64 x N agents
 // as three arrays of 64 N dwords; DB = two blocks taking turns (one barrier per step) instead of one (two barriers).
 // NWW writer waves share the block: wave w takes the store instructions w, w + NWW, ... of the span (and of the reward /
-// done arrays), so that NWW times as many stores of a workgroup are in flight (one writer wave per 64 envs at 2 waves per SIMD
-// could not cover the 325-475 cycles of write latency: profiles/r04_scn_pmc.txt, r04_store_path_pmc.txt).
-#ifndef FG_LANE_WRITERS
-#define FG_LANE_WRITERS 2
-#endif
-constexpr int FG_LANE_NWW = FG_LANE_WRITERS;
-template <int N, int D, bool DB, int NWW = FG_LANE_NWW>
+// done arrays).  More writer waves do NOT buy store bandwidth here - every CU already has its write queue full (64 outstanding
+// 64-byte requests per CU x 330-480 cycles of write latency is the chip's store ceiling, profiles/r04_store_path_pmc.txt,
+// r05_place_channels.md): two waves gain 2 % at basic_formation_env's small blocks (3.08 -> 3.02 us/step at 65536 envs) and lose
+// 2-6 % at the larger rows of the other scenarios, three lose 2-20 % (profiles/r05_lane_writers_ab.txt).
+__host__ __device__ constexpr int scn_lane_writers(int kind) { return kind == FG_SCN_BASIC ? 2 : 1; }
+template <int N, int D, bool DB, int NWW = 1>
 FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int El, int obs_every,
                              float* __restrict__ obs, float* __restrict__ rew, float* __restrict__ indiv, uint8_t* __restrict__ done, int lane,
                              int w = 0) {
@@ -166,7 +165,7 @@ FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int 
 }
 
 template <int KIND, int N, int L, int M, int NBR>
-__global__ __launch_bounds__(64 + 64 * FG_LANE_NWW) void scn_lane_kernel(const ScnArgs a) {
+__global__ __launch_bounds__(64 + 64 * scn_lane_writers(KIND)) void scn_lane_kernel(const ScnArgs a) {
     constexpr bool DB = scn_lane_double(KIND, N, L, M, NBR);
     constexpr int BLOCK_UNITS = scn_lane_block_bytes(KIND, N, L, M, NBR) / 8;   // float2 units from one block to the next
     constexpr int NE = N + M;
@@ -193,8 +192,8 @@ __global__ __launch_bounds__(64 + 64 * FG_LANE_NWW) void scn_lane_kernel(const S
     const int KS = a.K > 1 ? a.K : 1;
 
     if (threadIdx.x >= 64) {
-        lane_writer_wave<N, D, DB>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane,
-                                   __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1);
+        lane_writer_wave<N, D, DB, scn_lane_writers(KIND)>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane,
+                                                           __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1);
         return;
     }
 

@@ -293,11 +293,18 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
     // 8 agents, a batch that fills the chip: an env's 1536 bytes as one contiguous span of 16-byte stores instead of rows in
     // 64- / 128-byte pieces (LDS tiles: 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; the gather writer since: 18.9 ->
     // 18.6, equal at 8192); 8 x 1024 is bound by the producers' chain and keeps the rows writer (1.09 vs 1.48)
-    if constexpr (PER == 0 && NC == 8) {
+    if constexpr (NC == 8) {
         // ... and with one workgroup per CU (4096 envs) into a buffer beyond the Infinity Cache, 16 envs and eight writer
         // waves per workgroup: 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it: profiles/r04_writers_ab.txt)
-        if (a.B >= 4096 && a.B < 5120 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6)
-            return launch_roll_v<NC, G, 128, 512, 128 / G, 9, PER>(a, st);
+        if constexpr (PER == 0)
+            if (a.B >= 4096 && a.B < 5120 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6)
+                return launch_roll_v<NC, G, 128, 512, 128 / G, 9, PER>(a, st);
+        // (the closed loop takes the gather writer as well since round 5 - no gain by itself, 23.2 -> 22.7 us/step at 8 x 65536 -)
+        // closed loop, a batch of many workgroup generations: the producers' chain (controller + physics, ~3.6 us per step) is
+        // the bound, so ONE writer wave per workgroup leaves room for more resident producer waves - 8 x 65536 22.7 -> 20.9
+        // us/step; at 8192 envs two writer waves stay ahead (3.17 vs 3.50: profiles/r05_r8_ab.txt)
+        if constexpr (PER > 0)
+            if (a.B >= 32768) return launch_roll_v<NC, G, 64, 64, 64 / G, FG_WR_GATHER, PER>(a, st);
         if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, FG_WR_GATHER, PER>(a, st);
     }
     return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
@@ -381,10 +388,10 @@ static int launch_roll_64(const Args& a, hipStream_t st) {
 // loop (actions from act_seq); else the closed loop of fg_rollout_hd_policy.  Returns false when (N, per) has no instantiation
 // (the caller then runs step_kernel's K-loop / chained launches).
 // 3 and 4 agents, open loop, contiguous observations, a batch that fills the chip: one env per lane (fg_hd_lane_kernel.hpp)
-template <int NC>
+template <int NC, int PER = 0>
 static int launch_hd_lane(const Args& a, hipStream_t st) {
     const int grid = 8 * (((a.B + 63) / 64 + 7) / 8);
-    hipLaunchKernelGGL((hd_lane_kernel<NC>), dim3(grid), dim3(64 + 64 * FG_LANE_NWW), hd_lane_lds_bytes(NC), st, a);
+    hipLaunchKernelGGL((hd_lane_kernel<NC, PER>), dim3(grid), dim3(128), hd_lane_lds_bytes(NC), st, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
@@ -395,9 +402,13 @@ constexpr int FG_HD_LANE_MIN_B = 32768;
 
 static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
 #define FG_ROLL(FN, NN, PP) if (a.N == NN && per == PP) { *rc = FN<NN, PP>(a, st); return true; }
-    if (per == 0 && a.B >= FG_HD_LANE_MIN_B && a.obs_pitch == 3LL * a.N * a.N) {
-        if (a.N == 3) { *rc = launch_hd_lane<3>(a, st); return true; }
-        if (a.N == 4) { *rc = launch_hd_lane<4>(a, st); return true; }
+    if (a.B >= FG_HD_LANE_MIN_B && a.obs_pitch == 3LL * a.N * a.N) {
+        if (a.N == 3 && per == 0) { *rc = launch_hd_lane<3>(a, st); return true; }
+        if (a.N == 4 && per == 0) { *rc = launch_hd_lane<4>(a, st); return true; }
+        // ... and the closed loop with the controller on the lane's registers (bfs_policy_lane)
+        if (a.N == 3 && per == 3) { *rc = launch_hd_lane<3, 3>(a, st); return true; }
+        if (a.N == 4 && per == 2) { *rc = launch_hd_lane<4, 2>(a, st); return true; }
+        if (a.N == 4 && per == 4) { *rc = launch_hd_lane<4, 4>(a, st); return true; }
     }
     FG_ROLL(launch_roll_8, 3, 0) FG_ROLL(launch_roll_8, 3, 3)
     FG_ROLL(launch_roll_8, 4, 0) FG_ROLL(launch_roll_8, 4, 2) FG_ROLL(launch_roll_8, 4, 4)
@@ -663,18 +674,17 @@ int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes) {
 
 int64_t fg_step_hd_bytes(int N) { return 24LL * N * N + 53LL * N + 16LL; }
 
-int fg_step_hd(const FgParams* params, int B, int N,
-               float* pos_x, float* pos_y, float* vel_x, float* vel_y,
-               const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
-               float* obs, float* reward, float* indiv_reward, uint8_t* done,
-               int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
-    const DeviceGuard device_guard(stream, pos_x);
+// fg_step_hd in two halves: argument checks + the launch description, and the dispatch of a checked description
+static int step_hd_describe(const FgParams* params, int B, int N,
+                            float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                            const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+                            float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                            int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, Args* out) {
     int rc = check_params(params);
     if (rc) return rc;
-    if (B == 0) return FG_OK;                         // an empty batch is a no-op (e.g. a rank that owns no envs)
     if (B < 0) return fail(FG_ERR_BAD_ARG, "B must be >= 0%s");
     if (N < 3 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
-    if (!pos_x || !pos_y || !vel_x || !vel_y || !act || !ideal_shape || !ideal_vel || !step || !obs || !reward)
+    if (B > 0 && (!pos_x || !pos_y || !vel_x || !vel_y || !act || !ideal_shape || !ideal_vel || !step || !obs || !reward))
         return fail(FG_ERR_BAD_ARG, "fg_step_hd: a required pointer is NULL%s");
     if (((uintptr_t)obs & 15u) || ((uintptr_t)act & 7u) || ((uintptr_t)ideal_shape & 7u) || ((uintptr_t)ideal_vel & 7u))
         return fail(FG_ERR_ALIGNMENT, "obs must be 16-byte, act/ideal_shape/ideal_vel 8-byte aligned%s");
@@ -685,15 +695,72 @@ int fg_step_hd(const FgParams* params, int B, int N,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     a.near_lm = near_lm; a.near_ag = near_ag; a.hd_idx = hd_idx;
+    *out = a;
+    return FG_OK;
+}
+
+static int step_hd_dispatch(const Args& a, hipStream_t stream) {
+    if (a.B == 0) return FG_OK;                       // an empty batch is a no-op (e.g. a rank that owns no envs)
+    const bool plain = !world_options_set(a.p) && !a.near_lm && !a.near_ag && !a.hd_idx;
     // 243 agents, >= 4096 envs: pipeline over env batches inside the launch (no index outputs, no World options):
     // 1.85-2.2 ms vs 2.1-2.3 ms at 243 x 8192 (round 1; 1.75 ms on placed buffers).
-    if (N == 243 && B >= FG_WIDE243_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
-        return launch_wide<243, 0>(a, (hipStream_t)stream);
+    if (a.N == 243 && a.B >= FG_WIDE243_MIN_B && plain) return launch_wide<243, 0>(a, stream);
     // 81 agents: the pipelined kernel pays from 16 env batches per workgroup on (81 x 16384: 419 vs 448 us; 81 x 12288 equal,
     // 81 x 2048 62 vs 56: profiles/r03_step/pipelined_single_step_81.txt)
-    if (N == 81 && B >= FG_WIDE81_MIN_B && !world_options_set(a.p) && !near_lm && !near_ag && !hd_idx)
-        return launch_wide<81, 0>(a, (hipStream_t)stream);
-    return launch_step(a, (hipStream_t)stream);
+    if (a.N == 81 && a.B >= FG_WIDE81_MIN_B && plain) return launch_wide<81, 0>(a, stream);
+    return launch_step(a, stream);
+}
+
+int fg_step_hd(const FgParams* params, int B, int N,
+               float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+               const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+               float* obs, float* reward, float* indiv_reward, uint8_t* done,
+               int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream) {
+    const DeviceGuard device_guard(stream, pos_x);
+    Args a;
+    const int rc = step_hd_describe(params, B, N, pos_x, pos_y, vel_x, vel_y, act, ideal_shape, ideal_vel, step,
+                                    obs, reward, indiv_reward, done, near_lm, near_ag, hd_idx, &a);
+    if (rc) return rc;
+    return step_hd_dispatch(a, (hipStream_t)stream);
+}
+
+// A step loop that re-uses its buffers launches the same description again and again with only the RNG offset moving: the
+// plan keeps the checked description, so the per-step host work is one two-argument call and the kernel launch (a ctypes
+// call with 19 arguments cost 1.7 us per env.step on top of the 7.7 us kernel at 9 x 4096: VERDICT r4).
+namespace { struct StepPlan { Args a; hipStream_t stream; int device; }; }
+
+int fg_step_hd_plan(const FgParams* params, int B, int N,
+                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                    const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+                    float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                    int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream, void** plan) {
+    if (!plan) return fail(FG_ERR_BAD_ARG, "fg_step_hd_plan: plan is NULL%s");
+    Args a;
+    const int rc = step_hd_describe(params, B, N, pos_x, pos_y, vel_x, vel_y, act, ideal_shape, ideal_vel, step,
+                                    obs, reward, indiv_reward, done, near_lm, near_ag, hd_idx, &a);
+    if (rc) return rc;
+    StepPlan* sp = new StepPlan();
+    sp->a = a; sp->stream = (hipStream_t)stream;
+    sp->device = visible_devices() < 2 ? -1 : resolve_device(stream, pos_x);
+    *plan = sp;
+    return FG_OK;
+}
+
+int fg_plan_launch(void* plan, uint64_t rng_offset) {
+    StepPlan* sp = (StepPlan*)plan;
+    if (!sp) return fail(FG_ERR_BAD_ARG, "fg_plan_launch: plan is NULL%s");
+    int prev = -1;
+    bool switched = false;
+    if (sp->device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != sp->device) switched = hipSetDevice(sp->device) == hipSuccess;
+    sp->a.p.rng_offset = rng_offset;
+    const int rc = step_hd_dispatch(sp->a, sp->stream);
+    if (switched) (void)hipSetDevice(prev);
+    return rc;
+}
+
+int fg_plan_destroy(void* plan) {
+    delete (StepPlan*)plan;
+    return FG_OK;
 }
 
 int fg_physics_step(const FgParams* params, int B, int N,
@@ -850,7 +917,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
             constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
             hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)),               \
-                               dim3(64 + 64 * FG_LANE_NWW),                                                                 \
+                               dim3(64 + 64 * scn_lane_writers(KIND)),                                                      \
                                lds, st, a);                                                                                 \
             launched = true;                                                                                                \
         }
@@ -934,6 +1001,30 @@ int fg_reset_hd_mt_done(int B, int N, int world_length, uint32_t* mt_state,
                            world_length, obs, (long long)obs_env_pitch, stream);
 }
 
+int fg_reset_scenario_mt(const FgScenario* scenario, int B, int N, const uint8_t* mask, int world_length, uint32_t* mt_state,
+                         float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                         float* landmarks, float* obst_pos, float* obst_vel, int32_t* step, void* stream) {
+    const DeviceGuard device_guard(stream, pos_x);
+    if (!scenario) return fail(FG_ERR_BAD_ARG, "scenario descriptor is NULL%s");
+    const int L = scenario->num_landmarks, M = scenario->num_obstacles;
+    if (B == 0) return FG_OK;
+    if (B < 0 || L <= 0 || M < 0) return fail(FG_ERR_BAD_ARG, "B >= 0, L > 0, M >= 0 required%s");
+    if (N < 2 || N + M > FG_MAX_AGENTS || L > 1024)
+        return fail(FG_ERR_UNSUPPORTED_N, "scenario kernel needs 2 <= N, N + M <= 1024, L <= 1024%s");
+    if (!mt_state || !pos_x || !pos_y || !vel_x || !vel_y || !landmarks || (M > 0 && (!obst_pos || !obst_vel)))
+        return fail(FG_ERR_BAD_ARG, "fg_reset_scenario_mt: a required pointer is NULL%s");
+    if (!mask && world_length > 0 && !step) return fail(FG_ERR_BAD_ARG, "fg_reset_scenario_mt: the done rule needs the step counters%s");
+    if (((uintptr_t)landmarks & 7u) || ((uintptr_t)obst_pos & 7u) || ((uintptr_t)obst_vel & 7u))
+        return fail(FG_ERR_ALIGNMENT, "landmarks / obstacle buffers must be 8-byte aligned%s");
+    const int lds = (624 + 4 * (N + L + M)) * (int)sizeof(uint32_t);
+    hipLaunchKernelGGL(mt_reset_scn_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, B, N, L, M, mask, mt_state,
+                       pos_x, pos_y, vel_x, vel_y, reinterpret_cast<float2*>(landmarks), reinterpret_cast<float2*>(obst_pos),
+                       reinterpret_cast<float2*>(obst_vel), step, world_length, scenario->obstacle_vx, scenario->obstacle_vy);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "mt reset launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
 int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, float* comm_state, void* stream) {
     const DeviceGuard device_guard(stream, comm_state);
     int rc = check_params(params);
@@ -947,6 +1038,25 @@ int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, 
     const long long count = (long long)B * N;
     hipLaunchKernelGGL(update_comm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        *params, B, N, reinterpret_cast<const float2*>(action_c), reinterpret_cast<float2*>(comm_state));
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "comm launch failed: %s", hipGetErrorString(err));
+    return FG_OK;
+}
+
+int fg_update_comm_dim(const FgParams* params, int B, int N, int dim_c, const float* action_c, float* comm_state, void* stream) {
+    if (dim_c == 2) return fg_update_comm(params, B, N, action_c, comm_state, stream);
+    const DeviceGuard device_guard(stream, comm_state);
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B == 0 || dim_c == 0) return FG_OK;
+    if (B < 0 || dim_c < 0 || dim_c > 4096) return fail(FG_ERR_BAD_ARG, "B >= 0 and 0 <= dim_c <= 4096 required%s");
+    if (N < 1 || N > FG_MAX_AGENTS) return fail(FG_ERR_UNSUPPORTED_N, "N must be in [1, 1024]%s");
+    if (!action_c || !comm_state) return fail(FG_ERR_BAD_ARG, "fg_update_comm_dim: a required pointer is NULL%s");
+    if (((uintptr_t)action_c & 3u) || ((uintptr_t)comm_state & 3u))
+        return fail(FG_ERR_ALIGNMENT, "action_c and comm_state must be 4-byte aligned%s");
+    const long long count = (long long)B * N * ((dim_c + 1) / 2);
+    hipLaunchKernelGGL(update_comm_dim_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       *params, B, N, dim_c, action_c, comm_state);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "comm launch failed: %s", hipGetErrorString(err));
     return FG_OK;

@@ -14,10 +14,10 @@ _PKG_ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libformation_hip.so")
 BUILD_SCRIPT = os.path.join(_PKG_ROOT, "csrc", "build.sh")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_WALLS = 4
 AGENT_PROPS = 8                 # floats per row of FgParams.agent_props: mass, size, accel, max_speed, u_noise, c_noise, flags, 0
-AGENT_IMMOVABLE, AGENT_NO_COLLIDE, AGENT_GHOST = 1, 2, 4         # the flags column
+AGENT_IMMOVABLE, AGENT_NO_COLLIDE, AGENT_GHOST, AGENT_SCRIPTED = 1, 2, 4, 8         # the flags column
 
 FG_OK = 0
 FG_ERR_BAD_ARG = -1
@@ -109,18 +109,23 @@ SIGNATURES = {
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
     "fg_step_hd_bytes": (ctypes.c_int64, [_I]),
     "fg_step_hd": (_I, [_PP, _I, _I] + [_P] * 16),
+    "fg_step_hd_plan": (_I, [_PP, _I, _I] + [_P] * 16 + [ctypes.POINTER(ctypes.c_void_p)]),
+    "fg_plan_launch": (_I, [_P, ctypes.c_uint64]),
+    "fg_plan_destroy": (_I, [_P]),
     "fg_physics_step": (_I, [_PP, _I, _I] + [_P] * 6),
     "fg_observe_hd": (_I, [_PP, _I, _I] + [_P] * 15),
     "fg_rollout_hd": (_I, [_PP, _I, _I, _I] + [_P] * 12 + [_I, _P]),
     "fg_reset_hd": (_I, [_PP, _I, _I] + [_P] * 9),
     "fg_reset_hd_mt": (_I, [_I, _I] + [_P] * 11),
     "fg_reset_hd_mt_done": (_I, [_I, _I, _I] + [_P] * 10 + [ctypes.c_int64, _P]),
+    "fg_reset_scenario_mt": (_I, [ctypes.POINTER(FgScenario), _I, _I, _P, _I] + [_P] * 10),
     "fg_step_basic": (_I, [_PP, _I, _I, _I, _I] + [_P] * 13),
     "fg_step_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14),
     "fg_reset_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I] + [_P] * 10),
     "fg_rollout_scenario": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I] + [_P] * 14 + [_I, _P]),
     "fg_decode_actions": (_I, [_I, ctypes.c_int64, _P, _P, _P]),
     "fg_update_comm": (_I, [_PP, _I, _I, _P, _P, _P]),
+    "fg_update_comm_dim": (_I, [_PP, _I, _I, _I, _P, _P, _P]),
     "fg_policy_bfs": (_I, [_I, _I, _I, _P, ctypes.c_int64, _P, _P]),
     "fg_policy_bfs_state": (_I, [_I, _I, _I] + [_P] * 6),
     "fg_rollout_hd_policy": (_I, [_PP, _I, _I, _I, _I] + [_P] * 12 + [_I, _P]),

@@ -318,9 +318,8 @@ class World(_Tracked):
     def ensure_comm(self):
         """(comm_c, action_c): the communication state / action tensors [B, N, dim_c], allocated on first use."""
         if self.comm_c is None:
-            if self.dim_c != 2:
-                raise NotImplementedError("communication of non-silent agents is built for dim_c = 2 (every scenario "
-                                          "file of the reference), got %d" % self.dim_c)
+            if self.dim_c < 1:
+                raise ValueError("non-silent agents need World.dim_c >= 1, got %d" % self.dim_c)
             f = dict(dtype=torch.float32, device=self.device)
             self.comm_c = torch.zeros((self.num_envs, len(self.agents), self.dim_c), **f)
             self.action_c = torch.zeros((self.num_envs, len(self.agents), self.dim_c), **f)
@@ -360,7 +359,8 @@ class World(_Tracked):
         flags: 1 = not movable, 2 = does not collide, 4 = ghost (core.py:54-58), 0 for the agents of every reference scenario."""
         def flags(a):
             return float((0 if a.movable else _native.AGENT_IMMOVABLE) | (0 if a.collide else _native.AGENT_NO_COLLIDE) |
-                         (_native.AGENT_GHOST if a.ghost else 0))
+                         (_native.AGENT_GHOST if a.ghost else 0) |
+                         (_native.AGENT_SCRIPTED if a.action_callback is not None else 0))
         rows = [(float(a.mass), float(a.size), float(a.accel or 0.0), float(a.max_speed or 0.0), float(a.u_noise or 0.0),
                  -1.0 if a.silent else float(a.c_noise or 0.0), flags(a), 0.0) for a in self.agents]
         alike = len({r[:5] + r[6:] for r in rows}) == 1 and rows[0][6] == 0.0      # any flag: the table (the scalars cannot say it)
@@ -392,14 +392,15 @@ class World(_Tracked):
         return (torch.stack((self.pos_x, self.pos_y), -1), torch.stack((self.vel_x, self.vel_y), -1))
 
     # ---- physics ------------------------------------------------------------
-    def native_params(self, sensitivity=5.0, collide_thresh=0.0, auto_reset=False, seed=0, rng_offset=0):
+    def native_params(self, sensitivity=5.0, collide_thresh=0.0, auto_reset=False, seed=0, rng_offset=0, scripted_ok=False):
         """FgParams for the C ABI from this world's constants (uniform agents)."""
         a0 = self.agents[0]
-        if self.scripted_agents:
-            # core.py:210-211 runs `agent.action = agent.action_callback(agent, self)` per env on the host before the physics:
-            # arbitrary Python per agent and env, which a batched device step cannot call.  No reference scenario has one.
-            raise NotImplementedError("scripted agents (Agent.action_callback, core.py:210-211) are not built: set the "
-                                      "agent's action.u yourself before World.step()")
+        if self.scripted_agents and not scripted_ok:
+            # core.py:210-211 runs `agent.action = agent.action_callback(agent, self)` inside World.step: `World.step()` here
+            # evaluates a BATCHED callback on device tensors (see `run_scripted_agents`).  The fused env.step / rollout
+            # launches compute rewards and observations for policy agents and have no place to call it between their steps.
+            raise NotImplementedError("scripted agents (Agent.action_callback, core.py:210-211) are driven through the World "
+                                      "API: World.step() calls the batched callback; env.step / rollout do not")
         # agents that differ in mass / size / accel / max_speed / u_noise (core.py:45-109): a per-agent table; the
         # scalars below then only carry agent 0's contact distance (the scale of collide_thresh) and the sensitivity
         # of agents without an accel of their own
@@ -453,7 +454,8 @@ class World(_Tracked):
         contact force, integration - one HIP launch.  `action_u` holds the RAW
         action; environment.py:216-221's sensitivity scaling happens in-kernel."""
         self.world_step += 1
-        p = self.native_params(sensitivity=sensitivity, rng_offset=self.world_step)   # motor noise: fresh draws every step
+        self.run_scripted_agents()                        # core.py:210-211
+        p = self.native_params(sensitivity=sensitivity, rng_offset=self.world_step, scripted_ok=True)   # motor noise: fresh draws every step
         lib = _native.load()
         _native.check(lib.fg_physics_step(
             p, self.num_envs, len(self.agents),
@@ -463,6 +465,21 @@ class World(_Tracked):
         if self.scenario is not None and hasattr(self.scenario, "_cache"):
             self.scenario._cache = None                   # per-agent callbacks must re-evaluate on the new state
 
+    def run_scripted_agents(self):
+        """core.py:210-211 `agent.action = agent.action_callback(agent, self)` for every scripted agent, BATCHED: the callback
+        is called once per step with the Agent (whose `state.p_pos / p_vel` are [B, 2] device tensors) and this World, and
+        returns the agent's action for all B envs - an object with `.u` (and optionally `.c`) or the `u` tensor itself,
+        [B, 2] or broadcastable.  The values are used as they are: the sensitivity scaling of environment.py:216-221 applies
+        to policy agents only (FG_AGENT_SCRIPTED in the agent's flags)."""
+        for agent in self.scripted_agents:
+            res = agent.action_callback(agent, self)
+            u = getattr(res, "u", res)
+            i = self.agents.index(agent)
+            self.action_u[:, i] = torch.as_tensor(u, dtype=torch.float32, device=self.device).expand(self.num_envs, 2)
+            c = getattr(res, "c", None)
+            if c is not None and res is not agent.action and not agent.silent:
+                agent.action.c = c
+
     def update_agent_state(self, seed=0):
         """core.py:221-222, 279-286 for every agent: `state.c` = zeros for a silent agent, `action.c` (+ c_noise) for
         the others - one launch (`fg_update_comm`); nothing to do while everybody is silent (`state.c` reads zeros)."""
@@ -471,9 +488,9 @@ class World(_Tracked):
                 self.comm_c.zero_()
             return
         comm, act = self.ensure_comm()
-        p = self.native_params(seed=seed, rng_offset=self.world_step)
+        p = self.native_params(seed=seed, rng_offset=self.world_step, scripted_ok=True)
         props = self.agent_props()
         if props is not None:
             p.agent_props = props.data_ptr()              # the c_noise / silent column matters here even for alike agents
-        _native.check(_native.load().fg_update_comm(p, self.num_envs, len(self.agents), act.data_ptr(), comm.data_ptr(),
-                                                    _native.current_stream(self.device)))
+        _native.check(_native.load().fg_update_comm_dim(p, self.num_envs, len(self.agents), int(self.dim_c), act.data_ptr(),
+                                                        comm.data_ptr(), _native.current_stream(self.device)))

@@ -185,19 +185,24 @@ class MultiAgentEnv(object):
         roll = getattr(self.scenario, "rollout_batch", None)
         if roll is None:
             raise NotImplementedError("%s has no multi-step launch; call step()" % type(self.scenario).__name__)
-        if self._action_mode():
-            raise NotImplementedError("rollout launches take raw continuous actions (discrete action modes: call step())")
         if self.post_step_callback is not None:
             raise NotImplementedError("post_step_callback runs on the host after every step; call step()")
-        if not torch.is_tensor(action_seq) or action_seq.dim() != 4 or tuple(action_seq.shape[1:]) != tuple(self._act.shape):
-            raise ValueError("action_seq must be a tensor of shape [K, %d, %d, 2]" % tuple(self._act.shape[:2]))
+        mode = self._action_mode()
+        if mode:
+            # the discrete action modes of _set_action (environment.py:194-215): the whole sequence is decoded to raw u in
+            # ONE launch (`fg_decode_actions` over K B N entries), then the K steps run as for continuous actions
+            act = self._decode_action_seq(action_seq, mode)
+            K = int(act.shape[0])
+        else:
+            if not torch.is_tensor(action_seq) or action_seq.dim() != 4 or tuple(action_seq.shape[1:]) != tuple(self._act.shape):
+                raise ValueError("action_seq must be a tensor of shape [K, %d, %d, 2]" % tuple(self._act.shape[:2]))
+            K = int(action_seq.shape[0])
+            act = action_seq
+            if act.dtype != torch.float32 or act.device != self._act.device or not act.is_contiguous():
+                act = act.to(device=self._act.device, dtype=torch.float32).contiguous()
         obs_every = int(obs_every)
-        K = int(action_seq.shape[0])
         if K < 1 or obs_every < 1:
             raise ValueError("need K >= 1 steps and obs_every >= 1")
-        act = action_seq
-        if act.dtype != torch.float32 or act.device != self._act.device or not act.is_contiguous():
-            act = act.to(device=self._act.device, dtype=torch.float32).contiguous()
         B, N = self.num_envs, self.num_agents
         D = self._out["obs"].shape[-1]
         if out is None:
@@ -523,6 +528,31 @@ class MultiAgentEnv(object):
         if self.force_discrete_action:
             return _native.FG_ACT_ARGMAX
         return 0
+
+    def _decode_action_seq(self, action_seq, mode):
+        """A K-step sequence in one of the discrete action modes -> raw u [K, B, N, 2] (a staging tensor of the env, re-used
+        while K stays the same).  Shapes per mode as in `step`: [K,B,N,5] floats (one-hot-5 logits), [K,B,N] indices,
+        [K,B,N,2] floats (force_discrete_action: the caller's array is rewritten as the one-hot, environment.py:213-215)."""
+        B, N = self.num_envs, self.num_agents
+        dev = self.world.device
+        tail, dtype = {_native.FG_ACT_ONEHOT5: ((B, N, 5), torch.float32),
+                       _native.FG_ACT_INDEX: ((B, N), torch.int32),
+                       _native.FG_ACT_ARGMAX: ((B, N, 2), torch.float32)}[mode]
+        if not torch.is_tensor(action_seq) or tuple(action_seq.shape[1:]) != tail or action_seq.dim() != len(tail) + 1:
+            raise ValueError("action_seq must be a tensor of shape [K%s] in this action mode" % "".join(", %d" % d for d in tail))
+        K = int(action_seq.shape[0])
+        src = action_seq
+        if src.dtype != dtype or src.device != dev or not src.is_contiguous():
+            src = src.to(device=dev, dtype=dtype).contiguous()
+        stage = getattr(self, "_act_seq_stage", None)
+        if stage is None or stage.shape[0] != K:
+            stage = self._act_seq_stage = torch.empty((K, B, N, 2), dtype=torch.float32, device=dev)
+        if K:
+            _native.check(_native.load().fg_decode_actions(mode, K * B * N, src.data_ptr(), stage.data_ptr(),
+                                                           _native.current_stream(dev)))
+        if mode == _native.FG_ACT_ARGMAX and src is not action_seq:
+            action_seq.copy_(src)                      # the reference overwrites the caller's array (:213-215)
+        return stage
 
     def _decode_actions(self, action_n, mode, batched):
         """Non-default action modes: stage the caller's actions on the device ([B,N,5] floats,

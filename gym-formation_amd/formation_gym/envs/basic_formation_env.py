@@ -12,9 +12,10 @@ import torch
 from formation_gym import _native
 from formation_gym.core import World, Agent, Landmark
 from formation_gym.scenario import BaseScenario
+from formation_gym.landmark_scenario import MtResetMixin
 
 
-class Scenario(BaseScenario):
+class Scenario(MtResetMixin, BaseScenario):
     def make_world(self, num_agents=3, num_landmarks=3, num_envs=1, device=None):
         world = World(num_envs=num_envs, device=device)      # world_length = 50 (core.py:113)
         world.dim_c = 2

@@ -7,12 +7,30 @@ generate_shape).  The arithmetic of observation (:38-59), reward (:61-75) and
 the env shell's done (environment.py:172-178) runs inside the fused HIP kernel
 `fg_step_hd`; the per-agent callbacks return that agent's slice.
 """
+import ctypes
+
 import numpy as np
 import torch
 
 from formation_gym import _native, placement
 from formation_gym.core import World, Agent, Landmark
 from formation_gym.scenario import BaseScenario
+
+
+class _Plan(object):
+    """Owner of a library-side launch plan (fg_step_hd_plan): keeps the tensors whose addresses the plan holds alive and
+    frees the plan with the last reference to the bound launcher."""
+
+    def __init__(self, lib, handle, keep):
+        self.lib, self.handle, self.keep = lib, handle, keep
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.fg_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:                 # noqa: BLE001 - interpreter shutdown
+            pass
 
 
 class Scenario(BaseScenario):
@@ -103,13 +121,16 @@ class Scenario(BaseScenario):
     def obs_dim(self, world):
         return 6 * len(world.agents)
 
-    def params(self, world, auto_reset=False, rng_offset=0, obs=None):
+    def params(self, world, auto_reset=False, rng_offset=0, obs=None, scripted_ok=False):
         a0 = world.agents[0]
         p = world.native_params(collide_thresh=(a0.size + a0.size) / 2,   # :121
-                                auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset)
+                                auto_reset=auto_reset, seed=self._seed, rng_offset=rng_offset, scripted_ok=scripted_ok)
         p.obs_env_pitch = self.obs_env_pitch(obs, len(world.agents))
         p.env_index_base = int(getattr(self, "env_base", 0))
         if world.any_non_silent():                        # :48-51 the communication block carries the others' state.c
+            if world.dim_c != 2:
+                raise NotImplementedError("formation_hd_env's observation has a communication block of dim_c = 2 (:40, :48-51); "
+                                          "World.step / update_agent_state take any dim_c")
             p.comm_state = world.ensure_comm()[0].data_ptr()
         if obs is not None and obs.numel() and placement.is_placed(obs.data_ptr()):
             p.obs_placed = 1                              # a buffer of chunks spread over the device memory: more writer waves pay
@@ -166,22 +187,26 @@ class Scenario(BaseScenario):
                 out["obs"].data_ptr(), out["reward"].data_ptr(), _native.ptr(out.get("indiv")),
                 _native.ptr(out.get("done")), _native.ptr(out.get("near_lm")), _native.ptr(out.get("near_ag")),
                 _native.ptr(out.get("hd_idx")), _native.current_stream(world.device))
-        fn = lib.fg_step_hd
-        keep = (act, out)
+        # the checked launch description is kept by the library (fg_step_hd_plan): a step is a two-argument call
+        handle = ctypes.c_void_p()
+        _native.check(lib.fg_step_hd_plan(p, *args, ctypes.byref(handle)))
+        plan = _Plan(lib, handle, (act, out, p, world.pos_x, world.pos_y, world.vel_x, world.vel_y, self.ideal_shape,
+                                   self.ideal_vel, world.step_count))
+        fn = lib.fg_plan_launch
+        raw = plan.handle
 
         def launch(rng_offset=0):
-            p.rng_offset = rng_offset
-            rc = fn(p, *args)
+            rc = fn(raw, rng_offset)
             if rc:
                 _native.check(rc)
-            return keep
+            return plan
         self._cache = None
         return launch
 
     def observe_batch(self, world, out):
         lib = _native.load()
-        _native.check(lib.fg_observe_hd(
-            self.params(world, obs=out.get("obs")), world.num_envs, len(world.agents),
+        _native.check(lib.fg_observe_hd(                      # (no action involved: a World with scripted agents may be observed)
+            self.params(world, obs=out.get("obs"), scripted_ok=True), world.num_envs, len(world.agents),
             world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(), world.vel_y.data_ptr(),
             self.ideal_shape.data_ptr(), self.ideal_vel.data_ptr(), world.step_count.data_ptr(),
             _native.ptr(out.get("obs")), _native.ptr(out.get("reward")), _native.ptr(out.get("indiv")),

@@ -12,7 +12,64 @@ from formation_gym.core import World, Agent, Landmark
 from formation_gym.scenario import BaseScenario
 
 
-class LandmarkScenario(BaseScenario):
+class MtResetMixin(object):
+    """`reset_mode='device_mt'` for the scenarios with landmarks: each env's legacy MT19937 stream (RandomState(seed + 1000 g),
+    at its current position) continued on the GPU by `fg_reset_scenario_mt` - the draws of the host `reset_world`, bit for bit
+    (basic_formation_env.py:54-65, formation_hd_partial_env.py:88-99, formation_hd_partial_range_env.py:76-87,
+    formation_hd_obs_env.py:101-120).  The using class supplies `_streams(B)` and, for obstacles, `descriptor()`."""
+    _mt_state = None
+
+    def _mt_descriptor(self, world):
+        if hasattr(self, "descriptor"):
+            return self.descriptor()
+        return _native.FgScenario(kind=_native.FG_SCN_BASIC, num_landmarks=len(world.landmarks), num_obstacles=0)
+
+    def upload_mt_streams(self, world):
+        B = world.num_envs
+        st = np.zeros((B, 626), dtype=np.uint32)
+        for b, rs in enumerate(self._streams(B)):
+            _, key, pos = rs.get_state()[:3]
+            st[b, :624] = key
+            st[b, 624] = pos
+        self._mt_state = torch.as_tensor(st.view(np.int32)).to(world.device)
+        return self._mt_state
+
+    def _mt_args(self, world, mask, world_length):
+        if self._mt_state is None or self._mt_state.shape[0] != world.num_envs:
+            self.upload_mt_streams(world)
+        return (self._mt_descriptor(world), world.num_envs, len(world.agents), _native.ptr(mask), int(world_length),
+                self._mt_state.data_ptr(), world.pos_x.data_ptr(), world.pos_y.data_ptr(), world.vel_x.data_ptr(),
+                world.vel_y.data_ptr(), world.landmark_pos.data_ptr(), world.obstacle_pos.data_ptr(),
+                world.obstacle_vel.data_ptr(), world.step_count.data_ptr(), _native.current_stream(world.device))
+
+    def reset_mt(self, world, mask=None):
+        """Scenario.reset_world on the GPU for the masked envs (mask None: every env)."""
+        _native.check(_native.load().fg_reset_scenario_mt(*self._mt_args(world, mask, 0)))
+        self._cache = None
+
+    def bind_reset_mt_done(self, world, obs=None):
+        """The vec-env worker's `if all(done): ob = env.reset()` (env_wrappers.py:14-18) decided on the device: envs whose step
+        counter has reached world_length restart from their own streams; with `obs` the observation tensor is then brought up
+        to date for the whole batch (one more launch: unchanged envs get the bits they had)."""
+        lib = _native.load()
+        args = self._mt_args(world, None, int(world.world_length))
+        keep = (self._mt_state, obs)
+
+        def launch():
+            rc = lib.fg_reset_scenario_mt(*args)
+            if rc:
+                _native.check(rc)
+            self._cache = None
+            if obs is not None:
+                self.observe_batch(world, {"obs": obs})
+            return keep
+        return launch
+
+    def reset_mt_done(self, world, obs=None):
+        self.bind_reset_mt_done(world, obs)()
+
+
+class LandmarkScenario(MtResetMixin, BaseScenario):
     KIND = None                    # _native.FG_SCN_*
     AGENT_SIZE = 0.04
     LANDMARK_SIZE = 0.02

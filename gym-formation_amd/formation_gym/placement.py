@@ -302,32 +302,39 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
                 arena.kept_range = (0, 0)
                 arena.unmap(addr)
 
-        def spread_selection(t):
+        def time_window(base, start, r):                             # W chunks of a whole-arena mapping, from position `start`
+            addr = base + start * chunk
+            arena.kept_range = (addr, addr + W * chunk)                  # a spread candidate is timed as what it will be
+            try:
+                flat = arena.floats(addr, nfloats)
+                try:
+                    return _time_launch(time_fn, flat, stream, r)
+                except Exception as exc:                             # noqa: BLE001 - the CALLER's launch failed: not a placement problem
+                    raise _LaunchError(exc) from exc
+            finally:
+                flat = None
+                stream.synchronize()
+                arena.kept_range = (0, 0)
+
+        def arena_orders(t):
             # What makes a selection fast (profiles/r03_place/selection_rules_*.txt): chunks that are CONSECUTIVE in the
             # buffer must lie far apart in memory (>= 8-20 GB) - two clusters at the ends of the arena written one after the
-            # other run like neighbours, the same clusters taken alternately run like the best spread.  Three families:
-            if t % 3 == 2:
-                R = 3 + (t // 3) % 3                                  # R regions of the arena taken round-robin
-                per = -(-W // R)
-                if n // R >= per:
-                    starts = [r * (n // R) + rnd.randrange(n // R - per + 1) for r in range(R)]
-                    return "regions round-robin (%d)" % R, [starts[k % R] + k // R for k in range(W)]
-            idx = sorted({min(n - 1, int((j + rnd.random()) * n / W)) for j in range(W)})
-            while len(idx) < W:                                       # strata narrower than a chunk can collide
-                c = rnd.randrange(n)
-                if c not in idx:
-                    idx.append(c)
-            idx.sort()
-            if t % 2 == 0:
-                rnd.shuffle(idx)                                      # strata in random order
-                return "spread, shuffled", idx
-            # strata in a golden-ratio stride order: consecutive chunks of the buffer (the slabs of consecutive steps) always
-            # come from far-apart parts of the arena, and so do chunks two and three apart
-            g = max(1, int(round(W * 0.6180339887)))
-            while math.gcd(g, W) != 1:
+            # other run like neighbours, the same clusters taken alternately run like the best spread.  Three orders of ALL the
+            # arena's chunks in which EVERY window of W consecutive positions has that property; the candidates are windows
+            # of one mapping per order (round 4 made one mapping per candidate and retired 65 x the buffer of address space per
+            # probe instead of 3 x the arena):
+            g = max(1, int(round(n * 0.6180339887)))
+            while math.gcd(g, n) != 1:
                 g += 1
-            off = rnd.randrange(W)
-            return "spread, golden stride", [idx[(off + k * g) % W] for k in range(W)]
+            off = rnd.randrange(n)
+            yield "spread, golden stride", [(off + k * g) % n for k in range(n)]   # neighbours of the buffer 0.62 arenas apart
+            R = 3 + (t % 3)                                           # R regions of the arena taken round-robin
+            per = n // R
+            order = [(k % R) * per + k // R for k in range(R * per)] + list(range(R * per, n))
+            yield "regions round-robin (%d)" % R, order
+            order = list(range(n))
+            rnd.shuffle(order)
+            yield "spread, shuffled", order
 
         first = list(range(W))
         t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
@@ -352,10 +359,17 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
         # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
         # and its selections differ by 1 %)
         count = int(max(int(trials), min(8 * int(trials), budget_s / max(1e-6, (reps_c + 1) * ms[0] * 1e-3 + 4e-3))))
-        for t in range(count):
-            kind, idx = spread_selection(t)
-            cands.append((kind, idx))
-            ms.append(timed(idx, reps_c, True))
+        per_order = -(-count // 3)
+        for kind, order in arena_orders(seed):
+            last = n - W                                             # last window start
+            starts = sorted({int(round(j * last / max(1, per_order - 1))) for j in range(per_order)}) if last > 0 else [0]
+            base = arena.map(order)                                  # every chunk of the arena, once per order
+            try:
+                for st in starts:
+                    cands.append((kind, order[st:st + W]))
+                    ms.append(time_window(base, st, reps_c))
+            finally:
+                arena.unmap(base)
         finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
         final = {i: timed(cands[i][1], 2 * reps_c + 1, i > 0) for i in finalists}
         for i, v in final.items():

@@ -14,7 +14,7 @@ class FormationVecEnv(object):
     def __init__(self, env, reset_mode="device", numpy=False, infos="dict"):
         """reset_mode:
           'device'    counter RNG inside the fused step launch (fastest; distributional parity); every scenario in envs/
-          'device_mt' (formation_hd_env) the reference's own MT19937 streams continued on the GPU (bit-exact resets,
+          'device_mt' (every built-in scenario) the reference's own MT19937 streams continued on the GPU (bit-exact resets,
                       no host round trip: the host mirrors the step counters, which are deterministic)
           'host'      the reference's streams on the host (bit-exact; needs a device->host sync)
         numpy=True: `reset` / `step` return what the reference's vec envs return (env_wrappers.py:68-72, :113-122): NumPy float64

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define FG_ABI_VERSION 7
+#define FG_ABI_VERSION 8
 #define FG_MAX_AGENTS 1024
 #define FG_MAX_WALLS 4
 
@@ -157,6 +157,8 @@ typedef struct FgParams {
 #define FG_AGENT_IMMOVABLE 1
 #define FG_AGENT_NO_COLLIDE 2
 #define FG_AGENT_GHOST 4
+#define FG_AGENT_SCRIPTED 8   /* the action of this agent is a scripted agent's `action.u` (Agent.action_callback, core.py:210-211):
+                                 taken as it is - environment.py:216-221's sensitivity scaling applies to policy agents only */
 
 /* Landmark scenarios with few agents (fg_step_scenario).  Field -> reference source:
  *   kind            which Scenario file under formation_gym/envs/
@@ -252,6 +254,20 @@ int fg_step_hd(const FgParams* params, int B, int N,
                float* obs, float* reward, float* indiv_reward, uint8_t* done,
                int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream);
 
+/* The same step as a PLAN: fg_step_hd_plan checks the arguments once and keeps the launch description (the pointers are the
+ * caller's and must stay valid while the plan lives - like fg_arena_*, a declared exception to "keeps no pointer");
+ * fg_plan_launch(plan, rng_offset) enqueues one step on the plan's stream with FgParams.rng_offset = rng_offset and nothing
+ * else changed; fg_plan_destroy frees the description.  For step loops that re-use their buffers (MultiAgentEnv.step called
+ * per step, environment.py:113-142, test.py:17-28): the per-step host work is a two-argument call plus the kernel launch.
+ * Results equal fg_step_hd's bit for bit (the same dispatch). */
+int fg_step_hd_plan(const FgParams* params, int B, int N,
+                    float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                    const float* act, float* ideal_shape, float* ideal_vel, int32_t* step,
+                    float* obs, float* reward, float* indiv_reward, uint8_t* done,
+                    int32_t* near_lm, int32_t* near_ag, int32_t* hd_idx, void* stream, void** plan);
+int fg_plan_launch(void* plan, uint64_t rng_offset);
+int fg_plan_destroy(void* plan);
+
 /* World.step only (core.py:206-225) incl. the action scaling of
  * environment.py:216-221; for per-stage parity tests.  Updates pos/vel in place. */
 int fg_physics_step(const FgParams* params, int B, int N,
@@ -304,11 +320,25 @@ int fg_reset_hd_mt_done(int B, int N, int world_length, uint32_t* mt_state,
                         float* ideal_shape, float* ideal_vel, float* landmark_pos, int32_t* step,
                         float* obs, int64_t obs_env_pitch, void* stream);
 
+/* Scenario.reset_world of the landmark scenarios (basic_formation_env.py:54-65, formation_hd_partial_env.py:88-99,
+ * formation_hd_partial_range_env.py:76-87, formation_hd_obs_env.py:101-120) continued on the device from each env's own legacy
+ * NumPy MT19937 stream (mt_state uint32 [B][626] as for fg_reset_hd_mt): N agent positions, num_landmarks landmark positions,
+ * num_obstacles obstacles from uniform([s_k, 2.0], [s_k+1, 2.5]) with the scenario's obstacle velocity - bit-exact with the
+ * reference's draws.  Which envs: mask bytes (mask != NULL), every env (mask NULL, world_length <= 0), or the vec-env
+ * worker's rule step[b] >= world_length (mask NULL, world_length > 0; env_wrappers.py:14-18). */
+int fg_reset_scenario_mt(const FgScenario* scenario, int B, int N, const uint8_t* mask, int world_length, uint32_t* mt_state,
+                         float* pos_x, float* pos_y, float* vel_x, float* vel_y,
+                         float* landmarks, float* obst_pos, float* obst_vel, int32_t* step, void* stream);
+
 /* World.update_agent_state (core.py:279-286) for all B x N agents: state.c = action.c + c_noise * N(0,1) for a
  * non-silent agent, zeros for a silent one (agent_props[i][5] < 0; without a table every agent is non-silent and
  * noise-free).  dim_c = 2.  action_c, comm_state float [B][N][2]; the noise comes from the device counter RNG
  * (seed, env_index_base + b, agent, rng_offset: distributional parity, the reference draws np.random.randn). */
 int fg_update_comm(const FgParams* params, int B, int N, const float* action_c, float* comm_state, void* stream);
+/* The same for any World.dim_c (core.py:279-286 takes whatever the World says): action_c, comm_state float [B][N][dim_c].
+ * dim_c = 2 is fg_update_comm itself; the fused formation_hd_env kernels read a communication block of dim_c = 2 only
+ * (FgParams.comm_state), other widths serve the World API (World.step / update_agent_state). */
+int fg_update_comm_dim(const FgParams* params, int B, int N, int dim_c, const float* action_c, float* comm_state, void* stream);
 
 /* MultiAgentEnv.step for basic_formation_env (BASELINE config 1):
  * same physics; observation basic_formation_env.py:29-41, reward :43-52.

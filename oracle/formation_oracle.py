@@ -164,7 +164,7 @@ def wall_force(pos, size, wall, P, dtype=np.float64, ghost=None):
 
 
 def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None, walls=None, mass=None, size=None,
-                 movable=None, collide=None, ghost=None):
+                 movable=None, collide=None, ghost=None, scripted=None):
     """World.step for agent-only colliders (core.py:206-322 with the early-outs
     of :292-297 applied: landmarks have collide=False, so only agent-agent
     pairs survive).  pos, vel, act: [B,N,2].  Returns new (pos, vel).
@@ -178,6 +178,8 @@ def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None,
     movable / collide / ghost: per-agent booleans [N] (core.py:54-58): a pair needs both to collide and one to move
     (:292-295); against an immovable partner the force is not scaled by the mass ratio (:319-321); an immovable agent
     takes no action force (:231) and is not integrated (:266-267); a ghost passes through soft walls (:326-327).
+    scripted: per-agent booleans [N]: `act` of such an agent is a scripted agent's `action.u` (core.py:210-211), used as it
+    is - the sensitivity of environment.py:216-221 scales policy agents' actions only.
     """
     pos = np.asarray(pos, dtype=dtype); vel = np.asarray(vel, dtype=dtype)
     act = np.asarray(act, dtype=dtype)
@@ -187,6 +189,8 @@ def physics_step(pos, vel, act, P, dtype=np.float64, max_speed=None, accel=None,
     acc = np.full(N, np.nan) if accel is None else np.broadcast_to(np.asarray(accel, dtype=np.float64), (N,))
     has_acc = ~np.isnan(acc)
     sens = np.where(has_acc, acc, P.sensitivity).astype(dtype)           # environment.py:218-220
+    if scripted is not None:
+        sens = np.where(np.asarray(scripted, dtype=bool), dtype(1), sens)   # core.py:210-211, 235-236
     gain = np.where(has_acc, m * np.where(has_acc, acc, 1.0), m).astype(dtype)   # core.py:236
     F = gain[None, :, None] * (sens[None, :, None] * act)
     delta = pos[:, :, None, :] - pos[:, None, :, :]            # [B,i,j,2] = p_i - p_j

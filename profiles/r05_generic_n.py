@@ -12,6 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gym-formation_amd")]
 import torch                                              # noqa: E402
 import formation_gym                                      # noqa: E402
+from formation_gym import _native                         # noqa: E402
+
+if os.environ.get("FG_EXPERIMENT_LIB"):                   # A/B runs of experiment builds
+    _native.LIB_PATH = os.path.abspath(os.environ["FG_EXPERIMENT_LIB"])
 
 dev = "cuda:0"
 K = 20

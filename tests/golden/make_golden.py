@@ -251,6 +251,56 @@ def immovable_fixture(fg, N, T, seed, act_seed, crowd):
     return res
 
 
+def scripted_u(p_own, v_own, p_lead):
+    """The deterministic scripted agent of fixture hd_n6_scripted: orbit the origin, damp, lean towards agent 0.  Written
+    with + - * only, on the last axis, so that tests/test_gpu_hetero_comm.py can evaluate the SAME function on [B, 2] tensors."""
+    return 0.6 * np.stack([-p_own[..., 1], p_own[..., 0]], -1) - 0.3 * v_own + 0.2 * (p_lead - p_own)
+
+
+def scripted_fixture(fg, N, T, seed, act_seed, crowd):
+    """Scripted agents (Agent.action_callback, core.py:152-158, 210-211): World.step calls the callback and uses its action.u
+    as it is; the other agents get 5 x the raw action as _set_action would give them.  Driven through core.py's own API."""
+    core = sys.modules[type(fg.make_env("formation_hd_env", False, 3).world).__module__]
+    env = fg.make_env("formation_hd_env", False, N)
+    sc = _scenario_of(env)
+    world = env.world
+    scripted = np.zeros(N, dtype=bool); scripted[[2, N - 1]] = True
+    mass = np.random.RandomState(seed).uniform(0.5, 2.0, N)
+
+    def callback(agent, w):
+        act = core.Action()
+        act.u = scripted_u(agent.state.p_pos, agent.state.p_vel, w.agents[0].state.p_pos)
+        act.c = np.zeros(w.dim_c)
+        return act
+    for a, s_, m_ in zip(world.agents, scripted, mass):
+        a.initial_mass = float(m_)
+        if s_:
+            a.action_callback = callback
+    assert len(world.scripted_agents) == 2 and len(world.policy_agents) == N - 2
+    env.seed(seed)
+    env.reset()
+    for a in world.agents:
+        a.state.p_pos = a.state.p_pos * crowd
+    p0, v0 = _state(env)
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, N, 2)).astype(np.float32)
+    rec = {k: [] for k in ("pos", "vel", "obs", "indiv", "u_scripted")}
+    for t in range(T):
+        for i, a in enumerate(world.agents):
+            if not scripted[i]:
+                a.action.u = 5.0 * acts[t, i].astype(np.float64)     # what _set_action does for a policy agent (environment.py:216-221)
+        world.step()
+        p, v = _state(env)
+        rec["pos"].append(p); rec["vel"].append(v)
+        rec["u_scripted"].append(np.array([a.action.u for a in world.scripted_agents], dtype=np.float64))
+        rec["obs"].append(np.array([sc.observation(a, world) for a in world.agents], dtype=np.float64))
+        rec["indiv"].append(np.array([sc.reward(a, world) for a in world.agents], dtype=np.float64))
+    res = {k: np.array(v) for k, v in rec.items()}
+    res.update(pos0=p0, vel0=v0, acts=acts, scripted=scripted, mass=mass,
+               ideal_shape=np.array(sc.ideal_shape, dtype=np.float64), ideal_vel=np.array(sc.ideal_vel, dtype=np.float64),
+               seed=np.array(seed))
+    return res
+
+
 def hetero_options(N, seed):
     """Per-agent properties no reference scenario sets: mass 0.5 ... 3, size 0.02 ... 0.09, a third of the agents with
     their own accel, a third with a max_speed (NaN = None)."""
@@ -657,6 +707,8 @@ def main():
                                                         flags=dict(collide=np.arange(9) % 4 != 2, ghost=np.arange(9) % 3 == 1))))
     # an immovable agent, driven through the World API (env.step asserts on it)
     save("hd_n6_immovable", lambda: immovable_fixture(fg, 6, 12, seed=107, act_seed=108, crowd=0.2))
+    # scripted agents (Agent.action_callback), driven through the World API
+    save("hd_n6_scripted", lambda: scripted_fixture(fg, 6, 12, seed=109, act_seed=110, crowd=0.25))
     # non-silent agents: World.step + Scenario.observation with state.c in the communication block
     save("hd_n5_comm", lambda: comm_fixture(fg, 5, 10, seed=99, act_seed=100, crowd=0.3))
     save("hd_n3_done", lambda: rollout_hd(fg, 3, 1, 102, seed=9, act_seed=19, obs_at=[100]))

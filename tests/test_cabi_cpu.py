@@ -40,8 +40,8 @@ def test_abi_version_and_struct_layout(lib, tmp_path):
     """The ctypes mirrors must have the C layout: compile the header with gcc and compare
     sizeof / offsetof of every field."""
     import subprocess
-    assert lib.fg_abi_version() == _native.ABI_VERSION == 7
-    assert "#define FG_ABI_VERSION 7" in open(HEADER).read()
+    assert lib.fg_abi_version() == _native.ABI_VERSION == 8
+    assert "#define FG_ABI_VERSION 8" in open(HEADER).read()
     structs = {"FgParams": _native.FgParams, "FgScenario": _native.FgScenario, "FgWall": _native.FgWall}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "formation_hip.h"', 'int main(void){']
     for name, cls in structs.items():

@@ -278,6 +278,61 @@ def test_immovable_agent_through_the_world_api(golden):
     assert np.abs(g["vel"][:, frozen] - g["vel0"][frozen]).max() == 0       # (the reference leaves its velocity alone too)
 
 
+def test_scripted_agents_through_the_world_api(golden):
+    """Scripted agents (Agent.action_callback, core.py:152-158, 210-211) through World.step: the callback is BATCHED - called
+    once per step with the Agent (state.p_pos / p_vel are [B, 2] device tensors) and the World, returning the action of all B
+    envs - and its `u` is used as it is (no sensitivity: FG_AGENT_SCRIPTED); the policy agents' raw actions get the x5 of
+    _set_action in-kernel.  Fixture hd_n6_scripted: the same callback run by the reference's core.py, one env; here the env is
+    replicated so that the batched contract is exercised.  env.step refuses (the fused launch has nowhere to call back)."""
+    import formation_gym
+    g = golden("hd_n6_scripted")
+    T, N = g["acts"].shape[:2]
+    B = 5
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    world, sc = env.world, env.scenario
+    calls = []
+
+    def callback(agent, w):                                   # tests/golden/make_golden.py scripted_u on [B, 2] tensors
+        p, v, lead = agent.state.p_pos, agent.state.p_vel, w.agents[0].state.p_pos
+        calls.append(tuple(p.shape))
+        act = formation_gym.core.Action()
+        act.u = 0.6 * torch.stack((-p[..., 1], p[..., 0]), -1) - 0.3 * v + 0.2 * (lead - p)
+        return act
+    for a, s_, m in zip(world.agents, g["scripted"], g["mass"]):
+        a.initial_mass = float(m)
+        if s_:
+            a.action_callback = callback
+    assert len(world.scripted_agents) == 2 and len(world.policy_agents) == N - 2
+    with pytest.raises(NotImplementedError):
+        env.step(torch.zeros((B, N, 2), device="cuda"))
+    rep = lambda x: np.repeat(np.asarray(x)[None], B, 0)
+    prev_pos, prev_vel = g["pos0"], g["vel0"]
+    for t in range(T):                                        # teacher-forced per step, 1e-5
+        _load(env, rep(prev_pos), rep(prev_vel), rep(g["ideal_shape"]), rep(g["ideal_vel"]), np.zeros(B))
+        for i, a in enumerate(world.agents):
+            if not g["scripted"][i]:
+                a.action.u = torch.as_tensor(g["acts"][t, i])[None].expand(B, 2)     # RAW action
+        world.step()
+        pos, vel = world.get_state()
+        for b in (0, B - 1):
+            np.testing.assert_allclose(_np(pos)[b], g["pos"][t], rtol=0, atol=ATOL)
+            np.testing.assert_allclose(_np(vel)[b], g["vel"][t], rtol=0, atol=ATOL)
+        u = _np(world.action_u)[0][g["scripted"]]
+        np.testing.assert_allclose(u, g["u_scripted"][t], rtol=0, atol=ATOL)
+        obs = np.stack([_np(sc.observation(a, world))[0] for a in world.agents])
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=0, atol=ATOL)
+        prev_pos, prev_vel = g["pos"][t], g["vel"][t]
+    assert calls == [(B, 2)] * (2 * T)                        # once per scripted agent and step, on batched views
+    # free-running over the fixture's horizon stays inside 1e-4 (fp32 trajectory)
+    _load(env, rep(g["pos0"]), rep(g["vel0"]), rep(g["ideal_shape"]), rep(g["ideal_vel"]), np.zeros(B))
+    for t in range(T):
+        for i, a in enumerate(world.agents):
+            if not g["scripted"][i]:
+                a.action.u = torch.as_tensor(g["acts"][t, i])[None].expand(B, 2)
+        world.step()
+    np.testing.assert_allclose(_np(world.get_state()[0])[0], g["pos"][-1], rtol=0, atol=1e-4)
+
+
 @pytest.mark.parametrize("N,B", [(5, 60), (27, 33), (70, 7), (130, 4)])
 def test_random_entity_flags_against_oracle(N, B):
     """Random movable / collide / ghost flags with soft and hard walls over lane-group and whole-workgroup agent counts:
@@ -330,3 +385,38 @@ def test_landmark_scenarios_refuse_flagged_agents(name):
             env.step(act)
         setattr(env.world.agents[1], attr, not val)
     env.step(act)
+
+
+@pytest.mark.parametrize("dim_c", [1, 3, 5])
+def test_update_agent_state_with_other_comm_widths(dim_c):
+    """World.update_agent_state (core.py:279-286) for dim_c != 2: state.c = action.c for non-silent agents (+ c_noise N(0,1)),
+    zeros for silent ones - `fg_update_comm_dim`; pair 0 of the noise equals what dim_c = 2 draws."""
+    B, N = 7, 6
+    env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device="cuda:0")
+    world = env.world
+    world.dim_c = dim_c
+    for i, a in enumerate(world.agents):
+        a.silent = i % 3 == 0
+        a.c_noise = None
+    gen = torch.Generator(device="cuda"); gen.manual_seed(dim_c)
+    want = torch.rand((B, N, dim_c), device="cuda", generator=gen)
+    for i, a in enumerate(world.agents):
+        if not a.silent:
+            a.action.c = want[:, i]
+    world.update_agent_state()
+    for i, a in enumerate(world.agents):
+        got = a.state.c
+        assert tuple(got.shape) == (B, dim_c)
+        assert torch.equal(got, torch.zeros_like(got) if a.silent else want[:, i])
+    # with noise: deterministic per (seed, step), about N(0, c_noise^2) around the action, silent agents still zero
+    for a in world.agents:
+        a.c_noise = 0.5
+    world.update_agent_state(seed=3)
+    c1 = world.comm_c.clone()
+    world.update_agent_state(seed=3)
+    assert torch.equal(c1, world.comm_c)
+    talk = [i for i, a in enumerate(world.agents) if not a.silent]
+    d = (c1[:, talk] - want[:, talk]).flatten()
+    assert 0.2 < float(d.std()) < 0.9 and float(d.abs().max()) < 3.0 and float(c1[:, [0, 3]].abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        env.scenario.params(world)                        # the fused kernels' communication block is dim_c = 2

@@ -1178,6 +1178,46 @@ def test_action_modes_match_reference_fixtures(golden, name, mode):
             np.testing.assert_array_equal(_np(act)[0] * 5.0, g["acts_after"][t])   # one-hot written back
 
 
+@pytest.mark.parametrize("mode", ["onehot5", "index", "argmax"])
+def test_rollout_launch_in_the_discrete_action_modes(mode):
+    """env.rollout(action_seq) in the non-default branches of _set_action (environment.py:194-215): the sequence is decoded to
+    raw u in one launch, then K steps run in one launch - bit-identical to K env.step calls in the same mode."""
+    import formation_gym
+    N, B, K = 9, 300, 6
+
+    def build():
+        sc = formation_gym.load_scenario("formation_hd_env")
+        world = sc.make_world(N, num_envs=B, device="cuda:0")
+        if mode == "argmax":
+            world.discrete_action = True
+        env = formation_gym.MultiAgentEnv(world, sc.reset_world, sc.reward, sc.observation, discrete_action=(mode == "onehot5"))
+        env.discrete_action_input = mode == "index"
+        env.seed(3); env.reset()
+        env.world.pos_x.mul_(0.3); env.world.pos_y.mul_(0.3)
+        return env
+    a, b = build(), build()
+    gen = torch.Generator(device="cuda"); gen.manual_seed(7)
+    if mode == "onehot5":
+        seq = torch.rand((K, B, N, 5), device="cuda", generator=gen)
+    elif mode == "index":
+        seq = torch.randint(0, 5, (K, B, N), device="cuda", generator=gen, dtype=torch.int32)
+    else:
+        seq = torch.rand((K, B, N, 2), device="cuda", generator=gen) * 2 - 1
+    seq_b = seq.clone()
+    obs_seq, rew_seq, done_seq, info_seq = b.rollout(seq_b, out=False)
+    for k in range(K):
+        obs, rew, done, info = a.step(seq[k])
+        assert torch.equal(obs, obs_seq[k]) and torch.equal(rew, rew_seq[k]) and torch.equal(done, done_seq[k])
+        assert torch.equal(info["individual_reward"], info_seq["individual_reward"][k])
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    if mode == "argmax":
+        assert torch.equal(seq, seq_b)                   # both rewrote the caller's array as the one-hot (:213-215)
+        assert set(np.unique(seq_b.cpu().numpy()).tolist()) <= {0.0, 1.0}
+    with pytest.raises(ValueError):
+        b.rollout(torch.zeros((K, B, N, 3), device="cuda"))
+
+
 @pytest.mark.parametrize("N,B", [(81, 2048), (243, 8192), (243, 4099), (81, 16387)])     # 4099, 16387: the smallest batches of the pipelined single-step launch, ragged
 def test_baseline_full_size_per_gpu_properties(N, B):
     """BASELINE configs 3 and 4 at their per-GPU batch (81 x 2048, 243 x 8192): size-independent

@@ -325,3 +325,58 @@ def test_scenario_shards_reproduce_the_global_batch_across_resets(scenario, kind
         for s, t in zip(_state(whole), _state(e)):
             assert torch.equal(s[l:h], t)
     assert saw_done
+
+
+@pytest.mark.parametrize("scenario,kind,N", SCENARIOS)
+def test_device_mt19937_reset_of_the_landmark_scenarios_is_bit_exact(scenario, kind, N):
+    """fg_reset_scenario_mt continues each env's legacy NumPy stream on the GPU: three consecutive resets (all envs, a masked
+    half, the envs whose episode is over) equal the host path `reset_world` - the reference's draws - exactly, obstacles'
+    np.random.uniform([s_k, 2.0], [s_k+1, 2.5]) included."""
+    B = 37
+    dev_env, host_env = _pair(scenario, N, B, seed=91)
+    dev_env.scenario.upload_mt_streams(dev_env.world)          # both envs have drawn their first reset: the streams are aligned
+    for rep in range(3):
+        if rep == 0:
+            host_env.scenario.reset_world(host_env.world)
+            dev_env.scenario.reset_mt(dev_env.world)
+        elif rep == 1:
+            m = np.zeros(B, dtype=bool); m[::2] = True
+            host_env.scenario.reset_world(host_env.world, env_mask=m)
+            dev_env.scenario.reset_mt(dev_env.world, torch.as_tensor(m.astype(np.uint8)).cuda())
+        else:
+            L = int(host_env.world.world_length)
+            steps = torch.as_tensor(np.where(np.arange(B) % 3 == 1, L, 2).astype(np.int32)).cuda()
+            for e in (dev_env, host_env):
+                e.world.step_count.copy_(steps)
+            host_env.scenario.reset_world(host_env.world, env_mask=(np.arange(B) % 3 == 1))
+            dev_env.scenario.reset_mt_done(dev_env.world)
+        for x, y in zip(_state(dev_env), _state(host_env)):
+            assert torch.equal(x, y), (scenario, rep)
+
+
+@pytest.mark.parametrize("scenario,kind,N", SCENARIOS[:4])
+def test_vec_env_device_mt_of_the_landmark_scenarios_matches_host_mode(scenario, kind, N):
+    """FormationVecEnv(reset_mode='device_mt') for the landmark scenarios: multi-episode rollouts equal the 'host' reset mode
+    bit for bit (observations incl. the reset observation, pre-reset rewards and dones, the streams' continuation)."""
+    import formation_gym
+    from formation_gym.vec_env import FormationVecEnv
+    B, T, L = 11, 9, 4
+    phase = (np.arange(B) * 3) % L
+    envs = []
+    for mode in ("device_mt", "host"):
+        e = formation_gym.make_env(scenario, False, N, num_envs=B, device="cuda:0")
+        e.seed(33)
+        v = FormationVecEnv(e, reset_mode=mode)
+        v.reset()
+        e.world.world_length = L
+        e.world.step_count.copy_(torch.as_tensor(phase.astype(np.int32)))
+        v.ts[:] = phase
+        envs.append((e, v))
+    rs = np.random.RandomState(5)
+    for t in range(T):
+        act = torch.as_tensor(rs.uniform(-1, 1, (B, N, 2)).astype(np.float32)).cuda()
+        outs = [v.step(act) for (_, v) in envs]
+        for k in range(3):
+            assert torch.equal(torch.as_tensor(outs[0][k]), torch.as_tensor(outs[1][k])), (scenario, t, k)
+        for x, y in zip(_state(envs[0][0]), _state(envs[1][0])):
+            assert torch.equal(x, y)

@@ -462,6 +462,37 @@ def test_entity_flags_match_reference(golden):
     assert np.abs(st2["pos"] - g["pos"][-1]).max() > 1e-3
 
 
+def scripted_u(p_own, v_own, p_lead):
+    """tests/golden/make_golden.py scripted_u: the deterministic scripted agent of fixture hd_n6_scripted"""
+    return 0.6 * np.stack([-p_own[..., 1], p_own[..., 0]], -1) - 0.3 * v_own + 0.2 * (p_lead - p_own)
+
+
+def test_scripted_agents_match_reference(golden):
+    """Agent.action_callback (core.py:210-211): the callback's action.u is used as it is, the policy agents' raw actions
+    are scaled by the sensitivity (environment.py:216-221).  The oracle free-runs on the reference's trajectory."""
+    g = golden("hd_n6_scripted")
+    P = O.HdParams()
+    scripted = g["scripted"]
+    assert scripted.sum() == 2
+    pos, vel = g["pos0"][None], g["vel0"][None]
+    for t in range(g["acts"].shape[0]):
+        act = g["acts"][t][None].astype(np.float64)
+        u = scripted_u(pos[0][scripted], vel[0][scripted], pos[0][0][None])
+        np.testing.assert_allclose(u, g["u_scripted"][t], rtol=0, atol=1e-12)
+        act[0][scripted] = u
+        pos, vel = O.physics_step(pos, vel, act, P, mass=g["mass"], scripted=scripted)
+        np.testing.assert_allclose(pos[0], g["pos"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vel[0], g["vel"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(O.observation_hd(pos, vel, g["ideal_shape"][None], g["ideal_vel"][None])[0], g["obs"][t], rtol=0, atol=1e-12)
+    # the flag matters: with the sensitivity applied to the scripted agents too the oracle leaves the reference's trajectory
+    pos2, vel2 = g["pos0"][None], g["vel0"][None]
+    for t in range(g["acts"].shape[0]):
+        act = g["acts"][t][None].astype(np.float64)
+        act[0][scripted] = scripted_u(pos2[0][scripted], vel2[0][scripted], pos2[0][0][None])
+        pos2, vel2 = O.physics_step(pos2, vel2, act, P, mass=g["mass"])
+    assert np.abs(pos2[0] - g["pos"][-1]).max() > 1e-3
+
+
 @pytest.mark.parametrize("kind,name", [("obstacle", "obst_n5_masses"), ("partial", "partial_n6_masses")])
 def test_landmark_scenarios_with_per_agent_tables_match_reference(golden, kind, name):
     g = golden(name)
