@@ -115,6 +115,9 @@ void step_kernel(const int pre_B, const int pre_N, const real* __restrict__ pre_
 
     // KONE: the single-step instantiation (K = 1, obs_every = 1 known at compile time: no step loop, no slot arithmetic)
     const int K = KONE ? 1 : a.K;
+    // (Streaming the static two thirds of every row - zeros | ideal_shape | ideal_vel - from the agent-less waves while the others
+    // run the pair loops does NOT shorten a single-step launch: 27 x 4096 15.2 -> 16.1 us (each 648-byte row then leaves as two
+    // partial-line pieces), 32 x 4096 18.3 -> 17.9 where rows are whole lines: profiles/r05_step_early_ab.txt.)
     const uint64_t rbase = rng_base(a.p);            // read once: no load from the device counter inside the step loop
     for (int k = 0; k < K; ++k) {
         // the agent's own properties as the step loop reads them: the 1024-thread instantiations (128-VGPR budget) fetch them

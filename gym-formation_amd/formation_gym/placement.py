@@ -323,15 +323,15 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
             # arena's chunks in which EVERY window of W consecutive positions has that property; the candidates are windows
             # of one mapping per order (round 4 made one mapping per candidate and retired 65 x the buffer of address space per
             # probe instead of 3 x the arena):
+            R = 3 + (t % 3)                                           # R regions of the arena taken round-robin (kept most often)
+            per = n // R
+            order = [(k % R) * per + k // R for k in range(R * per)] + list(range(R * per, n))
+            yield "regions round-robin (%d)" % R, order
             g = max(1, int(round(n * 0.6180339887)))
             while math.gcd(g, n) != 1:
                 g += 1
             off = rnd.randrange(n)
             yield "spread, golden stride", [(off + k * g) % n for k in range(n)]   # neighbours of the buffer 0.62 arenas apart
-            R = 3 + (t % 3)                                           # R regions of the arena taken round-robin
-            per = n // R
-            order = [(k % R) * per + k // R for k in range(R * per)] + list(range(R * per, n))
-            yield "regions round-robin (%d)" % R, order
             order = list(range(n))
             rnd.shuffle(order)
             yield "spread, shuffled", order
@@ -341,17 +341,17 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
         addr = arena.map(first)                                      # probe measured 5-8 % slow
         try:
             flat0 = arena.floats(addr, nfloats)
-            while time.perf_counter() - t_warm < 0.05:
-                try:
+            try:
+                while time.perf_counter() - t_warm < 0.05:
                     _time_launch(time_fn, flat0, stream, 2)
-                except Exception as exc:                             # noqa: BLE001 - see timed()
-                    raise _LaunchError(exc) from exc
+                ms = [_time_launch(time_fn, flat0, stream, reps)]        # "as created": the arena's first chunks, on the same mapping
+            except Exception as exc:                                 # noqa: BLE001 - see timed()
+                raise _LaunchError(exc) from exc
         finally:
             flat0 = None
             stream.synchronize()
             arena.unmap(addr)
         cands = [("as created", first)]
-        ms = [timed(first, reps, False)]
         # a short launch is timed more often: the median of 3 launches of 0.24 ms is good to ~1.5 %, which is what separates
         # the best selections (one of six fresh processes kept a selection 2.4 % slower than the others' for it); every
         # candidate gets >= 3 ms of timed launches, at most 15 of them
@@ -359,8 +359,11 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
         # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
         # and its selections differ by 1 %)
         count = int(max(int(trials), min(8 * int(trials), budget_s / max(1e-6, (reps_c + 1) * ms[0] * 1e-3 + 4e-3))))
-        per_order = -(-count // 3)
-        for kind, order in arena_orders(seed):
+        # one mapping of the whole arena per order: three orders for buffers of a few GB, fewer for the large ones, whose
+        # windows overlap most of the arena anyway (a 46 GB buffer in a 70 GB arena) and whose launches gain 3-6 % at most
+        orders = list(arena_orders(seed))[:3 if nbytes < (4 << 30) else 2 if nbytes < (16 << 30) else 1]
+        per_order = -(-count // len(orders))
+        for kind, order in orders:
             last = n - W                                             # last window start
             starts = sorted({int(round(j * last / max(1, per_order - 1))) for j in range(per_order)}) if last > 0 else [0]
             base = arena.map(order)                                  # every chunk of the arena, once per order
@@ -370,11 +373,14 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
                     ms.append(time_window(base, st, reps_c))
             finally:
                 arena.unmap(base)
-        finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
-        final = {i: timed(cands[i][1], 2 * reps_c + 1, i > 0) for i in finalists}
-        for i, v in final.items():
-            ms[i] = v
-        best = min(final, key=final.get)
+        if ms[0] < 2.0:
+            finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
+            final = {i: timed(cands[i][1], 2 * reps_c + 1, i > 0) for i in finalists}
+            for i, v in final.items():
+                ms[i] = v
+            best = min(final, key=final.get)
+        else:                                                        # a launch of milliseconds is timed well enough the first time
+            best = min(range(len(ms)), key=lambda i: ms[i])
         addr = arena.map(cands[best][1])                             # the winner, for good ...
         arena.trim()                                                 # ... and every other chunk back to the driver
         if best > 0:                                                 # every candidate but "as created" is a spread buffer

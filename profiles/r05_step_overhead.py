@@ -11,11 +11,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "gym-formation_amd")]
 import torch                                              # noqa: E402
 import formation_gym                                      # noqa: E402
+from formation_gym import _native                         # noqa: E402
+
+if os.environ.get("FG_EXPERIMENT_LIB"):                   # A/B runs of experiment builds
+    _native.LIB_PATH = os.path.abspath(os.environ["FG_EXPERIMENT_LIB"])
+SHAPES = [tuple(int(x) for x in a.split(":")) for a in sys.argv[1:]] or [(9, 4096), (27, 4096), (81, 2048)]
 
 dev = "cuda:0"
 print("| agents x envs | bound launcher us/step | env.step(act) us/step | hipGraph of 20 steps us/step |")
 print("|---|---|---|---|")
-for N, B in ((9, 4096), (27, 4096), (81, 2048)):
+for N, B in SHAPES:
     env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
     env.seed(1); env.reset(); env.auto_reset = True
     P = 20
