@@ -28,6 +28,7 @@
 // points.  formation_hip_f64.hip builds the step kernel's source in double (tests only).
 
 #include <atomic>
+#include <cstdarg>
 #include <cstdlib>
 #include <vector>
 #include "fg_common.hpp"
@@ -53,6 +54,25 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 }
 
 struct Geometry { int G, T, E, lds; };
+
+// Dry run of the dispatch (fg_describe_launch): while `g_describe` points at a caller's buffer the launchers below append the
+// kernel instantiation and launch geometry they WOULD use and return without touching the device.  A CPU-side test holds a
+// committed snapshot of these choices over a grid of shapes (tests/golden/dispatch.json): a threshold that moves changes the
+// snapshot, not just a timing somebody may or may not look at.
+static thread_local char* g_describe = nullptr;
+static thread_local int g_describe_cap = 0;
+static bool describe(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+static bool describe(const char* fmt, ...) {
+    if (!g_describe) return false;
+    const int used = (int)strlen(g_describe);
+    if (used < g_describe_cap - 1) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(g_describe + used, (size_t)(g_describe_cap - used), fmt, ap);
+        va_end(ap);
+    }
+    return true;
+}
 
 // A launch goes to the device its DATA lives on: if that is not the calling thread's current device (an env living
 // on cuda:1 driven from a thread whose current device is cuda:0), switch for the duration of the call.  A non-NULL
@@ -110,6 +130,9 @@ static int pow2ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 template <int NC, int G, int T, int E, bool IDX, bool OPTS>
 static hipError_t launch_v(const Args& a, int grid, int lds, hipStream_t st) {
     const int n_split = a.N | ((E == 1 && a.split > 1 ? a.split : 0) << 16);
+    if (describe("step_kernel<%d,%d,%d,%d,%d,%d,%d> grid %d lds %d%s; ", NC, G, T, E, (int)IDX, (int)OPTS,
+                 (int)(!IDX && !OPTS && NC >= 27 && a.K == 1 && a.obs_every == 1), grid, lds, a.obs_only ? " obs-only" : ""))
+        return hipSuccess;
     if (lds > 64 * 1024) {                 // run-time N close to 1024 (+ the per-agent tables of the OPTS instantiation)
         static std::atomic<unsigned long long> raised{0};
         const hipError_t err = raise_lds_limit((const void*)&step_kernel<NC, G, T, E, IDX, OPTS>, lds, &raised);
@@ -239,6 +262,8 @@ static int launch_wide_v(Args a, hipStream_t st) {
     const int grid = (a.B + E * a.groups - 1) / (E * a.groups);
     const int lds = E * roll_block_floats(NC) * (int)sizeof(float) +
                     (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
+    if (describe("rollout_kernel_wide<%d,%d,%d,%d,%d,%d> grid %d lds %d groups %d; ", NC, A, E, TW, PER, (int)BATCHES, grid, lds, a.groups))
+        return FG_OK;
     static std::atomic<unsigned long long> raised{0};
     hipError_t err = raise_lds_limit((const void*)&rollout_kernel_wide<NC, A, E, TW, PER, BATCHES>, lds, &raised);
     if (err == hipSuccess) {
@@ -271,6 +296,7 @@ static int launch_roll_v(const Args& a, hipStream_t st) {
     int lds = E * roll_block_floats(NC) * (int)sizeof(float);
     lds += roll_writer_units<NC, WR, TW / 64>() * (int)sizeof(float2);
     if (PER > 0) lds += E * policy_block_units(NC) * (int)sizeof(float2);
+    if (describe("rollout_kernel<%d,%d,%d,%d,%d,%d,%d,%d> grid %d lds %d; ", NC, G, TP, TW, E, WR, PER, (int)STREAM, grid, lds)) return FG_OK;
     static std::atomic<unsigned long long> raised{0};
     hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>, lds, &raised);
     if (err == hipSuccess) {
@@ -391,6 +417,7 @@ static int launch_roll_64(const Args& a, hipStream_t st) {
 template <int NC, int PER = 0>
 static int launch_hd_lane(const Args& a, hipStream_t st) {
     const int grid = 8 * (((a.B + 63) / 64 + 7) / 8);
+    if (describe("hd_lane_kernel<%d,%d> grid %d lds %d; ", NC, PER, grid, hd_lane_lds_bytes(NC))) return FG_OK;
     hipLaunchKernelGGL((hd_lane_kernel<NC, PER>), dim3(grid), dim3(128), hd_lane_lds_bytes(NC), st, a);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
@@ -763,6 +790,49 @@ int fg_plan_destroy(void* plan) {
     return FG_OK;
 }
 
+// the tail of fg_rollout_hd: which kernel runs a checked K-step description (also walked dry by fg_describe_launch)
+static int rollout_hd_dispatch(const Args& a, hipStream_t st) {
+    int rc = FG_OK;
+    // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
+    // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
+    if (a.K == 1 && !world_options_set(a.p)) {                                                       // as fg_step_hd
+        if (a.N == 243 && a.B >= FG_WIDE243_MIN_B) return launch_wide<243, 0>(a, st);
+        if (a.N == 81 && a.B >= FG_WIDE81_MIN_B) return launch_wide<81, 0>(a, st);
+    }
+    if (a.K >= 2 && !world_options_set(a.p) && launch_pipelined(a, 0, st, &rc)) return rc;
+    return launch_step(a, st);
+}
+
+static int launch_policy_state(int B, int N, const FgPolicyLevels& pl, const float* px, const float* py,
+                               const float* shape, const float* ivel, float* act, hipStream_t st);
+
+// ... and of fg_rollout_hd_policy (a.pl, a.act_out set)
+static int rollout_hd_policy_dispatch(const Args& a, int per_layer, hipStream_t st) {
+    int rc = FG_OK;
+    // N = per^L up to 243 agents (per 2, 3, 4, 5, 8): the controller runs inside the pipelined kernels, ONE launch
+    if (!world_options_set(a.p) && launch_pipelined(a, per_layer, st, &rc)) return rc;
+    // everything else: K times (controller launch, single-step launch) chained on the stream - the same device
+    // function on the same state, so the results equal the in-kernel loop's and fg_policy_bfs on the written rows
+    const size_t bn = (size_t)a.B * a.N;
+    for (int k = 0; k < a.K; ++k) {
+        float* act_k = a.act_out + (size_t)k * bn * 2;
+        rc = launch_policy_state(a.B, a.N, a.pl, a.px, a.py, a.shape, a.ivel, act_k, st);
+        if (rc) return rc;
+        Args s1 = a;
+        s1.K = 1; s1.obs_every = 1; s1.act = act_k; s1.act_out = nullptr;
+        s1.p.rng_offset = a.p.rng_offset + (uint64_t)k;
+        s1.rew = a.rew + (size_t)k * bn;
+        s1.indiv = a.indiv ? a.indiv + (size_t)k * bn : nullptr;
+        s1.done = a.done ? a.done + (size_t)k * bn : nullptr;
+        s1.obs = (a.obs && (k + 1) % a.obs_every == 0)
+                     ? a.obs + (size_t)(k / a.obs_every) * (size_t)a.B * (size_t)a.obs_pitch * 2 : nullptr;
+        rc = launch_step(s1, st);
+        if (rc) return rc;
+        if (g_describe && k == 0 && a.K > 1) { describe("x %d chained; ", a.K); break; }   // dry run: one round says it all
+    }
+    return FG_OK;
+}
+
 int fg_physics_step(const FgParams* params, int B, int N,
                     float* pos_x, float* pos_y, float* vel_x, float* vel_y,
                     const float* act, void* stream) {
@@ -832,14 +902,7 @@ int fg_rollout_hd(const FgParams* params, int B, int N, int K,
     a.px = pos_x; a.py = pos_y; a.vx = vel_x; a.vy = vel_y; a.act = act_seq;
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
-    // K >= 2 at the specialised agent counts: producer / writer pipelined kernels.  World options (walls, max_speed,
-    // accel, u_noise) exist only in step_kernel's OPTS instantiation, whose K-loop runs the rollout then.
-    if (K == 1 && !world_options_set(a.p)) {                                                         // as fg_step_hd
-        if (N == 243 && B >= FG_WIDE243_MIN_B) return launch_wide<243, 0>(a, (hipStream_t)stream);
-        if (N == 81 && B >= FG_WIDE81_MIN_B) return launch_wide<81, 0>(a, (hipStream_t)stream);
-    }
-    if (K >= 2 && !world_options_set(a.p) && launch_pipelined(a, 0, (hipStream_t)stream, &rc)) return rc;
-    return launch_step(a, (hipStream_t)stream);
+    return rollout_hd_dispatch(a, (hipStream_t)stream);
 }
 
 int fg_reset_hd(const FgParams* params, int B, int N, const uint8_t* mask,
@@ -916,6 +979,8 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
 #define FG_SCN_LANE(KIND, NN, LL, MM, NBR)                                                                              \
         if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
             constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
+            if (describe("scn_lane_kernel<%d,%d,%d,%d,%d> grid %d threads %d lds %d; ", KIND, NN, LL, MM, NBR,               \
+                         8 * (((B + 63) / 64 + 7) / 8), 64 + 64 * scn_lane_writers(KIND), lds)) return FG_OK;               \
             hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)),               \
                                dim3(64 + 64 * scn_lane_writers(KIND)),                                                      \
                                lds, st, a);                                                                                 \
@@ -947,6 +1012,7 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         a.stage = (lds + stage <= 48 * 1024) ? 1 : 0;
         if (a.stage) lds += (int)stage;
     }
+    if (describe("scn_kernel<%d,%d> grid %d lds %d stage %d; ", G, G <= 64 ? FG_SCN_T : G, grid, lds, a.stage)) return FG_OK;
     if (G == 4) hipLaunchKernelGGL((scn_kernel<4, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
     else if (G == 8) hipLaunchKernelGGL((scn_kernel<8, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
     else if (G == 16) hipLaunchKernelGGL((scn_kernel<16, FG_SCN_T>), dim3(grid), dim3(FG_SCN_T), lds, st, a);
@@ -1125,6 +1191,7 @@ static int launch_policy_state(int B, int N, const FgPolicyLevels& pl, const flo
     const int E = 256 / lpe;
     const int grid = (B + E - 1) / E;
     const int lds = E * policy_block_units(N) * (int)sizeof(float2);        // <= 56 KiB
+    if (describe("policy_state_kernel<%d> grid %d lds %d; ", pl.per, grid, lds)) return FG_OK;
 #define FG_POLICY(PER) case PER: hipLaunchKernelGGL((policy_state_kernel<PER>), dim3(grid), dim3(256), lds, st, B, N, lpe, pl, \
                                                    px, py, shape, ivel, act); break;
     switch (pl.per) { FG_POLICY(2) FG_POLICY(3) FG_POLICY(4) FG_POLICY(5) FG_POLICY(6) FG_POLICY(7) FG_POLICY(8) }
@@ -1176,28 +1243,7 @@ int fg_rollout_hd_policy(const FgParams* params, int B, int N, int K, int per_la
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs_seq; a.rew = reward_seq; a.indiv = indiv_seq; a.done = done_seq;
     a.pl = pl; a.act_out = act_seq;
-    hipStream_t st = (hipStream_t)stream;
-    // N = per^L up to 243 agents (per 2, 3, 4, 5, 8): the controller runs inside the pipelined kernels, ONE launch
-    if (!world_options_set(a.p) && launch_pipelined(a, per_layer, st, &rc)) return rc;
-    // everything else: K times (controller launch, single-step launch) chained on the stream - the same device
-    // function on the same state, so the results equal the in-kernel loop's and fg_policy_bfs on the written rows
-    const size_t bn = (size_t)B * N;
-    for (int k = 0; k < K; ++k) {
-        float* act_k = act_seq + (size_t)k * bn * 2;
-        rc = launch_policy_state(B, N, pl, pos_x, pos_y, ideal_shape, ideal_vel, act_k, st);
-        if (rc) return rc;
-        Args s1 = a;
-        s1.K = 1; s1.obs_every = 1; s1.act = act_k; s1.act_out = nullptr;
-        s1.p.rng_offset = a.p.rng_offset + (uint64_t)k;
-        s1.rew = reward_seq + (size_t)k * bn;
-        s1.indiv = indiv_seq ? indiv_seq + (size_t)k * bn : nullptr;
-        s1.done = done_seq ? done_seq + (size_t)k * bn : nullptr;
-        s1.obs = (obs_seq && (k + 1) % a.obs_every == 0)
-                     ? obs_seq + (size_t)(k / a.obs_every) * (size_t)B * (size_t)a.obs_pitch * 2 : nullptr;
-        rc = launch_step(s1, st);
-        if (rc) return rc;
-    }
-    return FG_OK;
+    return rollout_hd_policy_dispatch(a, per_layer, (hipStream_t)stream);
 }
 
 int fg_policy_bfs(int B, int N, int per_layer, const float* obs, int64_t obs_env_stride, float* act, void* stream) {
@@ -1241,6 +1287,47 @@ int fg_decode_actions(int mode, int64_t count, void* action, float* u_out, void*
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "decode launch failed: %s", hipGetErrorString(err));
     return FG_OK;
+}
+
+int fg_describe_launch(const FgParams* params, const FgScenario* scenario, int B, int N, int K, int per_layer, int obs_every,
+                       int index_outputs, char* out, int out_len) {
+    if (!out || out_len < 2) return fail(FG_ERR_BAD_ARG, "fg_describe_launch: out buffer required%s");
+    int rc = check_params(params);
+    if (rc) return rc;
+    if (B <= 0 || K < 0) return fail(FG_ERR_BAD_ARG, "fg_describe_launch: B > 0 and K >= 0 required%s");
+    out[0] = 0;
+    // stand-ins for the caller's buffers: only their NULL-ness and alignment steer the dispatch, nothing is dereferenced
+    float* const f = reinterpret_cast<float*>((uintptr_t)4096);
+    int32_t* const i32 = reinterpret_cast<int32_t*>((uintptr_t)4096);
+    uint8_t* const u8 = reinterpret_cast<uint8_t*>((uintptr_t)4096);
+    g_describe = out; g_describe_cap = out_len;
+    if (scenario) {
+        rc = launch_scenario(params, scenario, B, N, 1, f, f, f, f, f, f, scenario->num_obstacles ? f : nullptr,
+                             scenario->num_obstacles ? f : nullptr, i32, f, f, f, u8, nullptr, nullptr, K < 1 ? 1 : K,
+                             obs_every < 1 ? 1 : obs_every);
+    } else if (N < 3 || N > FG_MAX_AGENTS) {
+        rc = fail(FG_ERR_UNSUPPORTED_N, "formation_hd_env needs 3 <= N <= 1024%s");
+    } else {
+        Args a; memset(&a, 0, sizeof(a));
+        a.p = *params; a.B = B; a.N = N; a.inv_n = 1.0f / (float)N; a.K = K < 1 ? 1 : K; a.obs_every = obs_every < 1 ? 1 : obs_every;
+        a.do_phys = 1; a.do_post = 1;
+        a.px = f; a.py = f; a.vx = f; a.vy = f; a.act = f; a.shape = f; a.ivel = f; a.step = i32;
+        a.obs = f; a.rew = f; a.indiv = f; a.done = u8;
+        if (index_outputs) { a.near_lm = i32; a.near_ag = i32; a.hd_idx = i32; }
+        rc = set_obs_pitch(&a);
+        if (rc == FG_OK) {
+            if (per_layer > 0) {
+                if (!policy_levels_for(N, per_layer, &a.pl)) rc = fail(FG_ERR_UNSUPPORTED_N, "N must be per_layer^L with 2 <= per_layer <= 8%s");
+                else { a.act_out = f; rc = rollout_hd_policy_dispatch(a, per_layer, nullptr); }
+            } else if (K == 0) {
+                rc = step_hd_dispatch(a, nullptr);                      // fg_step_hd
+            } else {
+                rc = rollout_hd_dispatch(a, nullptr);                   // fg_rollout_hd with K steps
+            }
+        }
+    }
+    g_describe = nullptr; g_describe_cap = 0;
+    return rc;
 }
 
 }  // extern "C"

@@ -107,6 +107,7 @@ SIGNATURES = {
     "fg_arena_retired_address_bytes": (ctypes.c_uint64, []),
     "fg_arena_destroy": (_I, [_P]),
     "fg_kernel_config": (_I, [_I, ctypes.POINTER(_I), ctypes.POINTER(_I), ctypes.POINTER(_I)]),
+    "fg_describe_launch": (_I, [_PP, ctypes.POINTER(FgScenario), _I, _I, _I, _I, _I, _I, ctypes.c_char_p, _I]),
     "fg_step_hd_bytes": (ctypes.c_int64, [_I]),
     "fg_step_hd": (_I, [_PP, _I, _I] + [_P] * 16),
     "fg_step_hd_plan": (_I, [_PP, _I, _I] + [_P] * 16 + [ctypes.POINTER(ctypes.c_void_p)]),

@@ -237,6 +237,12 @@ int fg_launch_device(void* stream, const void* data);
 /* Launch geometry the library will use for N agents: threads per workgroup,
  * environments per workgroup, dynamic LDS bytes.  Returns FgStatus. */
 int fg_kernel_config(int N, int* threads, int* envs_per_wg, int* lds_bytes);
+/* Dry run of the dispatch: which kernel instantiation(s) and launch geometry fg_step_hd (K = 0), fg_rollout_hd (K >= 1,
+ * per_layer = 0), fg_rollout_hd_policy (per_layer > 0) or - with a scenario descriptor - fg_rollout_scenario would use for this
+ * shape and these params (obs_env_pitch, obs_placed, World options and all), written to `out` as text.  Touches no device:
+ * callable without a GPU.  tests/test_dispatch_snapshot.py holds the committed choices over a grid of shapes. */
+int fg_describe_launch(const FgParams* params, const FgScenario* scenario, int B, int N, int K, int per_layer, int obs_every,
+                       int index_outputs, char* out, int out_len);
 /* Algorithmic bytes per env-step of fg_step_hd (24 N^2 + 53 N + 16). */
 int64_t fg_step_hd_bytes(int N);
 
