@@ -666,6 +666,34 @@ int fg_arena_unmap(void* arena, void* base) {
     return fail(FG_ERR_BAD_ARG, "fg_arena_unmap: not a mapping of this arena%s");
 }
 
+// Shrinks a mapping to the window [first, first + count) of its chunks: the chunks outside are unmapped (their part of the
+// reservation is retired), the window stays where it is.  The probe keeps its winner this way when it lies in the mapping it
+// timed last, instead of mapping it once more at a fresh address.
+int fg_arena_keep_window(void* arena, void* base, uint32_t first, uint32_t count, void** new_base) {
+    Arena* a = (Arena*)arena;
+    if (!a || !base || !new_base || count == 0) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_window: arena, base, new_base and count > 0 required%s");
+    for (size_t k = 0; k < a->maps.size(); ++k) {
+        Arena::Mapping& m = a->maps[k];
+        if (m.base != (char*)base) continue;
+        if ((size_t)first + count > m.chunks.size()) return fail(FG_ERR_BAD_ARG, "fg_arena_keep_window: window beyond the mapping%s");
+        drain_device(a->dev);
+        size_t gone = 0;
+        for (size_t j = 0; j < m.chunks.size(); ++j) {
+            if (j >= first && j < (size_t)first + count) continue;
+            (void)hipMemUnmap(m.base + j * a->chunk, a->chunk);
+            a->mapped_in[m.chunks[j]] = -1;
+            ++gone;
+        }
+        g_retired_address_bytes.fetch_add((unsigned long long)(gone * a->chunk));
+        std::vector<uint32_t> kept(m.chunks.begin() + first, m.chunks.begin() + first + count);
+        m.base += (size_t)first * a->chunk;
+        m.chunks.swap(kept);
+        *new_base = m.base;
+        return FG_OK;
+    }
+    return fail(FG_ERR_BAD_ARG, "fg_arena_keep_window: not a mapping of this arena%s");
+}
+
 uint64_t fg_arena_retired_address_bytes(void) { return (uint64_t)g_retired_address_bytes.load(); }
 
 int fg_arena_trim(void* arena) {

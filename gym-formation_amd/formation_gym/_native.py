@@ -103,6 +103,7 @@ SIGNATURES = {
                              ctypes.POINTER(ctypes.c_uint32)]),
     "fg_arena_map": (_I, [_P, ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.POINTER(_P)]),
     "fg_arena_unmap": (_I, [_P, _P]),
+    "fg_arena_keep_window": (_I, [_P, _P, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(_P)]),
     "fg_arena_trim": (_I, [_P]),
     "fg_arena_retired_address_bytes": (ctypes.c_uint64, []),
     "fg_arena_destroy": (_I, [_P]),

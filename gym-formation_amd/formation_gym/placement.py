@@ -147,6 +147,13 @@ class Arena(object):
     def unmap(self, base):
         _native.check(_native.load().fg_arena_unmap(self._handle, ctypes.c_void_p(int(base))))
 
+    def keep_window(self, base, first, count):
+        """Shrinks the mapping at `base` to `count` chunks from position `first` (the rest is unmapped); returns its address."""
+        new_base = ctypes.c_void_p()
+        _native.check(_native.load().fg_arena_keep_window(self._handle, ctypes.c_void_p(int(base)), int(first), int(count),
+                                                          ctypes.byref(new_base)))
+        return int(new_base.value)
+
     def trim(self):
         """Hand every chunk that is not mapped right now back to the driver."""
         _native.check(_native.load().fg_arena_trim(self._handle))
@@ -224,7 +231,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     stages = []
     previous = None
     while True:
-        placed = _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed + len(stages), budget_s, free, t_start)
+        placed = _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed + len(stages), budget_s, free, t_start,
+                              stage_index=len(stages))
         if placed is None:
             if previous is None:
                 return None
@@ -243,8 +251,14 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         # allocation, where other boxes reach 50.5): when the arena offered nothing, look at four times as much memory, twice
         # at most, within `mem_fraction` of what is free.  A caller that names the arena size gets that size.
         bigger = next_arena_bytes(geometry[0], nbytes, free, mem_fraction)
+        # ... unless the launch does not care where its buffer lies: when the arena's first chunks and the median spread candidate ran within 2.5 % of the
+        # best (a launch bound by its dependent chain, e.g. 9 x 4096 x 128: 0.2015 ... 0.2074 ms), a larger arena has nothing
+        # to offer either - round 4 took it through 6 / 24 / 98 GB for nothing, 0.6 TB of address space
+        spread = report.get("spread_ms_min_median_max") or [report["kept_ms"]] * 3
+        best_ms = min(report["kept_ms"], report["as_created_ms"], spread[0])
+        insensitive = max(spread[1], report["as_created_ms"]) <= ESCALATE_INSENSITIVE * best_ms     # the MEDIAN: one slow outlier is noise
         if (max_arena_bytes is not None or not escalate or nbytes < ESCALATE_MIN_BYTES or len(stages) >= 3 or bigger is None
-                or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]):
+                or insensitive or stages[0]["arena_GB"] * 1e9 >= ESCALATE_MAX_FIRST_ARENA or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]):
             return placed
         del flat, placed
         arena.close()
@@ -261,6 +275,12 @@ ESCALATE_BELOW_GAIN = 0.97
 # 0.82 of peak.  The price is paid by launches that placement cannot help: 9 x 4096 x 128, bound by its dependent chain, goes
 # through 6 / 24 / 98 GB for 0.2339 / 0.2317 / 0.2334 ms, ~1.2 s once per buffer shape.
 ESCALATE_MIN_BYTES = 0
+# ... but not for launches that do not care where their buffer lies (median candidate within 2.5 % of the best), and not
+# when the first arena was a large sample of the device's memory already (a 6.4 GB buffer starts with 39 GB; the escalation
+# exists for the 1-2 GB buffers whose first 6-9 GB can be all alike).  Four times such an arena would retire hundreds of GB
+# of address space per probe.
+ESCALATE_INSENSITIVE = 1.025
+ESCALATE_MAX_FIRST_ARENA = 32 << 30
 
 
 def next_arena_bytes(total, nbytes, free_bytes, mem_fraction=0.5):
@@ -270,8 +290,8 @@ def next_arena_bytes(total, nbytes, free_bytes, mem_fraction=0.5):
     return bigger if bigger >= 2 * total and bigger >= 2 * nbytes else None
 
 
-def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_s, free, t_start):
-    """One arena of probe_arena: (flat, report, arena) or None."""
+def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_s, free, t_start, stage_index=0):
+    """One arena of probe_arena: (flat, report, arena) or None.  stage_index > 0: a follow-up arena of an escalating probe."""
     import math
     import random
     import time
@@ -337,51 +357,68 @@ def _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed, budget_
             yield "spread, shuffled", order
 
         first = list(range(W))
-        t_warm = time.perf_counter()                                 # bring the clocks up first: the early candidates of a cold
-        addr = arena.map(first)                                      # probe measured 5-8 % slow
+        cands = [("as created", first)]
+        last_base, where = None, {}                                  # the mapping kept after the loop, candidate -> window start in it
+        t_warm = time.perf_counter()                             # bring the clocks up first: the early candidates of a cold
+        addr = arena.map(first)                                  # probe measured 5-8 % slow
         try:
             flat0 = arena.floats(addr, nfloats)
             try:
                 while time.perf_counter() - t_warm < 0.05:
                     _time_launch(time_fn, flat0, stream, 2)
-                ms = [_time_launch(time_fn, flat0, stream, reps)]        # "as created": the arena's first chunks, on the same mapping
-            except Exception as exc:                                 # noqa: BLE001 - see timed()
+                ms = [_time_launch(time_fn, flat0, stream, reps)]    # "as created": the arena's first chunks, on the same mapping
+            except Exception as exc:                             # noqa: BLE001 - see timed()
                 raise _LaunchError(exc) from exc
         finally:
             flat0 = None
             stream.synchronize()
             arena.unmap(addr)
-        cands = [("as created", first)]
         # a short launch is timed more often: the median of 3 launches of 0.24 ms is good to ~1.5 %, which is what separates
         # the best selections (one of six fresh processes kept a selection 2.4 % slower than the others' for it); every
         # candidate gets >= 3 ms of timed launches, at most 15 of them
         reps_c = int(min(15, max(reps, math.ceil(3.0 / max(ms[0], 1e-3)))))
-        # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch few,
-        # and its selections differ by 1 %)
+        # how many selections the budget affords (a 0.25 ms launch many, and its selections differ by 20 %; a 7 ms launch
+        # few, and its selections differ by 1 %)
         count = int(max(int(trials), min(8 * int(trials), budget_s / max(1e-6, (reps_c + 1) * ms[0] * 1e-3 + 4e-3))))
-        # one mapping of the whole arena per order: three orders for buffers of a few GB, fewer for the large ones, whose
-        # windows overlap most of the arena anyway (a 46 GB buffer in a 70 GB arena) and whose launches gain 3-6 % at most
-        orders = list(arena_orders(seed))[:3 if nbytes < (4 << 30) else 2 if nbytes < (16 << 30) else 1]
+        # one mapping of the whole arena per order: three orders for buffers up to 2 GB, two up to 4 GB, one above; a follow-up
+        # arena (escalation) is looked at through ONE order - it is four and sixteen times as large
+        orders = list(arena_orders(seed))[:1 if stage_index > 0 else 3 if nbytes < (2 << 30) else 2 if nbytes < (4 << 30) else 1]
         per_order = -(-count // len(orders))
-        for kind, order in orders:
-            last = n - W                                             # last window start
+        refine = ms[0] < 2.0                                     # short launches: the three fastest once more (below)
+        for o_i, (kind, order) in enumerate(orders):
+            last = n - W                                         # last window start
             starts = sorted({int(round(j * last / max(1, per_order - 1))) for j in range(per_order)}) if last > 0 else [0]
-            base = arena.map(order)                                  # every chunk of the arena, once per order
+            base = arena.map(order)                              # every chunk of the arena, once per order
+            keep = False
             try:
                 for st in starts:
                     cands.append((kind, order[st:st + W]))
                     ms.append(time_window(base, st, reps_c))
+                    if o_i == len(orders) - 1:
+                        where[len(ms) - 1] = st
+                # the winner of a long launch lies in this (the last) mapping: keep its window where it is
+                keep = (not refine) and o_i == len(orders) - 1 and min(range(len(ms)), key=lambda i: ms[i]) in where
             finally:
-                arena.unmap(base)
-        if ms[0] < 2.0:
-            finalists = sorted(range(len(ms)), key=lambda i: ms[i])[:3]  # the three fastest once more, with more repetitions
+                if keep:
+                    last_base = base
+                else:
+                    arena.unmap(base)
+                    if o_i == len(orders) - 1:
+                        where = {}
+        if refine:
+            # the three fastest once more, with more repetitions - and "as created" with them: the kept buffer is never one
+            # that measured slower than what a plain allocation would have given
+            finalists = sorted(set(sorted(range(len(ms)), key=lambda i: ms[i])[:3]) | {0})
             final = {i: timed(cands[i][1], 2 * reps_c + 1, i > 0) for i in finalists}
             for i, v in final.items():
                 ms[i] = v
             best = min(final, key=final.get)
         else:                                                        # a launch of milliseconds is timed well enough the first time
             best = min(range(len(ms)), key=lambda i: ms[i])
-        addr = arena.map(cands[best][1])                             # the winner, for good ...
+        if last_base is not None and best in where:
+            addr = arena.keep_window(last_base, where[best], W)      # the winner stays mapped, the rest of that mapping goes
+        else:
+            addr = arena.map(cands[best][1])                         # the winner, for good ...
         arena.trim()                                                 # ... and every other chunk back to the driver
         if best > 0:                                                 # every candidate but "as created" is a spread buffer
             arena.kept_range = (addr, addr + W * chunk)

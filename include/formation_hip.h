@@ -220,6 +220,9 @@ typedef struct FgScenario {
 int fg_arena_create(int device, uint64_t bytes, uint64_t chunk_bytes, void** arena, uint64_t* chunk_out, uint32_t* chunks_out);
 int fg_arena_map(void* arena, const uint32_t* chunk_index, uint32_t count, void** base);
 int fg_arena_unmap(void* arena, void* base);
+/* shrinks the mapping at `base` to chunks [first, first + count) of it (the others are unmapped, their addresses retired); the
+ * window keeps its address, returned in *new_base = base + first * chunk */
+int fg_arena_keep_window(void* arena, void* base, uint32_t first, uint32_t count, void** new_base);
 int fg_arena_trim(void* arena);
 uint64_t fg_arena_retired_address_bytes(void);
 int fg_arena_destroy(void* arena);

@@ -910,6 +910,7 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     from formation_gym import placement
     monkeypatch.setattr(placement, "ESCALATE_BELOW_GAIN", 0.0)
     monkeypatch.setattr(placement, "ESCALATE_MIN_BYTES", 0)
+    monkeypatch.setattr(placement, "ESCALATE_INSENSITIVE", 0.0)        # (a copy_ does not care where its buffer lies)
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
     n = (768 << 20) // 4
@@ -930,9 +931,9 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     # a larger arena that cannot be made: the size that worked is probed once more and kept
     real_stage, calls = placement._probe_stage, []
 
-    def failing_second(geometry, *args):
+    def failing_second(geometry, *args, **kw):
         calls.append(geometry[0])
-        return None if len(calls) == 2 else real_stage(geometry, *args)
+        return None if len(calls) == 2 else real_stage(geometry, *args, **kw)
     monkeypatch.setattr(placement, "_probe_stage", failing_second)
     flat, rep, arena = placement.probe_arena(n, lambda dst: dst.zero_(), "cuda", trials=4, budget_s=0.1)
     assert len(calls) == 3 and calls[2] == calls[0] and calls[1] > 3.9 * calls[0]
