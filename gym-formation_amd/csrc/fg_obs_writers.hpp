@@ -388,20 +388,32 @@ FG_DEV void build_gather_lut(uint4* __restrict__ lut, int t, int nthreads) {
     }
 }
 
+// The lane's table entries of one 8-byte phase, kept in registers across envs and steps: which phase an env block starts at
+// changes only when the env pitch or the batch's slab is an odd number of units, so a writer wave reads its entries from LDS
+// once per launch instead of once per env and step (one of the two LDS round trips in front of every env's stores).
+template <int NC> struct GatherEntries {
+    uint4 ent[gather_passes<NC>()];
+    int phase = -1;
+};
+
 // wave w of NW writes the envs w, w + NW, ... of the workgroup's El envs
 template <int NC, int NW, int E>
 FG_DEV void write_obs_gather(const float2* __restrict__ tables0, int env_stride, int w, const uint4* __restrict__ lut,
-                             float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El) {
+                             float2* __restrict__ out_env0, size_t unit0, size_t env_units, int El, GatherEntries<NC>& cache) {
     constexpr int PASSES = gather_passes<NC>(), P = PASSES * 64;
     const int lane = threadIdx.x & 63;
     for (int ee = w; ee < El; ee += NW) {
         const float2* __restrict__ T = tables0 + (size_t)ee * env_stride;
         const size_t first = unit0 + (size_t)ee * env_units;
-        const uint4* __restrict__ L = lut + (first & 1) * P + lane;
         float2* __restrict__ out = out_env0 + (size_t)ee * env_units;
-        uint4 ent[PASSES];
+        const int phase = (int)(first & 1);
+        if (phase != cache.phase) {                                  // wave-uniform
+            const uint4* __restrict__ L = lut + phase * P + lane;
 #pragma unroll
-        for (int c = 0; c < PASSES; ++c) ent[c] = L[c * 64];
+            for (int c = 0; c < PASSES; ++c) cache.ent[c] = L[c * 64];
+            cache.phase = phase;
+        }
+        uint4 (&ent)[PASSES] = cache.ent;
         f32x4 val[PASSES];
 #pragma unroll
         for (int c = 0; c < PASSES; ++c) {

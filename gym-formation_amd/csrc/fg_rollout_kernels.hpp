@@ -222,6 +222,7 @@ void rollout_kernel(const Args a) {
     // action prefetches, and no leftover prologue dependency makes the compiler drain them early
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
+    GatherEntries<(WR == FG_WR_GATHER ? NC : 2)> gather_entries;     // (the gather writer's table entries, see write_obs_gather)
     // hand-over step k: producers run step k+1 (consuming u_cur) while writers stream step k
     auto pipeline_step = [&](int k, const float2& u_cur, float2& u_nxt) {
         if (producer) {
@@ -240,7 +241,7 @@ void rollout_kernel(const Args a) {
                 else if constexpr (WR == FG_WR_GATHER)
                     write_obs_gather<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                  reinterpret_cast<const uint4*>(smemf + E * roll_block_floats(N)),
-                                                 reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
+                                                 reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El, gather_entries);
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1, STREAM>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                                 reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
