@@ -392,7 +392,7 @@ FG_DEV void build_gather_lut(uint4* __restrict__ lut, int t, int nthreads) {
 // changes only when the env pitch or the batch's slab is an odd number of units, so a writer wave reads its entries from LDS
 // once per launch instead of once per env and step (one of the two LDS round trips in front of every env's stores).
 template <int NC> struct GatherEntries {
-    uint4 ent[gather_passes<NC>()];
+    uint32_t ab0[gather_passes<NC>()], ab1[gather_passes<NC>()], dst[gather_passes<NC>()];   // a table entry's x, y, z (w is unused)
     int phase = -1;
 };
 
@@ -410,19 +410,21 @@ FG_DEV void write_obs_gather(const float2* __restrict__ tables0, int env_stride,
         if (phase != cache.phase) {                                  // wave-uniform
             const uint4* __restrict__ L = lut + phase * P + lane;
 #pragma unroll
-            for (int c = 0; c < PASSES; ++c) cache.ent[c] = L[c * 64];
+            for (int c = 0; c < PASSES; ++c) {
+                const uint4 t = L[c * 64];
+                cache.ab0[c] = t.x; cache.ab1[c] = t.y; cache.dst[c] = t.z;
+            }
             cache.phase = phase;
         }
-        uint4 (&ent)[PASSES] = cache.ent;
         f32x4 val[PASSES];
 #pragma unroll
         for (int c = 0; c < PASSES; ++c) {
-            const float2 A0 = T[ent[c].x & 0xffffu], B0 = T[ent[c].x >> 16], A1 = T[ent[c].y & 0xffffu], B1 = T[ent[c].y >> 16];
+            const float2 A0 = T[cache.ab0[c] & 0xffffu], B0 = T[cache.ab0[c] >> 16], A1 = T[cache.ab1[c] & 0xffffu], B1 = T[cache.ab1[c] >> 16];
             val[c] = (f32x4){A0.x - B0.x, A0.y - B0.y, A1.x - B1.x, A1.y - B1.y};
         }
 #pragma unroll
         for (int c = 0; c < PASSES; ++c) {
-            const unsigned kind = ent[c].z >> 16, dst = ent[c].z & 0xffffu;
+            const unsigned kind = cache.dst[c] >> 16, dst = cache.dst[c] & 0xffffu;
             if (kind == 2) *reinterpret_cast<f32x4*>(out + dst) = val[c];
             else if (kind == 1) out[dst] = make_float2(val[c].x, val[c].y);
         }

@@ -32,6 +32,28 @@ template <int NC, int WR, int NWW> constexpr int roll_writer_units() {
     else return 2 * NWW * tile_units<NC, WR - 1>();
 }
 
+// Dynamic LDS of rollout_kernel: env blocks | writer tiles / gather table | controller tables | reward hand-over.
+// The reward hand-over - shared reward, individual reward, done flag of the workgroup's E x N agents, two buffers like the tables -
+// lets the WRITER waves store them (lane-consecutive, whole 64-byte requests) so that the producer waves issue no store at all:
+// on gfx9 loads and stores share one counter, and a producer's wait for its prefetched action was also a wait for its own reward
+// stores behind the workgroup's observation stream.  Taken wherever it fits the 160 KiB.
+template <int NC, int TW, int E, int WR, int PER> constexpr int roll_lds_base_bytes() {
+    return E * roll_block_floats(NC) * (int)sizeof(float) + roll_writer_units<NC, WR, TW / 64>() * (int)sizeof(float2) +
+           (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
+}
+template <int NC, int E> constexpr int roll_rew_floats() { return 2 * 3 * E * NC; }
+template <int NC, int TW, int E, int WR, int PER> constexpr bool roll_rew_in_lds() {
+    // the gather-writer instantiations (8 / 9 agents: 8 % of their bytes are rewards and done flags, in 4-byte pieces from
+    // the producers); the tile-writer kernels of 16-32 agents have no registers to spare for it (the headline kernel would
+    // spill 16) and 1.4 % of their bytes to gain
+    return WR == FG_WR_GATHER &&
+           roll_lds_base_bytes<NC, TW, E, WR, PER>() + roll_rew_floats<NC, E>() * (int)sizeof(float) <= 160 * 1024;
+}
+template <int NC, int TW, int E, int WR, int PER> constexpr int roll_lds_bytes() {
+    return roll_lds_base_bytes<NC, TW, E, WR, PER>() +
+           (roll_rew_in_lds<NC, TW, E, WR, PER>() ? roll_rew_floats<NC, E>() * (int)sizeof(float) : 0);
+}
+
 // Workgroups of <= 512 threads must keep 4 waves per SIMD (<= 128 VGPRs): at 9 agents x >= 8192 envs two such
 // workgroups share a CU, and a build whose writer needed 133 VGPRs ran that shape at half the rate.  (The 8-ary controller
 // holds three 8-entry float2 tables per lane: its instantiations get the 168-register budget instead of spilling 57.)
@@ -102,6 +124,9 @@ void rollout_kernel(const Args a) {
     //        (9 x 4096 x 20 1.51 -> 1.59, 16 x 4096 4.18 -> 4.33) and keep
     //  else  one step ahead, two registers alternating roles over a loop unrolled by two, so that no copy (and with it the
     //        load's wait) lands inside the issuing step.
+    // (with the reward hand-over through LDS a producer issues no stores at all, yet the four-step batches stay: without them
+    // 8 x 65536 ran 18.0 -> 19.4 us/step and 9 x 16384 5.98 -> 6.16 - fewer, larger read events in a write-only stream are what
+    // they buy, profiles/r05_rew_lds_ab.txt)
     constexpr bool ACT4 = !POLICY && ((TP + TW) > 512 || WR == FG_WR_GATHER);
     float2 u_even = make_float2(0.f, 0.f), u_odd = u_even;
     const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
@@ -121,6 +146,9 @@ void rollout_kernel(const Args a) {
     // closed loop: controller tables of this env behind the env blocks and the writers' tiles
     float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW>() +
                             e * policy_block_units(N);
+    // reward hand-over (see roll_lds_base_bytes): [2][rew | indiv | done][E][N]
+    constexpr bool REWLDS = roll_rew_in_lds<NC, TW, E, WR, PER>();
+    float* const rew_lds = smemf + roll_lds_base_bytes<NC, TW, E, WR, PER>() / (int)sizeof(float);
 
     // one producer step: World.step + reward of step k into table buffer (k & 1);
     // u_cur = action of step k (loaded during step k-1), u_nxt receives the action of step k+1
@@ -175,10 +203,17 @@ void rollout_kernel(const Args a) {
         const float velterm = sqrtf(ex * ex + ey * ey);
         const bool is_done = t_step >= a.p.world_length;
         if (valid) {
-            const size_t o = ((size_t)k * a.B + b) * N + i;
-            if (a.rew) a.rew[o] = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
-            if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt;
-            if (a.done) a.done[o] = is_done ? 1 : 0;
+            const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            const float own = (-H - velterm) - (float)cnt;
+            if constexpr (REWLDS) {
+                float* const R = rew_lds + (k & 1) * 3 * E * N + e * N + i;
+                R[0] = shared; R[E * N] = own; reinterpret_cast<uint32_t*>(R)[2 * E * N] = is_done ? 1u : 0u;
+            } else {
+                const size_t o = ((size_t)k * a.B + b) * N + i;
+                if (a.rew) a.rew[o] = shared;
+                if (a.indiv) a.indiv[o] = own;
+                if (a.done) a.done[o] = is_done ? 1 : 0;
+            }
         }
         if (a.p.auto_reset) {
             const bool mine = is_done && env_ok;
@@ -228,6 +263,19 @@ void rollout_kernel(const Args a) {
         if (producer) {
             if (k + 1 < a.K) produce(k + 1, u_cur, u_nxt);
         } else {
+            if constexpr (REWLDS) {                          // step k's rewards and done flags: the workgroup's slice is contiguous
+                const float* const R = rew_lds + (k & 1) * 3 * E * N;
+                const int cnt = El * N;
+                const size_t o0 = ((size_t)k * a.B + b0) * N;
+                int q0 = tid - TP;
+                asm volatile("" : "+v"(q0));                // addresses made here from the step's scalar base, not three 64-bit
+                                                            // per-lane pointers kept (and spilled) across the step loop
+                for (int q = q0; q < cnt; q += TW) {
+                    if (a.rew) a.rew[o0 + q] = R[q];
+                    if (a.indiv) a.indiv[o0 + q] = R[E * N + q];
+                    if (a.done) a.done[o0 + q] = (uint8_t)reinterpret_cast<const uint32_t*>(R)[2 * E * N + q];
+                }
+            }
             int slot = k;
             bool want_obs = a.obs != nullptr;
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }

@@ -293,9 +293,7 @@ static int launch_wide(const Args& a, hipStream_t st) {
 template <int NC, int G, int TP, int TW, int E, int WR, int PER, bool STREAM = false>
 static int launch_roll_v(const Args& a, hipStream_t st) {
     const int grid = (a.B + E - 1) / E;
-    int lds = E * roll_block_floats(NC) * (int)sizeof(float);
-    lds += roll_writer_units<NC, WR, TW / 64>() * (int)sizeof(float2);
-    if (PER > 0) lds += E * policy_block_units(NC) * (int)sizeof(float2);
+    constexpr int lds = roll_lds_bytes<NC, TW, E, WR, PER>();     // env blocks, writer tiles, controller tables, reward hand-over
     if (describe("rollout_kernel<%d,%d,%d,%d,%d,%d,%d,%d> grid %d lds %d; ", NC, G, TP, TW, E, WR, PER, (int)STREAM, grid, lds)) return FG_OK;
     static std::atomic<unsigned long long> raised{0};
     hipError_t err = raise_lds_limit((const void*)&rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>, lds, &raised);
