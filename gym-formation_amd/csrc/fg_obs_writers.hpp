@@ -431,6 +431,68 @@ FG_DEV void write_obs_gather(const float2* __restrict__ tables0, int env_stride,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Span form of the gather writer: the E env blocks of a workgroup are ONE span of E * 3 N^2 units = E * 3 N^2 / 2 sixteen-byte
+// pieces, and when that span starts on a 16-byte boundary (a full workgroup of a contiguous tensor: its base is then even a
+// multiple of 64 bytes at 8 and 9 agents x 16 / 8 envs) store instruction p of the workgroup covers pieces [64 p, 64 p + 64):
+// 1 KiB at a 1 KiB-aligned offset of the span, every 64-byte write request whole.  The per-env form above starts each env's
+// instructions at the env's own base (1 944 bytes apart at 9 agents: 24 mod 64), so every instruction boundary splits a request
+// in two - ~34.5 requests per env instead of 30.4, and the store stream is bound by requests in flight.
+// Wave w of NW takes instructions w, w + NW, ...; which two units a lane stores in its t-th instruction, from which env's
+// tables, never changes: the operand offsets (relative to env 0's tables, < 64 Ki units) are computed once per launch into an
+// LDS table of one 8-byte entry per piece (it shares its place with the per-env form's table: a workgroup uses one of them).
+// ---------------------------------------------------------------------------
+template <int NC, int NW, int E, int CHMAX = 4> struct SpanGather {
+    static constexpr int ENVU = 3 * NC * NC, PIECES = E * ENVU / 2, INSTR = (PIECES + 63) / 64, MINE = (INSTR + NW - 1) / NW;
+    static_assert((E * ENVU) % 2 == 0, "an even number of units per workgroup span");
+    // table in LDS, one entry per piece: x = a | b << 16 of its first unit, y = of its second (unit = T[a] - T[b], T = env 0's
+    // tables); built once per launch by the writer waves themselves (each lane the entries it will read: no barrier needed)
+    static FG_DEV void setup(uint2* __restrict__ lut, int w, int env_stride) {
+        const int lane = threadIdx.x & 63;
+        auto operands = [&](int unit) -> uint32_t {               // unit of the span = T[a] - T[b]
+            const int e = unit / ENVU, q = unit - e * ENVU;
+            const int r = q / (3 * NC), u = q - r * (3 * NC);
+            uint32_t a, b;
+            if (u == 0) { a = NC; b = 4 * NC + r; }                // 0 - (-v_r): the operation the other writers do
+            else if (u < NC) { a = (u - 1 >= r) ? u : u - 1; b = r; }   // p_j - p_r, j != r in order
+            else { a = u; b = NC; }                                // zeros | ideal shape | ideal velocity: entry - 0
+            const uint32_t base = (uint32_t)(e * env_stride);
+            return (a + base) | ((b + base) << 16);
+        };
+        for (int t = 0; t < MINE; ++t) {
+            const int piece = (w + NW * t) * 64 + lane;
+            if (piece < PIECES) lut[piece] = make_uint2(operands(2 * piece), operands(2 * piece + 1));
+        }
+    }
+    // tables0: env 0's tables of this step's buffer; out: the workgroup's span (16-byte aligned)
+    static FG_DEV void write(const uint2* __restrict__ lut, const float2* __restrict__ tables0, int w, float2* __restrict__ out) {
+        const int lane = threadIdx.x & 63;
+        f32x4* const out4 = reinterpret_cast<f32x4*>(out);
+        constexpr int CH = MINE < CHMAX ? MINE : CHMAX;              // instructions whose operands are in flight together
+#pragma unroll
+        for (int t0 = 0; t0 < MINE; t0 += CH) {
+            uint2 ent[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int piece = (w + NW * (t0 + c)) * 64 + lane;
+                ent[c] = lut[(t0 + c < MINE && piece < PIECES) ? piece : 0];
+            }
+            f32x4 val[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const float2 A0 = tables0[ent[c].x & 0xffffu], B0 = tables0[ent[c].x >> 16];
+                const float2 A1 = tables0[ent[c].y & 0xffffu], B1 = tables0[ent[c].y >> 16];
+                val[c] = (f32x4){A0.x - B0.x, A0.y - B0.y, A1.x - B1.x, A1.y - B1.y};
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int piece = (w + NW * (t0 + c)) * 64 + lane;
+                if (t0 + c < MINE && piece < PIECES) out4[piece] = val[c];
+            }
+        }
+    }
+};
+
 }  // namespace fg
 
 #endif  // FG_OBS_WRITERS_HPP_

@@ -26,9 +26,10 @@ namespace fg {
 __host__ __device__ constexpr int roll_block_floats(int n) { return 20 * n + 6 * npad(n); }
 // LDS of the writer waves behind the env blocks, in float2 units: two tiles per wave (WR = 1 + rows per tile), the gather
 // writer's table (WR = FG_WR_GATHER), nothing for the rows writer (WR = 0)
-template <int NC, int WR, int NWW> constexpr int roll_writer_units() {
+template <int NC, int WR, int NWW, int E> constexpr int roll_writer_units() {
     if constexpr (WR == 0) return 0;
-    else if constexpr (WR == FG_WR_GATHER) return gather_lut_units<NC>();
+    else if constexpr (WR == FG_WR_GATHER)                                     // the per-env table or the span table (one entry per piece)
+        return gather_lut_units<NC>() > E * 3 * NC * NC / 2 ? gather_lut_units<NC>() : E * 3 * NC * NC / 2;
     else return 2 * NWW * tile_units<NC, WR - 1>();
 }
 
@@ -38,7 +39,7 @@ template <int NC, int WR, int NWW> constexpr int roll_writer_units() {
 // on gfx9 loads and stores share one counter, and a producer's wait for its prefetched action was also a wait for its own reward
 // stores behind the workgroup's observation stream.  Taken wherever it fits the 160 KiB.
 template <int NC, int TW, int E, int WR, int PER> constexpr int roll_lds_base_bytes() {
-    return E * roll_block_floats(NC) * (int)sizeof(float) + roll_writer_units<NC, WR, TW / 64>() * (int)sizeof(float2) +
+    return E * roll_block_floats(NC) * (int)sizeof(float) + roll_writer_units<NC, WR, TW / 64, E>() * (int)sizeof(float2) +
            (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
 }
 template <int NC, int E> constexpr int roll_rew_floats() { return 2 * 3 * E * NC; }
@@ -132,19 +133,23 @@ void rollout_kernel(const Args a) {
     const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
     const float2* const act0 = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0);
     const float2* act_next = act0 + (a.K > 1 ? act_stride : 0);
+    // (four-step batches: a scalar base per step + the lane's 32-bit offset, so that no 64-bit per-lane pointer is held - and,
+    // in the 128-register instantiations, spilled - across the step loop; B N < 2^29 entries)
+    const uint32_t lane_off = valid ? (uint32_t)sidx : 0u;
     float2 cur[4], nxt[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { cur[t] = make_float2(0.f, 0.f); nxt[t] = cur[t]; }
     auto load_batch = [&](float2 (&dst)[4], int j0) {          // actions of steps j0 ... j0 + 3 (clamped to the last step)
         if (valid) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) dst[t] = act0[(size_t)min(j0 + t, a.K - 1) * act_stride];
+            for (int t = 0; t < 4; ++t)
+                dst[t] = (reinterpret_cast<const float2*>(a.act) + (size_t)min(j0 + t, a.K - 1) * act_stride)[lane_off];
         }
     };
     if constexpr (ACT4) load_batch(cur, 0);
     else if (!POLICY && valid) u_even = *act0;
     // closed loop: controller tables of this env behind the env blocks and the writers' tiles
-    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW>() +
+    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW, E>() +
                             e * policy_block_units(N);
     // reward hand-over (see roll_lds_base_bytes): [2][rew | indiv | done][E][N]
     constexpr bool REWLDS = roll_rew_in_lds<NC, TW, E, WR, PER>();
@@ -235,8 +240,10 @@ void rollout_kernel(const Args a) {
                         v = make_float2(0.f, 0.f);
                         s = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
                         SX[i] = s.x; SY[i] = s.y;
-                        reinterpret_cast<float2*>(a.shape)[sidx] = s;
-                        if (i == 0) reinterpret_cast<float2*>(a.ivel)[b] = iv;
+                        int ir = i, br = b;                // opaque: the global addresses of this rarely taken branch are made
+                        asm volatile("" : "+v"(ir), "+v"(br));   // here, not kept in registers across the step loop
+                        reinterpret_cast<float2*>(a.shape)[(size_t)br * N + ir] = s;
+                        if (i == 0) reinterpret_cast<float2*>(a.ivel)[br] = iv;
                     }
                 }
             }
@@ -249,15 +256,27 @@ void rollout_kernel(const Args a) {
         }
     };
 
-    if constexpr (WR == FG_WR_GATHER)                     // the writers' table of operands, while the producers run step 0
-        if (!producer) build_gather_lut<NC>(reinterpret_cast<uint4*>(smemf + E * roll_block_floats(N)), tid - TP, TW);
+    // the span form of the gather writer for full workgroups of a contiguous tensor whose span starts on a 16-byte boundary
+    // (slot * B * 3 N^2 even: every step alike); partial workgroups, padded env pitches and odd slabs take the per-env form
+    constexpr bool SPAN_OK = WR == FG_WR_GATHER && (E * 3 * NC * NC) % 2 == 0 && (E - 1) * (roll_block_floats(NC) / 2) + 5 * NC < 32768;
+    using Span = SpanGather<(SPAN_OK ? NC : 2), NWW, (SPAN_OK ? E : 2), ((TP + TW) <= 512 ? 2 : 4)>;   // (128-register budget: two in flight)
+    uint2* const span_lut = reinterpret_cast<uint2*>(smemf + E * roll_block_floats(N));
+    bool use_span = false;
+    if constexpr (SPAN_OK)
+        use_span = El == E && a.obs_pitch == 3LL * N * N && (((size_t)a.B * (size_t)a.obs_pitch) & 1) == 0 &&
+                   (((size_t)b0 * (size_t)a.obs_pitch) & 1) == 0;
+    if constexpr (WR == FG_WR_GATHER) {                   // the writers' table of operands, while the producers run step 0
+        if (!producer) {
+            if (use_span) Span::setup(span_lut, (tid - TP) >> 6, roll_block_floats(N) / 2);
+            else build_gather_lut<NC>(reinterpret_cast<uint4*>(smemf + E * roll_block_floats(N)), tid - TP, TW);
+        }
+    }
     if (producer) __builtin_amdgcn_s_setprio(FG_PRODUCER_PRIO);   // the producers' dependent chain bounds small-N rollouts
     if (producer) produce(0, ACT4 ? cur[0] : u_even, u_odd);
     // every prologue load has landed before the loop: inside it the only loads in flight are the
     // action prefetches, and no leftover prologue dependency makes the compiler drain them early
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
-    GatherEntries<(WR == FG_WR_GATHER ? NC : 2)> gather_entries;     // (the gather writer's table entries, see write_obs_gather)
     // hand-over step k: producers run step k+1 (consuming u_cur) while writers stream step k
     auto pipeline_step = [&](int k, const float2& u_cur, float2& u_nxt) {
         if (producer) {
@@ -286,10 +305,16 @@ void rollout_kernel(const Args a) {
                 if constexpr (WR == 0)
                     write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                reinterpret_cast<float2*>(a.obs) + unit0, env_units, El, 3);
-                else if constexpr (WR == FG_WR_GATHER)
+                else if constexpr (WR == FG_WR_GATHER) {
+                  if (use_span)
+                    Span::write(span_lut, tables0, (tid - TP) >> 6, reinterpret_cast<float2*>(a.obs) + unit0);
+                  else {
+                    GatherEntries<(WR == FG_WR_GATHER ? NC : 2)> gather_entries;      // (the rare form: no state kept across steps)
                     write_obs_gather<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                  reinterpret_cast<const uint4*>(smemf + E * roll_block_floats(N)),
                                                  reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El, gather_entries);
+                  }
+                }
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1, STREAM>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                                 reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
@@ -314,7 +339,12 @@ void rollout_kernel(const Args a) {
             if (k + 1 < a.K) pipeline_step(k + 1, u_even, u_odd);
         }
     }
-    if (valid) { a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y; }
+    if (valid) {
+        int is = i, bs = b;                                // (opaque: the state's addresses are not held across the step loop)
+        asm volatile("" : "+v"(is), "+v"(bs));
+        const size_t so = (size_t)bs * N + is;
+        a.px[so] = p.x; a.py[so] = p.y; a.vx[so] = v.x; a.vy[so] = v.y;
+    }
     if (a.step && env_ok && i == 0) a.step[b] = t_step;
 }
 
