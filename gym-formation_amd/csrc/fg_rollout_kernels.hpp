@@ -659,6 +659,9 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             if (a.obs_every > 1) { want_obs = want_obs && ((k + 1) % a.obs_every == 0); slot = k / a.obs_every; }
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
+                // (1 KiB store instructions on the absolute 64-byte grid, every unit recomputed from two LDS reads - the span form of
+                // the gather writer - lose here: 81 x 2048 49.5 -> 54.7 us/step, 243 x 8192 1 740 -> 2 065, with eight writer
+                // waves 57 / 1 943: profiles/r05_wide_span_ab.txt.  The register-cached rows writer stays.)
                 write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, w,
                                            reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
