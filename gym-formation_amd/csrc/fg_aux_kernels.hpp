@@ -371,8 +371,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
     // agents of different mass / size / accel / max_speed / u_noise (FgParams.agent_props; core.py:45-109): the lane's own row;
     // its partners' mass and size are read from the table in the pair loops (a cold path: no reference scenario has them).
     // The obstacles keep the scenario's size and Entity's default mass 1 (formation_hd_obs_env.py:36-42).
+    // Column 6 of the table = the agent's flags (core.py:54-58), honoured as step_kernel's option path does: a pair needs both
+    // to collide (:292-293); against an immovable partner the force is taken as it is, not scaled by the mass ratio (:319-321);
+    // an immovable agent is not integrated (:266-267); a ghost passes through soft walls (:326-327); the penalties of an agent
+    // that does not collide are not counted (`if agent.collide:` in every reward callback).  The obstacles are ordinary colliders.
     const bool het = a.p.agent_props != nullptr;
     const AgentProps me = agent_props_of(a.p, i, het && i < N);
+    const int my_flags = (het && i < N) ? me.flags : 0;
     const float my_size = i < N ? (het ? me.size : 0.5f * a.p.dist_min) : 0.5f * (2.0f * a.sc.obstacle_size);
     const float my_mass = het ? (i < N ? me.mass : 1.0f) : a.p.mass;
     const int KS = a.K > 1 ? a.K : 1;
@@ -403,17 +408,22 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                     const int j = j0 + t;
                     const float2 q = qq[t];
                     float size_j = 0.5f * (j < N ? a.p.dist_min : 2.0f * a.sc.obstacle_size);
-                    if (het && j < N) size_j = a.p.agent_props[(size_t)j * FG_AGENT_PROPS + 1];
+                    int fj = 0;
+                    if (het && j < N) {
+                        size_j = a.p.agent_props[(size_t)j * FG_AGENT_PROPS + 1];
+                        fj = (int)a.p.agent_props[(size_t)j * FG_AGENT_PROPS + 6];
+                    }
                     const float dmin = my_size + size_j;
                     const float cut = dmin + 18.0f * k;
                     const float dx = p.x - q.x, dy = p.y - q.y;
                     const float d2 = dx * dx + dy * dy;
-                    if (j < NE && j != i && d2 < cut * cut) {
+                    if (j < NE && j != i && d2 < cut * cut && !((fj | my_flags) & FG_AGENT_NO_COLLIDE)) {
                         const float d = __builtin_amdgcn_sqrtf(d2);
                         const float x = (dmin - d) / k;
                         const float pen = k * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
                         float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
-                        if (het) c = ((j < N ? a.p.agent_props[(size_t)j * FG_AGENT_PROPS] : 1.0f) / my_mass) * c;   // core.py:314-317
+                        if (het && !(fj & FG_AGENT_IMMOVABLE))
+                            c = ((j < N ? a.p.agent_props[(size_t)j * FG_AGENT_PROPS] : 1.0f) / my_mass) * c;   // core.py:314-317
                         fx += dx * c; fy += dy * c;
                     }
                 }
@@ -423,11 +433,13 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
                 const float2 fa = action_force(a.p, me, u, (uint32_t)(b + a.p.env_index_base), (uint32_t)i, off);
                 fx += fa.x; fy += fa.y;
             }
-            if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy);
-            v.x = v.x * (1.0f - a.p.damping) + (fx / my_mass) * a.p.dt;
-            v.y = v.y * (1.0f - a.p.damping) + (fy / my_mass) * a.p.dt;
-            if (is_agent) v = clamp_speed(me.max_speed, v);
-            p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
+            if (a.p.num_walls > 0) wall_forces(a.p, p, my_size, fx, fy, (my_flags & FG_AGENT_GHOST) != 0);
+            if (!(my_flags & FG_AGENT_IMMOVABLE)) {
+                v.x = v.x * (1.0f - a.p.damping) + (fx / my_mass) * a.p.dt;
+                v.y = v.y * (1.0f - a.p.damping) + (fy / my_mass) * a.p.dt;
+                if (is_agent) v = clamp_speed(me.max_speed, v);
+                p.x += v.x * a.p.dt; p.y += v.y * a.p.dt;
+            }
             POST[i] = p;
             if (is_agent) {
                 a.px[sidx] = p.x; a.py[sidx] = p.y; a.vx[sidx] = v.x; a.vy[sidx] = v.y;
@@ -533,6 +545,7 @@ __global__ __launch_bounds__(T) void scn_kernel(const ScnArgs a) {
             cnt += (dx * dx + dy * dy < ot2) ? 1 : 0;
         }
     }
+    if (my_flags & FG_AGENT_NO_COLLIDE) cnt = 0;
     float cs[1] = {(float)cnt};
     env_reduce<G, T, 1, R_SUM, R_SUM, R_SUM, R_SUM>(cs, scratch);
     const bool is_done = t_step >= a.p.world_length;

@@ -233,7 +233,7 @@ class World(_Tracked):
     """B independent multi-agent worlds stepped in lock-step on one GPU.
 
     Constants and their reference defaults: core.py:113-139."""
-    _UNTRACKED = frozenset(("world_step", "_props", "_sig_cache", "_silent_cache", "_plain_cache", "_frozen_cache", "state_version"))   # hot path / caches
+    _UNTRACKED = frozenset(("world_step", "_props", "_sig_cache", "_silent_cache", "_frozen_cache", "state_version"))   # hot path / caches
 
     def __init__(self, world_length=50, num_envs=1, device=None):
         self.agents = []
@@ -340,17 +340,6 @@ class World(_Tracked):
             cache = (key, any((not a.movable) and a.silent for a in self.policy_agents))
             self._frozen_cache = cache
         return cache[1]
-
-    def require_plain_agents(self, who):
-        """Raises unless every agent is movable, colliding and not a ghost (cached behind the edit counter of the entities)."""
-        key = (_version[0], len(self.agents))
-        if getattr(self, "_plain_cache", None) != key:
-            odd = [a.name for a in self.agents if (not a.movable) or (not a.collide) or getattr(a, "ghost", False)]
-            if odd:
-                raise NotImplementedError("%s: immovable / non-colliding / ghost agents (%s) are honoured by formation_hd_env's "
-                                          "kernels only (core.py:54-58)" % (who, ", ".join(map(str, odd))))
-            self._plain_cache = key
-        return True
 
     def agent_props(self):
         """Device table float [N, 8] = (mass, size, accel, max_speed, u_noise, c_noise, flags, 0) per agent for

@@ -74,10 +74,8 @@ class Scenario(MtResetMixin, BaseScenario):
 
     def params(self, world, rng_offset=0, auto_reset=False):
         a0 = world.agents[0]
-        # The landmark-scenario kernels read mass / size / accel / max_speed / u_noise of the per-agent table only: an immovable,
-        # non-colliding or ghost agent (core.py:54-58) would silently be stepped like an ordinary one.  Only
-        # formation_hd_env's kernels honour those flags; here they are refused.
-        world.require_plain_agents(type(self).__name__)
+        # agents of different mass / size / accel / max_speed / u_noise and immovable, non-colliding or ghost agents
+        # (core.py:45-109, 54-58) travel in World.agent_props(): the run-time-count kernel honours every column
         p = world.native_params(collide_thresh=a0.size + a0.size, auto_reset=auto_reset, seed=self._seed,
                                 rng_offset=rng_offset)                                # :91
         # the device counter RNG (motor noise) is keyed by seed, GLOBAL env index and the per-step offset, like formation_hd_env's

@@ -140,9 +140,9 @@ typedef struct FgParams {
                                 With a table, `sensitivity` is the value for agents whose accel is None (5.0) and
                                 mass / dist_min / accel / max_speed / u_noise above are not read.  Honoured by
                                 fg_step_hd, fg_physics_step, fg_observe_hd, fg_rollout_hd, fg_rollout_hd_policy, and - columns
-                                [0] ... [4], the agents only: obstacles keep FgScenario.obstacle_size and unit mass - by
-                                fg_step_scenario, fg_step_basic, fg_rollout_scenario (penalty distance of a pair =
-                                collide_thresh / dist_min * (size_a + size_b)). */
+                                [0] ... [4] and [6], the agents only: obstacles keep FgScenario.obstacle_size, unit mass and
+                                are ordinary movable colliders - by fg_step_scenario, fg_step_basic, fg_rollout_scenario
+                                (penalty distance of a pair = collide_thresh / dist_min * (size_a + size_b)). */
     const float* comm_state;   /* optional DEVICE float [B][N][2] = AgentState.c of every agent (World.dim_c = 2): copied
                                 into the communication block of the observation, row i = c_j for j != i in index order
                                 (formation_hd_env.py:48-51,59); NULL = zeros, the silent agents of every reference

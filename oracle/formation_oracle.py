@@ -365,25 +365,32 @@ def observation_basic(pos, vel, landmarks, dtype=np.float64):
     return obs
 
 
-def reward_basic(pos, landmarks, P, dtype=np.float64):
+def reward_basic(pos, landmarks, P, dtype=np.float64, size=None, collide=None):
     """basic_formation_env.py:43-52: -sum_l min_a ||p_a - l|| - #{a (self
-    included): ||p_a - p_i|| < size_a + size_i}."""
+    included): ||p_a - p_i|| < size_a + size_i}; the count only `if agent.collide:` (:48).  size / collide: per agent [N]."""
     pos = np.asarray(pos, dtype=dtype); lm = np.asarray(landmarks, dtype=dtype)
     B, N, _ = pos.shape
     D = np.sqrt(((pos[:, :, None, :] - lm[:, None, :, :]) ** 2).sum(-1))   # [B,a,l]
     cover = D.min(1).sum(1)
     PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
-    cnt = (PD < dtype(P.collide_thresh)).sum(2)                # includes self
+    thr = dtype(P.collide_thresh)
+    if size is not None:
+        sz = np.asarray(size, dtype=dtype)
+        thr = (sz[:, None] + sz[None, :])[None]
+    cnt = (PD < thr).sum(2)                                    # includes self
+    if collide is not None:
+        cnt = np.where(np.asarray(collide, dtype=bool)[None, :], cnt, 0)
     indiv = -cover[:, None] - cnt
     return dict(indiv=indiv, shared=indiv.sum(1), cnt=cnt.astype(np.int32),
                 near_ag=D.argmin(1).astype(np.int32))
 
 
-def step_basic(state, act, P=None, dtype=np.float64):
+def step_basic(state, act, P=None, dtype=np.float64, **world_options):
+    """One env.step of basic_formation_env; world_options as `physics_step` takes them (per-agent mass / size / flags, walls)."""
     P = P or BasicParams()
-    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype)
+    pos, vel = physics_step(state["pos"], state["vel"], act, P, dtype, **world_options)
     step = np.asarray(state["step"]) + 1
-    out = reward_basic(pos, state["landmarks"], P, dtype)
+    out = reward_basic(pos, state["landmarks"], P, dtype, size=world_options.get("size"), collide=world_options.get("collide"))
     out["obs"] = observation_basic(pos, vel, state["landmarks"], dtype)
     N = pos.shape[1]
     out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]
@@ -705,28 +712,39 @@ def reset_scn(kind, seed, N):
                 obst_vel=np.tile(np.array(P.obstacle_vel), (1, M, 1)), step=np.zeros(1, dtype=np.int32))
 
 
-def physics_entities(pos, vel, force0, size, P, mass=None, max_speed=None):
-    """World.step over E movable colliding entities with per-entity size and mass
-    (core.py:240-277; force ratio m_b / m_a :314-317; speed clamp :271-276, NaN = None).  force0 = non-contact force per entity."""
+def physics_entities(pos, vel, force0, size, P, mass=None, max_speed=None, movable=None, collide=None, ghost=None, walls=None):
+    """World.step over E colliding entities with per-entity size and mass
+    (core.py:240-277; force ratio m_b / m_a :314-317; speed clamp :271-276, NaN = None).  force0 = non-contact force per entity.
+    movable / collide / ghost: per-entity booleans [E] (core.py:54-58), as in `physics_step`: a pair needs both to collide and
+    one to move (:292-295), the force against an immovable partner is not scaled by the mass ratio (:319-321), an immovable
+    entity takes no action force (:231) and keeps its state (:266-267), a ghost passes through soft walls (:326-327).
+    walls: as in `physics_step` (core.py:255-261)."""
     pos = np.asarray(pos, dtype=np.float64); vel = np.asarray(vel, dtype=np.float64)
     E = pos.shape[1]
     m = np.full(E, P.mass) if mass is None else np.asarray(mass, dtype=np.float64)
+    mov = np.ones(E, dtype=bool) if movable is None else np.asarray(movable, dtype=bool)
+    col = np.ones(E, dtype=bool) if collide is None else np.asarray(collide, dtype=bool)
     delta = pos[:, :, None, :] - pos[:, None, :, :]
     dist = np.sqrt((delta ** 2).sum(-1))
     dmin = size[:, None] + size[None, :]
     pen = softplus_penetration(dist, dmin[None], P.contact_margin)
     with np.errstate(invalid="ignore", divide="ignore"):
         f = P.contact_force * delta / dist[..., None] * pen[..., None]
-    f = (m[None, :] / m[:, None])[None, :, :, None] * f
-    f = np.where(np.eye(E, dtype=bool)[None, :, :, None], 0.0, f)
-    F = force0 + f.sum(2)
-    vel = vel * (1 - P.damping) + (F / m[None, :, None]) * P.dt
+    ratio = np.where(mov[:, None] & mov[None, :], m[None, :] / m[:, None], 1.0)
+    f = ratio[None, :, :, None] * f
+    pair = col[:, None] & col[None, :] & (mov[:, None] | mov[None, :]) & ~np.eye(E, dtype=bool)
+    f = np.where(pair[None, :, :, None], f, 0.0)
+    F = np.where(mov[None, :, None], force0, 0.0) + f.sum(2)
+    for w in (walls or []):
+        F = F + wall_force(pos, size[None, :], w, P, np.float64, ghost=ghost)
+    new_vel = vel * (1 - P.damping) + (F / m[None, :, None]) * P.dt
     if max_speed is not None:
         ms = np.asarray(max_speed, dtype=np.float64)[None, :, None]
-        speed = np.sqrt((vel ** 2).sum(-1, keepdims=True))
+        speed = np.sqrt((new_vel ** 2).sum(-1, keepdims=True))
         with np.errstate(invalid="ignore", divide="ignore"):
-            vel = np.where(speed > ms, vel / speed * ms, vel)
-    return pos + vel * P.dt, vel
+            new_vel = np.where(speed > ms, new_vel / speed * ms, new_vel)
+    keep = ~mov[None, :, None]
+    return np.where(keep, pos, pos + new_vel * P.dt), np.where(keep, vel, new_vel)
 
 
 def _hausdorff_centred(pos, lm):
@@ -753,10 +771,12 @@ def observation_scn(kind, pos, vel, lm, obst_pos, P):
     return np.concatenate((vel, lm_abs, ob_rel, rel[:, keep].reshape(B, N, 2 * (N - 1)), zeros), 2)
 
 
-def step_scn(kind, state, act, P=None, mass=None, size=None, max_speed=None):
+def step_scn(kind, state, act, P=None, mass=None, size=None, max_speed=None, movable=None, collide=None, ghost=None, walls=None):
     """One env.step of the three scenarios.  state: pos, vel [B,N,2], landmarks [B,L,2],
     obst_pos, obst_vel [B,M,2], step [B].  mass / size / max_speed: per-agent arrays [N] (core.py:45-109; the obstacles keep
-    the scenario's size and unit mass)."""
+    the scenario's size and unit mass).  movable / collide / ghost: per-agent booleans [N] (core.py:54-58; the obstacles are
+    ordinary movable colliders, formation_hd_obs_env.py:36-42); the penalties of an agent that does not collide are not
+    counted (`if agent.collide:`, formation_hd_partial_env.py:67, formation_hd_obs_env.py:91).  walls: core.py:255-261."""
     P = P or ScnParams(kind)
     pos = np.asarray(state["pos"], dtype=np.float64); vel = np.asarray(state["vel"], dtype=np.float64)
     act = np.asarray(act, dtype=np.float64)
@@ -769,8 +789,10 @@ def step_scn(kind, state, act, P=None, mass=None, size=None, max_speed=None):
     size = np.concatenate((asz, [P.obstacle_size] * M))
     F0 = np.concatenate((am[None, :, None] * P.sensitivity * act, np.zeros((B, M, 2))), 1)
     ems = None if max_speed is None else np.concatenate((np.asarray(max_speed, dtype=np.float64), [np.nan] * M))
+    ent = lambda flag, fill: None if flag is None else np.concatenate((np.asarray(flag, dtype=bool), [fill] * M))
     ep, ev = physics_entities(np.concatenate((pos, op), 1), np.concatenate((vel, ov), 1), F0, size, P,
-                              mass=np.concatenate((am, [1.0] * M)), max_speed=ems)
+                              mass=np.concatenate((am, [1.0] * M)), max_speed=ems, movable=ent(movable, True),
+                              collide=ent(collide, True), ghost=ent(ghost, False), walls=walls)
     pos, vel, op, ov = ep[:, :N], ev[:, :N], ep[:, N:], ev[:, N:]
     step = np.asarray(state["step"]) + 1
     lm = np.asarray(state["landmarks"], dtype=np.float64)
@@ -778,12 +800,13 @@ def step_scn(kind, state, act, P=None, mass=None, size=None, max_speed=None):
     PD = np.sqrt(((pos[:, :, None, :] - pos[:, None, :, :]) ** 2).sum(-1))
     close = PD < (asz[:, None] + asz[None, :])[None]           # is_collision: dist < size_a + size_b
     close[:, np.arange(N), np.arange(N)] = False
-    indiv = -H[:, None] - P.penalty * close.sum(2)
+    counted = np.ones(N, dtype=bool) if collide is None else np.asarray(collide, dtype=bool)
+    indiv = -H[:, None] - P.penalty * np.where(counted[None, :], close.sum(2), 0)
     if M:
         # reward side effect: obstacles keep falling until the floor (formation_hd_obs_env.py:84-89)
         ov = np.where((op[..., 1] > P.obstacle_floor)[..., None], np.array(P.obstacle_vel), 0.0)
         OD = np.sqrt(((pos[:, :, None, :] - op[:, None, :, :]) ** 2).sum(-1))
-        indiv = indiv - P.penalty * (OD < asz[None, :, None] + P.obstacle_size).sum(2)
+        indiv = indiv - P.penalty * np.where(counted[None, :], (OD < asz[None, :, None] + P.obstacle_size).sum(2), 0)
     out = dict(indiv=indiv, shared=indiv.sum(1), obs=observation_scn(kind, pos, vel, lm, op, P))
     out["reward"] = np.repeat(out["shared"][:, None], N, 1)[..., None]
     out["done"] = np.repeat((step >= P.world_length)[:, None], N, 1)

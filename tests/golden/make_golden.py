@@ -396,10 +396,29 @@ def rollout_action_mode(fg, mode, N, T, seed, act_seed):
     return res
 
 
-def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None, hetero=None):
-    """Seeded rollout of one of the remaining scenarios (formation_hd_partial_env,
+def _scn_world_options(env, hetero=None, flags=None, walls=False):
+    """hetero: per-agent mass / size / max_speed (core.py:45-109); flags: Entity.movable / collide / ghost per agent
+    (core.py:54-58); walls: WALLS + SOFT_WALLS (core.py:255-261, 325-362) - all on top of the scenario's own make_world."""
+    import formation_gym.core as rcore
+    if hetero:
+        for a, m_, s_, ms_ in zip(env.world.agents, hetero["mass"], hetero["size"], hetero["max_speed"]):
+            a.initial_mass = float(m_); a.size = float(s_)
+            a.max_speed = None if np.isnan(ms_) else float(ms_)
+    if flags:
+        for i, a in enumerate(env.world.agents):
+            a.collide = bool(flags["collide"][i]); a.ghost = bool(flags["ghost"][i])
+            if "movable" in flags:
+                a.movable = bool(flags["movable"][i])
+    if walls:
+        env.world.walls = ([rcore.Wall(o, ax, ep, w) for (o, ax, ep, w) in WALLS] +
+                           [rcore.Wall(o, ax, ep, w, hard=False) for (o, ax, ep, w) in SOFT_WALLS])
+
+
+def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None, hetero=None, flags=None, walls=False):
+    """Seeded rollout of one of the landmark scenarios (basic_formation_env, formation_hd_partial_env,
     formation_hd_partial_range_env, formation_hd_obs_env) through the reference API.  hetero: per-agent mass / size /
-    max_speed (core.py:45-109) on top of the file's own make_world - the obstacles keep theirs."""
+    max_speed (core.py:45-109) on top of the file's own make_world - the obstacles keep theirs; flags: agents that do not
+    collide, ghosts (core.py:54-58); walls: WALLS + SOFT_WALLS."""
     acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, B, N, 2)).astype(np.float32)
     keys = ("pos", "vel", "lm", "lmvel", "obs", "indiv", "shared", "done")
     out = {k: [] for k in keys}
@@ -407,10 +426,7 @@ def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None, hetero=None):
     meta = {}
     for b in range(B):
         env = fg.make_env(name, False, N)
-        if hetero:
-            for a, m_, s_, ms_ in zip(env.world.agents, hetero["mass"], hetero["size"], hetero["max_speed"]):
-                a.initial_mass = float(m_); a.size = float(s_)
-                a.max_speed = None if np.isnan(ms_) else float(ms_)
+        _scn_world_options(env, hetero, flags, walls)
         env.seed(seed + 1000 * b)
         o0 = env.reset()
         if crowd is not None:
@@ -448,6 +464,55 @@ def rollout_scn(fg, name, N, B, T, seed, act_seed, crowd=None, hetero=None):
                crowd=np.array(-1.0 if crowd is None else crowd))
     if hetero:
         res.update({"agent_" + k: np.array(v, dtype=np.float64) for k, v in hetero.items()})
+    if flags:
+        res.update({"agent_" + k: np.array(v, dtype=np.bool_) for k, v in flags.items()})
+    return res
+
+
+def scn_immovable_fixture(fg, name, N, T, seed, act_seed, crowd, hetero, flags):
+    """An immovable agent (core.py:231, 266-267, 294-295, 319-321) in a landmark scenario, next to non-colliding agents, ghosts,
+    walls and (formation_hd_obs_env) the falling obstacles, which are pushed by the immovable agent with the plain force
+    (:319-321).  env.step cannot take a silent immovable agent (environment.py:236, fixture hd_n6_immovable), so the World is
+    driven through core.py's own API: action.u = 5 * action (environment.py:216-221), world.step(), then the scenario's
+    observation and reward callbacks per agent in env.step's order (the obstacle scenario's reward re-arms the obstacle
+    velocities, formation_hd_obs_env.py:84-89)."""
+    env = fg.make_env(name, False, N)
+    _scn_world_options(env, hetero, flags, walls=True)
+    sc = _scenario_of(env)
+    world = env.world
+    env.seed(seed)
+    env.reset()
+    for a in world.agents:
+        a.state.p_pos = a.state.p_pos * crowd
+    for i, a in enumerate(world.agents):
+        if not a.movable:
+            a.state.p_vel = np.array([0.25, -0.15])               # an immovable agent keeps whatever velocity it has
+    if name == "formation_hd_obs_env":                            # bring the obstacles down to the agents
+        for k, l in enumerate(world.landmarks[sc.num_landmarks:]):
+            l.state.p_pos = np.array([0.3 * (k - 1), 0.45 + 0.05 * k])
+    lm = lambda: np.array([l.state.p_pos for l in world.landmarks], dtype=np.float64)
+    lmv = lambda: np.array([l.state.p_vel for l in world.landmarks], dtype=np.float64)
+    p0, v0 = _state(env)
+    init = dict(pos0=p0[None], vel0=v0[None], lm0=lm()[None], lmvel0=lmv()[None])
+    acts = np.random.RandomState(act_seed).uniform(-1, 1, (T, 1, N, 2)).astype(np.float32)
+    keys = ("pos", "vel", "lm", "lmvel", "obs", "indiv")
+    rec = {k: [] for k in keys}
+    for t in range(T):
+        for i, a in enumerate(world.agents):
+            a.action.u = 5.0 * acts[t, 0, i].astype(np.float64)
+        world.step()
+        obs_n, rew_n = [], []
+        for a in world.agents:
+            obs_n.append(sc.observation(a, world)); rew_n.append(sc.reward(a, world))
+        p, v = _state(env)
+        rec["pos"].append(p[None]); rec["vel"].append(v[None]); rec["lm"].append(lm()[None]); rec["lmvel"].append(lmv()[None])
+        rec["obs"].append(np.array(obs_n, dtype=np.float64)[None]); rec["indiv"].append(np.array(rew_n, dtype=np.float64)[None])
+    res = {k: np.array(v) for k, v in rec.items()}                # [T,1,...]
+    res.update(init)
+    res.update(acts=acts, seed=np.array(seed), act_seed=np.array(act_seed), crowd=np.array(crowd),
+               num_landmarks=np.array(getattr(sc, "num_landmarks", len(world.landmarks))))
+    res.update({"agent_" + k: np.array(v, dtype=np.float64) for k, v in hetero.items()})
+    res.update({"agent_" + k: np.array(v, dtype=np.bool_) for k, v in flags.items()})
     return res
 
 
@@ -753,6 +818,26 @@ def main():
     save("partial_n6_masses", lambda: rollout_scn(fg, "formation_hd_partial_env", 6, 2, 14, seed=59, act_seed=69, crowd=0.12,
                                                   hetero=dict(mass=[0.5, 1.0, 2.0, 3.0, 1.5, 0.7], size=[0.03, 0.05, 0.07, 0.04, 0.06, 0.05],
                                                               max_speed=[np.nan] * 6)))
+    # agents that do not collide and ghosts among walls (a soft one too) in the landmark scenarios, through env.step
+    save("obst_n5_flags", lambda: rollout_scn(fg, "formation_hd_obs_env", 5, 2, 30, seed=111, act_seed=112, crowd=0.3, walls=True,
+                                              hetero=dict(mass=[0.7, 1.0, 2.0, 1.3, 0.9], size=[0.07, 0.1, 0.13, 0.09, 0.11],
+                                                          max_speed=[np.nan, 0.6, np.nan, np.nan, np.nan]),
+                                              flags=dict(collide=[True, True, False, True, True], ghost=[False, True, False, False, True])))
+    save("basic_n4_flags", lambda: rollout_scn(fg, "basic_formation_env", 4, 2, 16, seed=113, act_seed=114, crowd=0.12, walls=True,
+                                               hetero=dict(mass=[1.0, 0.6, 1.8, 1.2], size=[0.15, 0.1, 0.2, 0.12],
+                                                           max_speed=[np.nan] * 4),
+                                               flags=dict(collide=[True, False, True, True], ghost=[True, False, False, False])))
+    # ... and with an immovable agent, driven through the World API
+    save("obst_n5_immovable", lambda: scn_immovable_fixture(
+        fg, "formation_hd_obs_env", 5, 24, seed=115, act_seed=116, crowd=0.3,
+        hetero=dict(mass=[0.7, 1.0, 2.0, 1.3, 0.9], size=[0.07, 0.1, 0.13, 0.09, 0.11], max_speed=[np.nan] * 5),
+        flags=dict(movable=[True, False, True, True, True], collide=[True, True, True, False, True],
+                   ghost=[False, False, True, False, False])))
+    save("partial_n6_immovable", lambda: scn_immovable_fixture(
+        fg, "formation_hd_partial_env", 6, 14, seed=117, act_seed=118, crowd=0.12,
+        hetero=dict(mass=[0.5, 1.0, 2.0, 3.0, 1.5, 0.7], size=[0.03, 0.05, 0.07, 0.04, 0.06, 0.05], max_speed=[np.nan] * 6),
+        flags=dict(movable=[True, True, False, True, True, False], collide=[True, True, True, True, False, True],
+                   ghost=[False, True, False, False, False, False])))
 
 
 if __name__ == "__main__":

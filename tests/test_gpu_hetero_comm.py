@@ -370,21 +370,106 @@ def test_random_entity_flags_against_oracle(N, B):
     assert (out["cnt"][:, ~collide] == 0).all() and out["cnt"].sum() > 0
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["basic_formation_env", "formation_hd_partial_env", "formation_hd_obs_env"])
-def test_landmark_scenarios_refuse_flagged_agents(name):
-    """The landmark-scenario kernels read only mass / size / accel / max_speed / u_noise of the per-agent table: an immovable,
-    non-colliding or ghost agent must be refused, not silently stepped like an ordinary one."""
-    env = formation_gym.make_env(name, False, 3, num_envs=4, device="cuda:0")
-    env.seed(0); env.reset()
-    act = torch.zeros((4, 3, 2), device="cuda:0")
-    env.step(act)                                                        # ordinary agents: fine
-    for attr, val in (("movable", False), ("collide", False), ("ghost", True)):
-        setattr(env.world.agents[1], attr, val)
-        with pytest.raises((NotImplementedError, AssertionError)):
-            env.step(act)
-        setattr(env.world.agents[1], attr, not val)
-    env.step(act)
+def _scn_env(g, scenario, B, movable=True):
+    """A landmark-scenario env with the fixture's per-agent mass / size / max_speed, flags and walls."""
+    from formation_gym.core import Wall
+    N = g["acts"].shape[2]
+    env = _make(N, B, scenario)
+    for i, a in enumerate(env.world.agents):
+        a.initial_mass = float(g["agent_mass"][i]); a.size = float(g["agent_size"][i])
+        ms = g["agent_max_speed"][i]
+        a.max_speed = None if np.isnan(ms) else float(ms)
+        a.collide = bool(g["agent_collide"][i]); a.ghost = bool(g["agent_ghost"][i])
+        if movable and "agent_movable" in g:
+            a.movable = bool(g["agent_movable"][i])
+    env.world.walls = ([Wall(o, ax, ep, w) for (o, ax, ep, w) in O.GOLDEN_WALLS] +
+                       [Wall(o, ax, ep, w, hard=False) for (o, ax, ep, w) in O.GOLDEN_SOFT_WALLS])
+    return env
+
+
+def _scn_load(env, g, t, L, rep=1):
+    """State before step t of the fixture (teacher forcing), every fixture env `rep` times."""
+    src = (lambda k: np.repeat(g[k + "0"], rep, 0)) if t == 0 else (lambda k: np.repeat(g[k][t - 1], rep, 0))
+    env.world.set_state(src("pos"), src("vel"))
+    lm, lmvel = src("lm"), src("lmvel")
+    env.world.landmark_pos.copy_(torch.as_tensor(lm[:, :L], dtype=torch.float32))
+    if lm.shape[1] > L:
+        env.world.obstacle_pos.copy_(torch.as_tensor(lm[:, L:], dtype=torch.float32))
+        env.world.obstacle_vel.copy_(torch.as_tensor(lmvel[:, L:], dtype=torch.float32))
+    env.world.step_count.fill_(t)
+
+
+def _scn_check(env, g, t, L, obs, indiv, rep=1):
+    pos, vel = env.world.get_state()
+    np.testing.assert_allclose(_np(pos)[::rep], g["pos"][t], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(vel)[::rep], g["vel"][t], rtol=0, atol=ATOL)
+    if g["lm"].shape[2] > L:
+        np.testing.assert_allclose(_np(env.world.obstacle_pos)[::rep], g["lm"][t][:, L:], rtol=0, atol=ATOL)
+        np.testing.assert_allclose(_np(env.world.obstacle_vel)[::rep], g["lmvel"][t][:, L:], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(_np(obs)[::rep], g["obs"][t], rtol=0, atol=ATOL)
+    bad = np.abs(_np(indiv)[::rep] - g["indiv"][t]) > ATOL
+    if bad.any():                                            # integers: excuse only a pair sitting on its threshold
+        sz = g["agent_size"]
+        N = len(sz)
+        PD = np.sqrt(((g["pos"][t][:, :, None] - g["pos"][t][:, None]) ** 2).sum(-1)) + 10 * np.eye(N)
+        assert np.abs(PD - (sz[:, None] + sz[None, :])).min() < 1e-5, "individual reward mismatch away from a threshold"
+
+
+@pytest.mark.parametrize("scenario,name", [("formation_hd_obs_env", "obst_n5_flags"), ("basic_formation_env", "basic_n4_flags")])
+def test_landmark_scenarios_with_flagged_agents(golden, scenario, name):
+    """Agents that do not collide and ghosts (core.py:54-58, 292-293, 326-327) with per-agent mass / size among hard and soft
+    walls in the landmark scenarios, through env.step: column 6 of FgParams.agent_props in the run-time-count scenario kernel
+    (these were stepped like ordinary agents, then refused; now honoured).  Teacher-forced against the reference at
+    1e-5; a K-step launch equals single steps bit for bit."""
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    L = int(g["num_landmarks"])
+    env = _scn_env(g, scenario, B)
+    free = g["indiv"][..., ~g["agent_collide"]]
+    for t in range(T):
+        _scn_load(env, g, t, L)
+        obs, rew, done, info = env.step(torch.as_tensor(g["acts"][t]).cuda())
+        _scn_check(env, g, t, L, obs, info["individual_reward"])
+        np.testing.assert_array_equal(done.cpu().numpy(), g["done"][t])
+    # the agent that does not collide collects no penalty: its reward is the formation term alone, the best of its env
+    assert (free >= g["indiv"].max(-1, keepdims=True) - 1e-9).all() and (g["indiv"].min(-1) < g["indiv"].max(-1) - 0.5).any()
+    a, b = _scn_env(g, scenario, B), _scn_env(g, scenario, B)
+    for e in (a, b):
+        _scn_load(e, g, 0, L)
+    acts = torch.as_tensor(g["acts"][:8]).cuda().contiguous()
+    o_seq, r_seq, d_seq, i_seq = b.rollout(acts)
+    for t in range(8):
+        o, r, d, i = a.step(acts[t])
+        assert torch.equal(o, o_seq[t]) and torch.equal(r, r_seq[t]) and torch.equal(i["individual_reward"], i_seq["individual_reward"][t])
+
+
+@pytest.mark.parametrize("scenario,name", [("formation_hd_obs_env", "obst_n5_immovable"), ("formation_hd_partial_env", "partial_n6_immovable")])
+def test_landmark_scenarios_with_an_immovable_agent(golden, scenario, name):
+    """An immovable agent (core.py:231, 266-267, 294-295, 319-321) in a landmark scenario: it keeps position and velocity,
+    pushes its neighbours and the falling obstacles with the plain force (no mass ratio).  The reference's env.step asserts on
+    a silent immovable agent (environment.py:236) and so does this one; the fixture was made through core.py's World API
+    (world.step, then Scenario.observation / reward per agent) - its counterpart here is the scenario's batch step."""
+    g = golden(name)
+    T, _, N = g["acts"].shape[:3]
+    L = int(g["num_landmarks"])
+    rep = 3
+    env = _scn_env(g, scenario, rep)
+    with pytest.raises(AssertionError):
+        env.step(torch.zeros((rep, N, 2), device="cuda"))
+    frozen = ~g["agent_movable"]
+    for t in range(T):
+        _scn_load(env, g, t, L, rep)
+        act = torch.as_tensor(np.repeat(g["acts"][t], rep, 0)).cuda().contiguous()
+        env.scenario.step_batch(env.world, act, env._out)
+        _scn_check(env, g, t, L, env._out["obs"], env._out["indiv"], rep)
+        pos, vel = env.world.get_state()
+        assert np.array_equal(_np(pos)[:, frozen], np.repeat(g["pos0"], rep, 0)[:, frozen].astype(np.float32))
+        assert np.array_equal(_np(vel)[:, frozen], np.repeat(g["vel0"], rep, 0)[:, frozen].astype(np.float32))
+    # the same steps with that agent movable end elsewhere: the flag is what the kernel honoured
+    other = _scn_env(g, scenario, 1, movable=False)
+    _scn_load(other, g, 0, L)
+    other.scenario.step_batch(other.world, torch.as_tensor(g["acts"][0]).cuda().contiguous(), other._out)
+    assert np.abs(_np(other.world.get_state()[0]) - g["pos"][0]).max() > 1e-3
 
 
 @pytest.mark.parametrize("dim_c", [1, 3, 5])

@@ -493,6 +493,59 @@ def test_scripted_agents_match_reference(golden):
     assert np.abs(pos2[0] - g["pos"][-1]).max() > 1e-3
 
 
+ALL_WALLS = O.GOLDEN_WALLS + [w + (False,) for w in O.GOLDEN_SOFT_WALLS]
+
+
+@pytest.mark.parametrize("kind,name", [("obstacle", "obst_n5_flags"), ("obstacle", "obst_n5_immovable"), ("partial", "partial_n6_immovable")])
+def test_landmark_scenarios_with_flagged_agents_match_reference(golden, kind, name):
+    """Agents that do not collide, ghosts, an immovable agent (core.py:54-58) among walls in the landmark scenarios: the
+    restatement against the reference (obst_n5_flags through env.step, the immovable fixtures through core.py's World API)."""
+    g = golden(name)
+    P = O.ScnParams(kind)
+    T = g["acts"].shape[0]
+    movable = g["agent_movable"] if "agent_movable" in g else None
+    seen = 0
+    for t in range(T):
+        prev = _scn_state(g, P, t - 1) if t else _scn_state(g, P)
+        new, out = O.step_scn(kind, prev, g["acts"][t].astype(np.float64), P, mass=g["agent_mass"], size=g["agent_size"],
+                              max_speed=g["agent_max_speed"], movable=movable, collide=g["agent_collide"],
+                              ghost=g["agent_ghost"], walls=ALL_WALLS)
+        np.testing.assert_allclose(new["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(new["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(new["obst_pos"], g["lm"][t][:, P.num_landmarks:], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+        # the flags matter: the same step with ordinary agents goes elsewhere
+        plain, _ = O.step_scn(kind, prev, g["acts"][t].astype(np.float64), P, mass=g["agent_mass"], size=g["agent_size"],
+                              max_speed=g["agent_max_speed"], walls=ALL_WALLS)
+        seen += int(np.abs(plain["pos"] - new["pos"]).max() > 1e-4)
+    assert seen > T // 4
+    if movable is not None:
+        frozen = ~movable
+        assert np.array_equal(g["pos"][-1][:, frozen], g["pos0"][:, frozen]) and np.array_equal(g["vel"][-1][:, frozen], g["vel0"][:, frozen])
+        assert np.abs(g["vel0"][:, frozen]).min() > 0.1       # ... whatever velocity it had
+
+
+def test_basic_scenario_with_flagged_agents_matches_reference(golden):
+    """basic_formation_env with per-agent mass / size, an agent that does not collide (no contact force, no penalties - the self
+    "collision" of :48-51 included), a ghost and the walls."""
+    g = golden("basic_n4_flags")
+    P = O.BasicParams()
+    T, B = g["acts"].shape[:2]
+    opts = dict(mass=g["agent_mass"], size=g["agent_size"], collide=g["agent_collide"], ghost=g["agent_ghost"], walls=ALL_WALLS)
+    for t in range(T):
+        src = (lambda k: g[k + "0"]) if t == 0 else (lambda k: g[k][t - 1])
+        st = dict(pos=src("pos"), vel=src("vel"), landmarks=src("lm"), step=np.full(B, t))
+        new, out = O.step_basic(st, g["acts"][t].astype(np.float64), P, **opts)
+        np.testing.assert_allclose(new["pos"], g["pos"][t], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(new["vel"], g["vel"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["obs"], g["obs"][t], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(out["indiv"], g["indiv"][t], rtol=0, atol=1e-10)
+    cnt = np.round(-g["indiv"] - (-g["indiv"]).min(2, keepdims=True))
+    assert (g["indiv"][..., ~g["agent_collide"]] > g["indiv"][..., g["agent_collide"]].max(-1, keepdims=True) - 1e-9).all()
+    assert cnt.max() >= 1
+
+
 @pytest.mark.parametrize("kind,name", [("obstacle", "obst_n5_masses"), ("partial", "partial_n6_masses")])
 def test_landmark_scenarios_with_per_agent_tables_match_reference(golden, kind, name):
     g = golden(name)
