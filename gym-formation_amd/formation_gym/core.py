@@ -362,19 +362,23 @@ class World(_Tracked):
             self._props = (sig, torch.tensor(rows, dtype=torch.float32, device=self.device), alike)
         return self._props[1]
 
-    def set_state(self, pos=None, vel=None):
-        """Upload [B,N,2] positions / velocities (any array-like, or a tensor on any device) into the SoA tensors."""
+    def set_state(self, pos=None, vel=None, mask=None):
+        """Upload [B,N,2] positions / velocities (any array-like, or a tensor on any device) into the SoA tensors.
+        mask: bool [B] on the device - only those envs take the new values (a device-side select: no synchronisation)."""
         def as_dev(x):
             if not torch.is_tensor(x):
                 x = torch.as_tensor(np.asarray(x), dtype=torch.float32)
             return x.to(device=self.device, dtype=torch.float32)
         self.state_version += 1
+
+        def put(dst, src):
+            dst.copy_(src if mask is None else torch.where(mask[:, None], src, dst))
         if pos is not None:
             pos = as_dev(pos)
-            self.pos_x.copy_(pos[..., 0]); self.pos_y.copy_(pos[..., 1])
+            put(self.pos_x, pos[..., 0]); put(self.pos_y, pos[..., 1])
         if vel is not None:
             vel = as_dev(vel)
-            self.vel_x.copy_(vel[..., 0]); self.vel_y.copy_(vel[..., 1])
+            put(self.vel_x, vel[..., 0]); put(self.vel_y, vel[..., 1])
 
     def get_state(self):
         """(pos[B,N,2], vel[B,N,2]) as new tensors."""
@@ -438,13 +442,15 @@ class World(_Tracked):
                 tuple((w.orient, float(w.axis_pos), float(w.endpoints[0]), float(w.endpoints[1]), float(w.width), w.hard)
                       for w in self.walls))
 
-    def step(self, sensitivity=5.0):
+    def step(self, sensitivity=5.0, rng_offset=None):
         """World.step (core.py:206-225) for all envs: action force, all-pairs
         contact force, integration - one HIP launch.  `action_u` holds the RAW
-        action; environment.py:216-221's sensitivity scaling happens in-kernel."""
+        action; environment.py:216-221's sensitivity scaling happens in-kernel.
+        rng_offset: the offset of the motor-noise draws (default: this world's own step count - fresh draws every step)."""
         self.world_step += 1
         self.run_scripted_agents()                        # core.py:210-211
-        p = self.native_params(sensitivity=sensitivity, rng_offset=self.world_step, scripted_ok=True)   # motor noise: fresh draws every step
+        p = self.native_params(sensitivity=sensitivity, rng_offset=self.world_step if rng_offset is None else rng_offset,
+                               scripted_ok=True)
         lib = _native.load()
         _native.check(lib.fg_physics_step(
             p, self.num_envs, len(self.agents),

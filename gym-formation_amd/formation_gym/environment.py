@@ -103,7 +103,8 @@ class MultiAgentEnv(object):
         self._roll_launchers = {}         # pre-bound K-step launches into caller-owned buffers, see rollout
         self.placement = None             # report of the last buffer placement probe (alloc_rollout_buffers)
         self._auto_out = {}               # (K, obs_every, policy) -> placed output buffers of rollout(out=None), see _default_out
-        self.default_placed = True        # rollout(out=None): env-owned, placed, re-used buffers (False: fresh tensors per call)
+        # rollout(out=None): env-owned, placed, re-used buffers (False: fresh tensors per call)
+        self.default_placed = bool(getattr(self.scenario, "DEFAULT_PLACED", True))
         self.shared_viewer = shared_viewer
         self.viewers = [None]
 
@@ -329,11 +330,14 @@ class MultiAgentEnv(object):
                if torch.is_tensor(getattr(w, k, None))}
         scn = {k: getattr(sc, k).clone() for k in ("ideal_shape", "ideal_vel") if torch.is_tensor(getattr(sc, k, None))}
         ctr = None if w.rng_counter is None else w.rng_counter.clone()
-        return dev, scn, ctr, (self._rng_offset, self.current_step, w.world_step)
+        own = sc.snapshot_state() if hasattr(sc, "snapshot_state") else None      # a tensor scenario's per-env tensors, its generator
+        return dev, scn, ctr, (self._rng_offset, self.current_step, w.world_step), own
 
     def _restore(self, snap):
-        dev, scn, ctr, host = snap
+        dev, scn, ctr, host, own = snap
         w, sc = self.world, self.scenario
+        if own is not None:
+            sc.restore_state(own)
         for k, v in dev.items():
             getattr(w, k).copy_(v)
         for k, v in scn.items():

@@ -201,6 +201,9 @@ class CapturedLoop(object):
         self.buf["obs"][T - 1].copy_(env._out["obs"])
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        gen = getattr(env.scenario, "generator", None)                  # a tensor scenario's resets draw from its own generator:
+        if gen is not None:                                             # the graph advances its offset with every replay
+            self.graph.register_generator_state(gen)
         with torch.cuda.graph(self.graph, stream=side):
             self._body()
         env._restore(snap)                                              # capture executes nothing; host counters did move

@@ -1,5 +1,7 @@
 """Host-side logic that needs no GPU: spaces, scenario plugin loading, the
 reference-style action staging rules."""
+import os
+
 import numpy as np
 import pytest
 
@@ -84,3 +86,44 @@ def test_arena_geometry_for_the_bench_shapes():
     assert placement.next_arena_bytes(140 << 30, 6 << 30, 280 << 30) is None
     assert placement.next_arena_bytes(87 << 30, 58 << 30, 280 << 30) is None        # 243 x 8192: already most of what is free
     assert placement.next_arena_bytes(8 << 30, 1 << 30, 20 << 30) is None
+
+
+def test_tensor_plugin_callbacks_equal_the_per_agent_file():
+    """tests/plugins/ring_patrol_tensor_env.py (the batched-callback contract, formation_gym/tensor_scenario.py) states the
+    observation / reward of tests/plugins/ring_patrol_env.py (the reference's per-agent plugin API) on tensors: the same numbers
+    on a hand-made state, on the CPU (the GPU suite holds both against the reference's fixture: test_gpu_tensor_scenario.py)."""
+    import importlib.util
+    import torch
+
+    def load(name):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", name + ".py")
+        spec = importlib.util.spec_from_file_location("plugin_" + name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m.Scenario()
+
+    class Obj(object):
+        pass
+    B, N = 4, 6
+    batched, per_agent = load("ring_patrol_tensor_env"), load("ring_patrol_env")
+    w = Obj(); w.num_envs = B; w.device = torch.device("cpu"); w.agents = []; w.landmarks = []
+    batched.build_world(w, N)
+    rs = np.random.RandomState(3)
+    pos, vel = rs.uniform(-.25, .25, (B, N, 2)), rs.uniform(-1, 1, (B, N, 2))
+    beacon, radius = rs.uniform(-.3, .3, (B, 1, 2)), rs.uniform(.3, .6, B)
+    pos[1, 2] = pos[1, 4] + [0.01, 0.0]                                    # a pair in contact
+    w.get_state = lambda: (torch.as_tensor(pos, dtype=torch.float32), torch.as_tensor(vel, dtype=torch.float32))
+    w.landmark_pos = torch.as_tensor(beacon, dtype=torch.float32)
+    batched.radius = torch.as_tensor(radius, dtype=torch.float32)
+    obs, rew = batched.observation_batch(w).numpy(), batched.reward_batch(w).numpy()
+    assert obs.shape == (B, N, 6 + 3 * (N - 1)) and rew.shape == (B, N)
+    for b in range(B):
+        hw = Obj(); hw.agents = []; hw.landmarks = [Obj()]
+        hw.landmarks[0].state = Obj(); hw.landmarks[0].state.p_pos = beacon[b, 0]
+        for i in range(N):
+            a = Obj(); a.state = Obj(); a.state.p_pos = pos[b, i]; a.state.p_vel = vel[b, i]; a.size = w.agents[i].size
+            hw.agents.append(a)
+        per_agent.radius = radius[b]
+        for i, a in enumerate(hw.agents):
+            np.testing.assert_allclose(obs[b, i], per_agent.observation(a, hw), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(rew[b, i], per_agent.reward(a, hw), rtol=0, atol=2e-6)
