@@ -308,103 +308,132 @@ static int launch_roll_v(const Args& a, hipStream_t st) {
 // 8 of 16 and 32), 0 = register-cached rows (few agents: a tile is too small to pay; 64 agents: a row is a wave)
 constexpr int roll_writer(int n) { return n == 9 ? FG_WR_GATHER : n == 27 ? 10 : n == 25 ? 6 : (n == 16 || n == 32) ? 9 : 0; }
 
+// ---- which instantiation a (agents, batch, buffer) gets: ONE rule table per agent-count class --------------------------------
+// A rule = a batch range, conditions on the observation buffer, the instantiation, and the measurement that put the threshold
+// where it is.  The FIRST rule that applies is taken; a row whose instantiation does not exist for this (agents, per) - `on`
+// false - is skipped, every table ends with a catch-all.  tests/golden/dispatch.json holds what these tables answer over a grid
+// of shapes (tests/test_dispatch_snapshot.py): a moved threshold is a diff of that file.
+//   rollout_kernel<NC, G, TP, TW, E, WR, PER, STREAM>: G lanes per env, TP producer + TW writer threads, E envs per workgroup,
+//   WR the observation writer (0 rows, FG_WR_GATHER, else 1 + rows per LDS tile), STREAM the HBM-streaming form of the writer
+using RollFn = int (*)(const Args&, hipStream_t);
+enum : unsigned {
+    R_HBM = 1u,          // the launch's observation buffer does not fit the 256 MiB Infinity Cache (> 400 MB)
+    R_CACHED = 2u,       // ... it does
+    R_PLACED = 4u,       // FgParams.obs_placed: the buffer was composed of chunks spread over the device's memory (fg_arena_*)
+};
+struct RollRule {
+    int b_lo, b_hi;      // batch sizes the rule covers (inclusive)
+    unsigned need;       // R_* conditions, all of them
+    RollFn fn;           // nullptr: no such instantiation for this (agents, per)
+    const char* why;     // the measurement behind the threshold
+};
+constexpr int B_ANY = 0x7fffffff;
+template <bool ON, int NC, int G, int TP, int TW, int E, int WR, int PER, bool STREAM = false>
+constexpr RollFn roll_fn() {
+    if constexpr (ON) return &launch_roll_v<NC, G, TP, TW, E, WR, PER, STREAM>;
+    else return nullptr;
+}
+template <size_t R>
+static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t st) {
+    const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+    for (const RollRule& r : rules) {
+        if (!r.fn || a.B < r.b_lo || a.B > r.b_hi) continue;
+        if (((r.need & R_HBM) && !hbm) || ((r.need & R_CACHED) && hbm) || ((r.need & R_PLACED) && !a.p.obs_placed)) continue;
+        return r.fn(a, st);
+    }
+    return fail(FG_ERR_UNSUPPORTED_N, "no rollout rule for this shape%s");       // (unreachable: every table ends with a catch-all)
+}
+
 // up to 8 agents (3, 4, 8): one wave of producers, two writer waves with the rows writer (rows of 9 units keep 9 of a wave's
 // 64 lanes busy; one writer wave was the bottleneck: 3 x 1024 x 20 2.28 -> 1.36 us/step, 3 x 16384 2.48 -> 1.63, 3 x 65536
 // 7.46 -> 7.05; four waves lose from 16384 envs up)
 template <int NC, int PER>
 static int launch_roll_8(const Args& a, hipStream_t st) {
-    constexpr int G = NC <= 4 ? 4 : 8;
-    // 8 agents, a batch that fills the chip: an env's 1536 bytes as one contiguous span of 16-byte stores instead of rows in
-    // 64- / 128-byte pieces (LDS tiles: 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; the gather writer since: 18.9 ->
-    // 18.6, equal at 8192); 8 x 1024 is bound by the producers' chain and keeps the rows writer (1.09 vs 1.48)
-    if constexpr (NC == 8) {
-        // ... and with one workgroup per CU (4096 envs) into a buffer beyond the Infinity Cache, 16 envs and eight writer
-        // waves per workgroup: 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it: profiles/r04_writers_ab.txt)
-        if constexpr (PER == 0)
-            if (a.B >= 4096 && a.B < 5120 && (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6)
-                return launch_roll_v<NC, G, 128, 512, 128 / G, 9, PER>(a, st);
-        // (the closed loop takes the gather writer as well since round 5 - no gain by itself, 23.2 -> 22.7 us/step at 8 x 65536 -)
-        // closed loop, a batch of many workgroup generations: the producers' chain (controller + physics, ~3.6 us per step) is
-        // the bound, so ONE writer wave per workgroup leaves room for more resident producer waves - 8 x 65536 22.7 -> 20.9
-        // us/step; at 8192 envs two writer waves stay ahead (3.17 vs 3.50: profiles/r05_r8_ab.txt)
-        if constexpr (PER > 0)
-            if (a.B >= 32768) return launch_roll_v<NC, G, 64, 64, 64 / G, FG_WR_GATHER, PER>(a, st);
-        if (a.B >= 4096) return launch_roll_v<NC, G, 64, 128, 64 / G, FG_WR_GATHER, PER>(a, st);
-    }
-    return launch_roll_v<NC, G, 64, 128, 64 / G, 0, PER>(a, st);
+    constexpr int G = NC <= 4 ? 4 : 8, E = 64 / G;
+    constexpr bool N8 = NC == 8, OPEN = PER == 0;
+    static constexpr RollRule rules[] = {
+        {4096, 5119, R_HBM, roll_fn<N8 && OPEN, NC, G, 128, 512, 128 / G, 9, PER>(),
+         "profiles/r04_writers_ab.txt: one workgroup per CU into a buffer beyond the Infinity Cache, 16 envs and eight writer waves "
+         "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it)"},
+        {32768, B_ANY, 0, roll_fn<N8 && !OPEN, NC, G, 64, 64, E, FG_WR_GATHER, PER>(),
+         "profiles/r05_r8_ab.txt: closed loop over many workgroup generations is bound by the producers' chain (controller + physics, "
+         "~3.6 us per step); ONE writer wave leaves room for more resident producer waves - 8 x 65536 22.7 -> 20.9 us/step; at 8192 "
+         "envs two writer waves stay ahead (3.17 vs 3.50)"},
+        {4096, B_ANY, 0, roll_fn<N8, NC, G, 64, 128, E, FG_WR_GATHER, PER>(),
+         "profiles/r04_gather_ab.txt: an env's 1536 bytes as one contiguous span of 16-byte stores instead of rows in 64- / 128-byte "
+         "pieces (LDS tiles: 8 x 65536 23.3 -> 20.2 us/step, 8 x 8192 3.14 -> 2.69; the gather writer since: 18.9 -> 18.6, equal at "
+         "8192; closed loop 23.2 -> 22.7); 8 x 1024 is bound by the producers' chain and keeps the rows writer (1.09 vs 1.48)"},
+        {0, B_ANY, 0, roll_fn<true, NC, G, 64, 128, E, 0, PER>(), "the default of this class (comment above)"},
+    };
+    return run_roll_rules(rules, a, st);
 }
 // 9 ... 16 agents: a batch of <= 4096 envs is bound by the producers' dependent chain and wants many small workgroups with
 // the row writer; larger batches are store-bound and want whole 128-byte lines per workgroup with the LDS-tile writer.
 template <int NC, int PER>
 static int launch_roll_16(const Args& a, hipStream_t st) {
     constexpr int WR = roll_writer(NC);
+    constexpr bool N9 = NC == 9, OPEN = PER == 0;
     // 9 agents into a rollout buffer beyond the Infinity Cache (128 steps of 4096 envs: 1 GB).  Cycle stamps inside the kernel
     // (profiles/r04_trace_ab.txt) showed the writer waves, not the producers' chain and not the memory, bounding it: 5400-5700
     // cycles per step for four waves with the tile writer against 2800 for the producers.  Hence the gather writer
     // (fg_obs_writers.hpp; 9 x 8192 3.40 -> 3.10 us/step, 9 x 16384 6.8 -> 6.3, profiles/r04_gather_ab.txt) and, while a
-    // workgroup has a CU to itself, more writer waves per env (profiles/r04_writers_ab.txt, r04_gather_geom.txt):
-    // 9 x 4096 x 128 2.42 -> 1.83, 9 x 2048 x 250 1.47 -> 1.31
-    if constexpr (NC == 9) {
-        if ((double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6) {
-            if constexpr (PER == 0) {
-                if (a.B > 1024 && a.B <= 2048) return launch_roll_v<NC, 16, 128, 256, 8, WR, PER>(a, st);
-                if (a.B > 2048 && a.B <= 4096) return launch_roll_v<NC, 16, 256, 512, 16, WR, PER>(a, st);
-            } else if (a.B > 2048 && a.B <= 4096) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
-        }
-    }
-    if (a.B >= 8192) return launch_roll_v<NC, 16, 256, 256, 16, WR, PER>(a, st);
-    if (a.B > 4096) return launch_roll_v<NC, 16, 128, 128, 8, WR, PER>(a, st);
-    return launch_roll_v<NC, 16, 64, 128, 4, 0, PER>(a, st);
+    // workgroup has a CU to itself, more writer waves per env
+    static constexpr RollRule rules[] = {
+        {1025, 2048, R_HBM, roll_fn<N9 && OPEN, NC, 16, 128, 256, 8, WR, PER>(),
+         "profiles/r04_writers_ab.txt, r04_gather_geom.txt: 9 x 2048 x 250 1.47 -> 1.31 us/step"},
+        {2049, 4096, R_HBM, roll_fn<N9 && OPEN, NC, 16, 256, 512, 16, WR, PER>(),
+         "profiles/r04_writers_ab.txt, r04_gather_geom.txt: 9 x 4096 x 128 2.42 -> 1.83 us/step (1.43 since: profiles/r05_9x4096_rollout.md)"},
+        {2049, 4096, R_HBM, roll_fn<N9 && !OPEN, NC, 16, 256, 256, 16, WR, PER>(),
+         "profiles/r04_writers_ab.txt: the closed loop's controller tables leave LDS for four writer waves"},
+        {8192, B_ANY, 0, roll_fn<true, NC, 16, 256, 256, 16, WR, PER>(), "profiles/README.md (round 2 sweeps): store-bound, whole lines per workgroup"},
+        {4097, B_ANY, 0, roll_fn<true, NC, 16, 128, 128, 8, WR, PER>(), "profiles/README.md (round 2 sweeps)"},
+        {0, B_ANY, 0, roll_fn<true, NC, 16, 64, 128, 4, 0, PER>(), "the producers' chain bounds it: many small workgroups, rows writer"},
+    };
+    return run_roll_rules(rules, a, st);
 }
 // 17 ... 32 agents (25, 27, 32).  Defaults from the MI355X sweeps at 27 agents (profiles/README.md): 16 envs per workgroup =
 // 8 producer + 4 writer waves, one workgroup per CU at 4096 envs, LDS-tile writer.
 template <int NC, int PER>
 static int launch_roll_32(const Args& a, hipStream_t st) {
     constexpr int WR = roll_writer(NC);
-    constexpr bool POLICY = PER > 0;
-    // HBM-streaming form of the tile writer (line ownership + paced stores, fg_obs_writers.hpp): batches of a few
-    // workgroup generations whose rollout buffer does not fit the 256 MiB Infinity Cache; else the plain form
-    const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
-    const bool stream = a.B < 16384 && hbm;
-    // A buffer composed of chunks spread over the device's memory (FgParams.obs_placed) takes the stream of 8 paced
-    // writer waves: 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384
-    // 47.6-48.4 against 48.7-49.4 (profiles/r03_wide/ab_27_writers_*.txt); on an ordinary allocation 8 waves lose
-    // (13.2-14.4 against 12.75, round 2).  The closed-loop instantiation cannot hold 16 tiles beside its controller tables: it
-    // takes its 8 writer waves with the rows writer (below).
-    // Batches that do not fill the chip with 16-env workgroups (4096 envs = 256 workgroups = one per CU): fewer envs
-    // per workgroup, so that the batch still spreads over the CUs.  27 x 1024 x 20: 9.2 -> 3.4 us/step, 27 x 512: 9.1 ->
-    // 2.6, 27 x 256: 9.1 -> 2.6, 27 x 2048: 8.0 -> 6.0-6.5 (placed or not; 27 x 2560 and up are faster with 16:
-    // profiles/r03_wide/ab_27_small_batches_*.txt)
-    if constexpr (NC == 27) {                           // the reference's own agent count: a geometry per batch-size class
-        if (a.B <= 512) return launch_roll_v<NC, 32, 64, 256, 2, WR, PER, false>(a, st);
-        if (a.B <= 1024) return launch_roll_v<NC, 32, 128, 256, 4, WR, PER, false>(a, st);
-        if (a.B <= 2048) {
-            if constexpr (POLICY) return launch_roll_v<NC, 32, 256, 256, 8, WR, PER, false>(a, st);
-            else return hbm ? launch_roll_v<NC, 32, 256, 512, 8, WR, 0, true>(a, st)
-                            : launch_roll_v<NC, 32, 256, 512, 8, WR, 0, false>(a, st);
-        }
-    } else {
-        if (a.B <= 1024) return launch_roll_v<NC, 32, 128, 256, 4, WR, PER, false>(a, st);
-    }
-    if (POLICY && a.p.obs_placed && hbm)                // closed loop: 8 writer waves with the rows writer (no tiles in LDS):
-        return launch_roll_v<NC, 32, 512, 512, 16, 0, PER, false>(a, st);   // 11.7 vs 13.35 us/step (profiles/r03_wide/ab_closed_loop_*)
-    // ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (the memory system is not the
-    // bound then, a workgroup's own store rate is): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072
-    // 12.5 -> 10.7 (27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4: profiles/r03_wide/ab_27_mid_batches.txt)
-    if constexpr (!POLICY) {
-        if (hbm && (a.p.obs_placed || a.B <= 3072)) return launch_roll_v<NC, 32, 512, 512, 16, WR, 0, true>(a, st);
-        if (stream) return launch_roll_v<NC, 32, 512, 256, 16, WR, 0, true>(a, st);
-    } else if constexpr (NC == 27) {
-        if (stream) return launch_roll_v<NC, 32, 512, 256, 16, WR, PER, true>(a, st);
-    }
-    return launch_roll_v<NC, 32, 512, 256, 16, WR, PER, false>(a, st);
+    constexpr bool POLICY = PER > 0, N27 = NC == 27;
+    static constexpr RollRule rules[] = {
+        // Batches that do not fill the chip with 16-env workgroups (4096 envs = 256 workgroups = one per CU): fewer envs per
+        // workgroup, so that the batch still spreads over the CUs
+        {0, 512, 0, roll_fn<N27, NC, 32, 64, 256, 2, WR, PER>(),
+         "profiles/r03_wide/ab_27_small_batches_*.txt: 27 x 512 x 20 9.1 -> 2.6 us/step, 27 x 256 9.1 -> 2.6"},
+        {0, 1024, 0, roll_fn<true, NC, 32, 128, 256, 4, WR, PER>(), "profiles/r03_wide/ab_27_small_batches_*.txt: 27 x 1024 x 20 9.2 -> 3.4 us/step"},
+        {0, 2048, 0, roll_fn<N27 && POLICY, NC, 32, 256, 256, 8, WR, PER>(), "profiles/r03_wide/ab_27_small_batches_*.txt: 27 x 2048 8.0 -> 6.0-6.5 us/step"},
+        {0, 2048, R_HBM, roll_fn<N27 && !POLICY, NC, 32, 256, 512, 8, WR, 0, true>(),
+         "profiles/r03_wide/ab_27_small_batches_*.txt: 27 x 2048 8.0 -> 6.0-6.5 us/step, placed or not; the HBM-streaming form of the tile writer"},
+        {0, 2048, R_CACHED, roll_fn<N27 && !POLICY, NC, 32, 256, 512, 8, WR, 0, false>(), "... and its plain form while the buffer stays in the Infinity Cache"},
+        // (27 x 2560 and up are faster with 16 envs per workgroup)
+        {0, B_ANY, R_HBM | R_PLACED, roll_fn<POLICY, NC, 32, 512, 512, 16, 0, PER>(),
+         "profiles/r03_wide/ab_closed_loop_*: the closed-loop instantiation cannot hold 16 tiles beside its controller tables; it takes its "
+         "8 writer waves with the rows writer - 11.7 vs 13.35 us/step"},
+        {0, B_ANY, R_HBM | R_PLACED, roll_fn<!POLICY, NC, 32, 512, 512, 16, WR, 0, true>(),
+         "profiles/r03_wide/ab_27_writers_*.txt: a buffer composed of chunks spread over the device's memory takes the stream of 8 paced writer "
+         "waves - 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384 47.6-48.4 against "
+         "48.7-49.4; on an ordinary allocation 8 waves lose (13.2-14.4 against 12.75, round 2)"},
+        {0, 3072, R_HBM, roll_fn<!POLICY, NC, 32, 512, 512, 16, WR, 0, true>(),
+         "profiles/r03_wide/ab_27_mid_batches.txt: ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (a "
+         "workgroup's own store rate is the bound then): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072 12.5 -> 10.7 "
+         "(27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4)"},
+        {0, 16383, R_HBM, roll_fn<!POLICY, NC, 32, 512, 256, 16, WR, 0, true>(),
+         "profiles/README.md (round 2): line ownership + paced stores for batches of a few workgroup generations whose buffer does not fit the Infinity Cache"},
+        {0, 16383, R_HBM, roll_fn<POLICY && N27, NC, 32, 512, 256, 16, WR, PER, true>(), "as above, closed loop"},
+        {0, B_ANY, 0, roll_fn<true, NC, 32, 512, 256, 16, WR, PER>(), "the default of this class (comment above)"},
+    };
+    return run_roll_rules(rules, a, st);
 }
 // 64 agents: an env is a wave of producers, a row of its observation 3 stores of a writer wave
 template <int NC, int PER>
 static int launch_roll_64(const Args& a, hipStream_t st) {
-    if constexpr (PER == 0)
-        if (a.B <= 1024) return launch_roll_v<NC, 64, 128, 256, 2, 0, 0>(a, st);
-    return launch_roll_v<NC, 64, 512, 256, 8, 0, PER>(a, st);
+    static constexpr RollRule rules[] = {
+        {0, 1024, 0, roll_fn<PER == 0, NC, 64, 128, 256, 2, 0, 0>(), "profiles/r04_generic_n.md: a batch that does not fill the chip with 8-env workgroups"},
+        {0, B_ANY, 0, roll_fn<true, NC, 64, 512, 256, 8, 0, PER>(), "profiles/r04_generic_n.md"},
+    };
+    return run_roll_rules(rules, a, st);
 }
 
 // The pipelined K-step kernels exist for the agent counts of the reference's hierarchies, N = per^L: the reference's own

@@ -101,3 +101,30 @@ def test_the_headline_shapes_take_the_kernels_the_profiles_name(lib):
     assert d(243, 8192, 0).startswith("rollout_kernel_wide<243,4,4,256,0,1>")          # single step: pipelined over env batches
     assert d(27, 4096, 0).startswith("step_kernel<27,32,256,4,0,0,1> grid 1024")
     assert _describe(lib, _params(), None, 65536, 4, 20, per=2).startswith("hd_lane_kernel<4,2>")
+
+
+def test_every_rule_names_a_measurement_that_is_in_the_repo():
+    """The rule tables of the pipelined rollout kernels (csrc/formation_hip.hip: RollRule rows = batch range, buffer conditions,
+    instantiation, the measurement behind the threshold): every profiles/... file a row cites exists, every table ends with a
+    catch-all row, and rows are written one instantiation each (thresholds in one table with the profile file named)."""
+    import glob
+    import re
+    src = open(os.path.join(ROOT, "gym-formation_amd", "csrc", "formation_hip.hip")).read()
+    body = src[src.index("struct RollRule"):src.index("// The pipelined K-step kernels exist")]
+    tables = re.findall(r"static constexpr RollRule rules\[\] = \{(.*?)\n    \};", body, flags=re.S)
+    assert len(tables) == 4
+    rows = 0
+    for t in tables:
+        entries = re.findall(r"\{\s*(\d+|B_ANY),\s*(\d+|B_ANY),\s*([^,]+),\s*roll_fn<([^>]*)>\(\),\s*((?:\"[^\"]*\"\s*)+)\}", t)
+        assert entries, "no rows parsed"
+        rows += len(entries)
+        lo, hi, need, fn, why = entries[-1]
+        assert (lo, hi, need.strip()) == ("0", "B_ANY", "0") and fn.split(",")[0].strip() == "true", "the last row must be a catch-all"
+        assert t.count("roll_fn<") == len(entries), "a row the test could not parse"
+        for lo, hi, need, fn, why in entries:
+            assert len(why.strip()) > 10
+    assert rows >= 20
+    cited = {n.rstrip(".:,;") for n in re.findall(r"profiles/[A-Za-z0-9_./*-]+", body)}
+    assert len(cited) >= 8
+    for n in cited:
+        assert glob.glob(os.path.join(ROOT, n) + "*"), "%s is cited by a dispatch rule but is not in the repo" % n
