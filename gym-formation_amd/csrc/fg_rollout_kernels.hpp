@@ -259,7 +259,9 @@ void rollout_kernel(const Args a) {
     // the span form of the gather writer for full workgroups of a contiguous tensor whose span starts on a 16-byte boundary
     // (slot * B * 3 N^2 even: every step alike); partial workgroups, padded env pitches and odd slabs take the per-env form
     constexpr bool SPAN_OK = WR == FG_WR_GATHER && (E * 3 * NC * NC) % 2 == 0 && (E - 1) * (roll_block_floats(NC) / 2) + 5 * NC < 32768;
-    using Span = SpanGather<(SPAN_OK ? NC : 2), NWW, (SPAN_OK ? E : 2), ((TP + TW) <= 512 ? 2 : 4)>;   // (128-register budget: two in flight)
+    // (pieces in flight per writer wave: 4; 2 in the workgroups of up to 512 threads, which keep 4 waves per SIMD = 128 registers;
+    // 1 in the 1024-thread workgroups - 128 registers again, and two pieces spilled two of them)
+    using Span = SpanGather<(SPAN_OK ? NC : 2), NWW, (SPAN_OK ? E : 2), ((TP + TW) > 768 ? 1 : (TP + TW) <= 512 ? 2 : 4)>;
     uint2* const span_lut = reinterpret_cast<uint2*>(smemf + E * roll_block_floats(N));
     bool use_span = false;
     if constexpr (SPAN_OK)

@@ -320,6 +320,8 @@ enum : unsigned {
     R_HBM = 1u,          // the launch's observation buffer does not fit the 256 MiB Infinity Cache (> 400 MB)
     R_CACHED = 2u,       // ... it does
     R_PLACED = 4u,       // FgParams.obs_placed: the buffer was composed of chunks spread over the device's memory (fg_arena_*)
+    R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), come in whole generations of 256 - or
+                         // in at least six generations, where a ragged last one weighs little
 };
 struct RollRule {
     int b_lo, b_hi;      // batch sizes the rule covers (inclusive)
@@ -339,6 +341,7 @@ static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t
     for (const RollRule& r : rules) {
         if (!r.fn || a.B < r.b_lo || a.B > r.b_hi) continue;
         if (((r.need & R_HBM) && !hbm) || ((r.need & R_CACHED) && hbm) || ((r.need & R_PLACED) && !a.p.obs_placed)) continue;
+        if ((r.need & R_FILL32) && ((a.B + 31) / 32) % 256 != 0 && (a.B + 31) / 32 < 6 * 256) continue;
         return r.fn(a, st);
     }
     return fail(FG_ERR_UNSUPPORTED_N, "no rollout rule for this shape%s");       // (unreachable: every table ends with a catch-all)
@@ -385,6 +388,10 @@ static int launch_roll_16(const Args& a, hipStream_t st) {
          "profiles/r04_writers_ab.txt, r04_gather_geom.txt: 9 x 4096 x 128 2.42 -> 1.83 us/step (1.43 since: profiles/r05_9x4096_rollout.md)"},
         {2049, 4096, R_HBM, roll_fn<N9 && !OPEN, NC, 16, 256, 256, 16, WR, PER>(),
          "profiles/r04_writers_ab.txt: the closed loop's controller tables leave LDS for four writer waves"},
+        {8192, B_ANY, R_HBM | R_FILL32, roll_fn<N9 && OPEN, NC, 16, 512, 512, 32, WR, PER>(),
+         "profiles/r05_9x32_ab.txt: 32 envs, 8 producer and 8 writer waves per workgroup - 9 x 8192 x 64 2.97 -> 2.84 us/step, 9 x 16384 5.69 -> "
+         "5.44, 9 x 32768 11.49 -> 11.10, 9 x 65536 23.9 -> 23.3 (0.76 -> 0.78-0.795 of 8 TB/s in real bytes); a batch that leaves the last "
+         "generation half empty loses (9 x 12288: 4.42 -> 4.97)"},
         {8192, B_ANY, 0, roll_fn<true, NC, 16, 256, 256, 16, WR, PER>(), "profiles/README.md (round 2 sweeps): store-bound, whole lines per workgroup"},
         {4097, B_ANY, 0, roll_fn<true, NC, 16, 128, 128, 8, WR, PER>(), "profiles/README.md (round 2 sweeps)"},
         {0, B_ANY, 0, roll_fn<true, NC, 16, 64, 128, 4, 0, PER>(), "the producers' chain bounds it: many small workgroups, rows writer"},

@@ -768,7 +768,10 @@ def test_arena_mappings_get_fresh_addresses_and_chunks_keep_their_contents():
 @pytest.mark.parametrize("N,B,K,obs_every,pad", [(27, 4096, 8, 2, False), (27, 4096, 6, 1, True), (81, 1024, 4, 2, True),
                                                  # 9 / 8 agents: the span form of the gather writer with every 2nd observation kept,
                                                  # and a padded env pitch (the per-env form)
-                                                 (9, 8192, 40, 2, False), (9, 8192, 18, 1, True), (8, 8200, 28, 1, False)])
+                                                 # (9 x 8192 and up into a buffer beyond the Infinity Cache: 32-env workgroups;
+                                                 # 49169 envs: a ragged last workgroup among 1537)
+                                                 (9, 8192, 60, 2, False), (9, 8192, 26, 1, True), (9, 49169, 6, 1, False),
+                                                 (8, 8200, 28, 1, False)])
 def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every, pad):
     """alloc_rollout_buffers with every obs_every-th observation kept and / or env blocks padded to whole 128-byte lines
     (FgParams.obs_env_pitch): the placed, strided buffer takes the same bits as K step calls."""

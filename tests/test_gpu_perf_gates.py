@@ -37,7 +37,7 @@ def _us_per_step(fn, K, reps=6, per=4):
 ROLLOUTS = [
     (27, 4096, 20, 14.6, "headline: 11.6-12.2 placed (13.2-13.6 un-placed; the 4-writer kernel on a placed buffer 12.9)"),
     (9, 4096, 20, 1.95, "1.46-1.55 with 4-env workgroups and the rows writer; 16-env workgroups 2.1-3.0"),
-    (9, 8192, 64, 3.8, "3.1 with the gather writer, 16-env workgroups; 8-env 3.4-4.9"),
+    (9, 8192, 64, 3.6, "2.75-2.85 with the span gather writer and 32-env workgroups (16-env 2.8-3.0; 8-env 3.4-4.9)"),
     (9, 4096, 128, 2.05, "1.54-1.6 with eight writer waves, the gather writer and four-step action batches; without them 1.8-2.6"),
     (16, 8192, 20, 11.0, "8.7; the flat-decode K-loop of round 3 12-13"),
     (64, 2048, 20, 40.0, "30.6-31.2; K-loop 45"),
