@@ -358,7 +358,18 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
         {4096, 5119, R_HBM, roll_fn<N8 && OPEN, NC, G, 128, 512, 128 / G, 9, PER>(),
          "profiles/r04_writers_ab.txt: one workgroup per CU into a buffer beyond the Infinity Cache, 16 envs and eight writer waves "
          "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it)"},
-        {32768, B_ANY, 0, roll_fn<N8 && !OPEN, NC, G, 64, 64, E, FG_WR_GATHER, PER>(),
+        {8192, 49152, R_HBM, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
+         "profiles/r05_8x32_ab.txt: 32 envs, 4 producer and 8 writer waves per workgroup - 8 x 8192 x 80 2.36 -> 2.22 us/step, 8 x 16384 "
+         "4.74-4.97 -> 4.28-4.39, 8 x 24576 6.96 -> 6.48, 8 x 32768 8.99 -> 8.61, 8 x 49152 13.36 -> 13.10 (0.80 of 8 TB/s in real bytes); "
+         "8 x 65536 stays with the small workgroups (17.6-17.8 vs 17.9-18.1)"},
+        {12288, B_ANY, 0, roll_fn<N8 && PER == 2, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
+         "profiles/r05_8x32_ab.txt: closed loop, 32 envs, 4 + 4 waves per workgroup - 8 x 12288 6.18 -> 3.90 us/step, 8 x 16384 6.88 -> 4.65, "
+         "8 x 24576 9.54 -> 7.39, 8 x 32768 10.64 -> 9.42, 8 x 65536 20.1-20.4 -> 18.95-19.4 (0.50-0.69 -> 0.72-0.74 real); 8 x 8192 keeps the "
+         "small workgroups (2.92 vs 3.03)"},
+        {12288, 49152, 0, roll_fn<N8 && PER == 8, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
+         "profiles/r05_8x32_ab.txt: the one-level 8-ary controller - 8 x 16384 9.93 -> 6.52 us/step, 8 x 24576 13.49 -> 9.87, 8 x 32768 14.65 -> "
+         "13.28, 8 x 49152 21.25 -> 20.35; equal at 65536 (27.9 vs 28.2)"},
+        {32768, B_ANY, 0, roll_fn<N8 && PER == 8, NC, G, 64, 64, E, FG_WR_GATHER, PER>(),
          "profiles/r05_r8_ab.txt: closed loop over many workgroup generations is bound by the producers' chain (controller + physics, "
          "~3.6 us per step); ONE writer wave leaves room for more resident producer waves - 8 x 65536 22.7 -> 20.9 us/step; at 8192 "
          "envs two writer waves stay ahead (3.17 vs 3.50)"},
@@ -392,6 +403,9 @@ static int launch_roll_16(const Args& a, hipStream_t st) {
          "profiles/r05_9x32_ab.txt: 32 envs, 8 producer and 8 writer waves per workgroup - 9 x 8192 x 64 2.97 -> 2.84 us/step, 9 x 16384 5.69 -> "
          "5.44, 9 x 32768 11.49 -> 11.10, 9 x 65536 23.9 -> 23.3 (0.76 -> 0.78-0.795 of 8 TB/s in real bytes); a batch that leaves the last "
          "generation half empty loses (9 x 12288: 4.42 -> 4.97)"},
+        {8192, 32768, R_HBM, roll_fn<NC == 16 && OPEN, NC, 16, 256, 512, 16, WR, PER>(),
+         "profiles/r05_16x_ab.txt: eight writer waves per 16 envs - 16 x 8192 x 24 8.61 -> 8.10 us/step, 16 x 16384 16.91 -> 16.03, 16 x 32768 "
+         "33.8 -> 33.55 (0.77-0.79 -> 0.80-0.83 of 8 TB/s in real bytes); 16 x 65536 and the closed loop keep four (69.8 vs 73.7; 16.5 vs 17.25)"},
         {8192, B_ANY, 0, roll_fn<true, NC, 16, 256, 256, 16, WR, PER>(), "profiles/README.md (round 2 sweeps): store-bound, whole lines per workgroup"},
         {4097, B_ANY, 0, roll_fn<true, NC, 16, 128, 128, 8, WR, PER>(), "profiles/README.md (round 2 sweeps)"},
         {0, B_ANY, 0, roll_fn<true, NC, 16, 64, 128, 4, 0, PER>(), "the producers' chain bounds it: many small workgroups, rows writer"},
