@@ -355,9 +355,10 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
     constexpr int G = NC <= 4 ? 4 : 8, E = 64 / G;
     constexpr bool N8 = NC == 8, OPEN = PER == 0;
     static constexpr RollRule rules[] = {
-        {4096, 5119, R_HBM, roll_fn<N8 && OPEN, NC, G, 128, 512, 128 / G, 9, PER>(),
+        {4096, 5119, R_HBM, roll_fn<N8 && OPEN, NC, G, 128, 512, 128 / G, FG_WR_GATHER, PER>(),
          "profiles/r04_writers_ab.txt: one workgroup per CU into a buffer beyond the Infinity Cache, 16 envs and eight writer waves "
-         "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it)"},
+         "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it); profiles/r05_8x32_ab.txt: with the span form of "
+         "the gather writer instead of LDS tiles 8 x 4096 x 160 1.152 -> 1.057 (0.74 -> 0.81 real), 8 x 4500 2.18 -> 1.98"},
         {8192, 49152, R_HBM, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
          "profiles/r05_8x32_ab.txt: 32 envs, 4 producer and 8 writer waves per workgroup - 8 x 8192 x 80 2.36 -> 2.22 us/step, 8 x 16384 "
          "4.74-4.97 -> 4.28-4.39, 8 x 24576 6.96 -> 6.48, 8 x 32768 8.99 -> 8.61, 8 x 49152 13.36 -> 13.10 (0.80 of 8 TB/s in real bytes); "
