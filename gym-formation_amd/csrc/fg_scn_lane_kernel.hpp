@@ -59,8 +59,8 @@ __host__ __device__ constexpr int scn_lane_pitch(int units) { return units | 1; 
 // NBR: neighbours observed = num_obs (partial) or N - 1 (the other kinds)
 // LDS of one hand-over block: the observation block [64][SU] (float2), then reward / individual reward / done of the
 // 64 x N agents as three arrays of 64 N dwords
-__host__ __device__ constexpr int scn_lane_block_bytes(int kind, int n, int l, int m, int nbr) {
-    return 64 * scn_lane_pitch(n * scn_obs_dim(kind, n, l, m, nbr) / 2) * 8 + 3 * 64 * n * 4;
+__host__ __device__ constexpr int scn_lane_block_bytes(int kind, int n, int l, int m, int nbr, int pw = 1) {
+    return pw * (64 * scn_lane_pitch(n * scn_obs_dim(kind, n, l, m, nbr) / 2) * 8 + 3 * 64 * n * 4);
 }
 // Two blocks (the producer composes step k+1 while the writer streams step k: one barrier per step, nobody waits for the
 // compose) where four workgroups per CU still fit the 160 KiB - basic_formation_env's 16 KiB blocks; the larger rows of
@@ -68,8 +68,8 @@ __host__ __device__ constexpr int scn_lane_block_bytes(int kind, int n, int l, i
 __host__ __device__ constexpr bool scn_lane_double(int kind, int n, int l, int m, int nbr) {
     return 2 * scn_lane_block_bytes(kind, n, l, m, nbr) <= 40 * 1024;
 }
-__host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int m, int nbr) {
-    return (scn_lane_double(kind, n, l, m, nbr) ? 2 : 1) * scn_lane_block_bytes(kind, n, l, m, nbr);
+__host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int m, int nbr, int pw = 1) {
+    return (scn_lane_double(kind, n, l, m, nbr) ? 2 : 1) * scn_lane_block_bytes(kind, n, l, m, nbr, pw);
 }
 
 // The WRITER wave of a one-env-per-lane workgroup (the landmark scenarios here, formation_hd_env in fg_hd_lane_kernel.hpp):
@@ -82,32 +82,35 @@ __host__ __device__ constexpr int scn_lane_lds_bytes(int kind, int n, int l, int
 // r05_place_channels.md): two waves gain 2 % at basic_formation_env's small blocks (3.08 -> 3.02 us/step at 65536 envs) and lose
 // 2-6 % at the larger rows of the other scenarios, three lose 2-20 % (profiles/r05_lane_writers_ab.txt).
 __host__ __device__ constexpr int scn_lane_writers(int kind) { return kind == FG_SCN_BASIC ? 2 : 1; }
-template <int N, int D, bool DB, int NWW = 1>
+// PW producer waves share the workgroup: the block is then the image of 64 PW envs (env = 64 * producer wave + lane) and the
+// workgroup's span 64 PW envs long.
+template <int N, int D, bool DB, int NWW = 1, int PW = 1>
 FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int El, int obs_every,
                              float* __restrict__ obs, float* __restrict__ rew, float* __restrict__ indiv, uint8_t* __restrict__ done, int lane,
                              int w = 0) {
     constexpr int U = N * D / 2, SU = scn_lane_pitch(U);
-    constexpr int BLOCK_UNITS = 64 * SU + (3 * 64 * N) / 2;
+    constexpr int ENVS = 64 * PW;
+    constexpr int BLOCK_UNITS = ENVS * SU + (3 * ENVS * N) / 2;
     for (int ks = 0; ks < KS; ++ks) {
         if (!DB) __syncthreads();                   // A: the block of step ks - 1 has been read (nothing to do for ks = 0)
         __syncthreads();                            // B: the block of step ks is complete
         const float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
-        const float* const s_rew = reinterpret_cast<const float*>(smem + 64 * SU);
-        const float* const s_ind = s_rew + 64 * N;
-        const uint32_t* const s_done = reinterpret_cast<const uint32_t*>(s_ind + 64 * N);
+        const float* const s_rew = reinterpret_cast<const float*>(smem + ENVS * SU);
+        const float* const s_ind = s_rew + ENVS * N;
+        const uint32_t* const s_done = reinterpret_cast<const uint32_t*>(s_ind + ENVS * N);
         const size_t kb = (size_t)ks * B;
         const bool want_obs = obs != nullptr && (obs_every <= 1 || (ks + 1) % obs_every == 0);
         if (want_obs) {
             // unit q of the workgroup's span = unit (q mod U) of env (q div U); 64 units per instruction, lanes consecutive
             const size_t ob = (size_t)(obs_every > 1 ? ks / obs_every : ks) * B;
             float2* const out = reinterpret_cast<float2*>(obs + (ob + (size_t)b0) * N * D);
-            if (El == 64) {
+            if (El == ENVS) {
                 // a full block: 32 U pairs of units, one 16-byte store per lane and instruction (1 KiB per wave instruction; the
                 // two units of a pair may sit in different rows of the LDS image.  8-byte stores: basic 3.2-3.45 -> 3.1 us/step,
                 // partial 6.8-7.5 -> 6.5, profiles/r04_lane_x4_ab.txt).  An odd U makes the image contiguous (pitch U | 1 = U):
                 // the pair is ONE 16-byte LDS read, lanes consecutive, no bank conflicts (the two 8-byte reads at a 16-byte lane
                 // stride met two-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.21 in profiles/r04_scn_pmc.txt).
-                constexpr int NP2 = 32 * U, IT = (NP2 + 63) / 64;
+                constexpr int NP2 = ENVS / 2 * U, IT = (NP2 + 63) / 64;
                 constexpr int MINE = (IT + NWW - 1) / NWW;          // store instructions of one writer wave
                 f32x4* const out4 = reinterpret_cast<f32x4*>(out);
                 const f32x4* const img4 = reinterpret_cast<const f32x4*>(smem);
@@ -151,23 +154,25 @@ FG_DEV void lane_writer_wave(const float2* smem_all, int KS, int B, int b0, int 
         const size_t o0 = (kb + b0) * N + lane;
         if (rew) {                                  // (one uniform branch per array, not per store)
 #pragma unroll
-            for (int c = 0; c < N; ++c) if (c % NWW == w && c * 64 + lane < cnt) rew[o0 + c * 64] = s_rew[c * 64 + lane];
+            for (int c = 0; c < N * PW; ++c) if (c % NWW == w && c * 64 + lane < cnt) rew[o0 + c * 64] = s_rew[c * 64 + lane];
         }
         if (indiv) {
 #pragma unroll
-            for (int c = 0; c < N; ++c) if ((c + 1) % NWW == w && c * 64 + lane < cnt) indiv[o0 + c * 64] = s_ind[c * 64 + lane];
+            for (int c = 0; c < N * PW; ++c) if ((c + 1) % NWW == w && c * 64 + lane < cnt) indiv[o0 + c * 64] = s_ind[c * 64 + lane];
         }
         if (done) {
 #pragma unroll
-            for (int c = 0; c < N; ++c) if ((c + 2) % NWW == w && c * 64 + lane < cnt) done[o0 + c * 64] = (uint8_t)s_done[c * 64 + lane];
+            for (int c = 0; c < N * PW; ++c) if ((c + 2) % NWW == w && c * 64 + lane < cnt) done[o0 + c * 64] = (uint8_t)s_done[c * 64 + lane];
         }
     }
 }
 
-template <int KIND, int N, int L, int M, int NBR>
-__global__ __launch_bounds__(64 + 64 * scn_lane_writers(KIND)) void scn_lane_kernel(const ScnArgs a) {
+// PW producer waves per workgroup (64 PW envs, one span of the observation tensor), PW * scn_lane_writers(KIND) writer waves
+template <int KIND, int N, int L, int M, int NBR, int PW = 1>
+__global__ __launch_bounds__(64 * PW * (1 + scn_lane_writers(KIND))) void scn_lane_kernel(const ScnArgs a) {
     constexpr bool DB = scn_lane_double(KIND, N, L, M, NBR);
-    constexpr int BLOCK_UNITS = scn_lane_block_bytes(KIND, N, L, M, NBR) / 8;   // float2 units from one block to the next
+    constexpr int BLOCK_UNITS = scn_lane_block_bytes(KIND, N, L, M, NBR, PW) / 8;   // float2 units from one block to the next
+    constexpr int ENVS = 64 * PW, NWW = PW * scn_lane_writers(KIND);
     constexpr int NE = N + M;
     constexpr int G = scn_group_lanes(NE);
     constexpr int D = scn_obs_dim(KIND, N, L, M, NBR);
@@ -183,17 +188,18 @@ __global__ __launch_bounds__(64 + 64 * scn_lane_writers(KIND)) void scn_lane_ker
     // (the host launches 8 x ceil(workgroups / 8) of them; the ones beyond the batch leave at once)
     const int per_xcd = (int)(gridDim.x >> 3);
     const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int b0 = wg * 64;
+    const int b0 = wg * ENVS;
     if (b0 >= a.B) return;                              // uniform over the workgroup, before any barrier
-    const int b = b0 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slot = wave * 64 + lane;                  // the lane's env inside the workgroup (producer waves)
+    const int b = b0 + slot;
     const bool live = b < a.B;
     const int bl = live ? b : a.B - 1;                  // loads of a lane beyond the batch stay in range; it stores nothing
-    const int El = min(64, a.B - b0);
+    const int El = min(ENVS, a.B - b0);
     const int KS = a.K > 1 ? a.K : 1;
 
-    if (threadIdx.x >= 64) {
-        lane_writer_wave<N, D, DB, scn_lane_writers(KIND)>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane,
-                                                           __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1);
+    if (wave >= PW) {
+        lane_writer_wave<N, D, DB, NWW, PW>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane, wave - PW);
         return;
     }
 
@@ -389,15 +395,15 @@ __global__ __launch_bounds__(64 + 64 * scn_lane_writers(KIND)) void scn_lane_ker
         // ks - 2, which the writer finished before it arrived at barrier B of step ks - 1
         if (!DB) __syncthreads();
         float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
-        float* const s_rew = reinterpret_cast<float*>(smem + 64 * SU);
-        float* const s_ind = s_rew + 64 * N;
-        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + 64 * N);
+        float* const s_rew = reinterpret_cast<float*>(smem + ENVS * SU);
+        float* const s_ind = s_rew + ENVS * N;
+        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + ENVS * N);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            s_rew[lane * N + i] = shared; s_ind[lane * N + i] = indiv[i]; s_done[lane * N + i] = done_flag;
+            s_rew[slot * N + i] = shared; s_ind[slot * N + i] = indiv[i]; s_done[slot * N + i] = done_flag;
         }
         if (want_obs) {
-            float2* const mine = smem + lane * SU;
+            float2* const mine = smem + slot * SU;
             const float r = (KIND == FG_SCN_RANGE) ? a.sc.obs_range : INFINITY;
 #pragma unroll
             for (int i = 0; i < N; ++i) {

@@ -542,6 +542,31 @@ static int check_params(const FgParams* p) {
     return FG_OK;
 }
 
+// one env per lane, PW producer waves (64 PW envs) and PW * scn_lane_writers(KIND) writer waves per workgroup
+// Four producer waves - 256 envs, one span of 55 ... 133 KB per workgroup and step instead of four - where such workgroups
+// come in whole generations of 256 (one per CU; or in six generations and more) - profiles/r05_lane_pw_ab.txt:
+//   basic 3 x 65536 3.04 -> 2.83 us/step (0.72 -> 0.77 of 8 TB/s, all bytes), 3 x 131072 6.26 -> 5.67 (0.70 -> 0.77);
+//   partial 5 x 131072 12.85 -> 12.51, range 4 x 131072 10.20 -> 9.33 (equal or slower at 65536: 6.44 / 6.40, 4.60 / 4.80);
+//   obstacle never (5.47 / 5.65, 11.25 / 11.24); half-filled generations lose everywhere (32768 envs: 1.70 -> 2.40).
+// Measured on rollouts whose observation buffer does not fit the Infinity Cache (> 400 MB, as for the formation_hd_env rules): only those.
+template <int KIND> static bool scn_lane_wide(int B, double obs_bytes) {
+    const int wgs = (B + 255) / 256;
+    if (obs_bytes <= 400e6 || (wgs % 256 != 0 && wgs < 6 * 256)) return false;
+    return KIND == FG_SCN_BASIC ? B >= 65536 : (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 131072;
+}
+template <int KIND, int NN, int LL, int MM, int NBR, int PW>
+static int launch_scn_lane(const ScnArgs& a, hipStream_t st) {
+    constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR, PW);
+    constexpr int threads = 64 * PW * (1 + scn_lane_writers(KIND));
+    const int grid = 8 * (((a.B + 64 * PW - 1) / (64 * PW) + 7) / 8);
+    if (describe("scn_lane_kernel<%d,%d,%d,%d,%d,%d> grid %d threads %d lds %d; ", KIND, NN, LL, MM, NBR, PW, grid, threads, lds)) return FG_OK;
+    static std::atomic<unsigned long long> raised{0};
+    const hipError_t err = raise_lds_limit((const void*)&scn_lane_kernel<KIND, NN, LL, MM, NBR, PW>, lds, &raised);
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "scenario launch failed: %s", hipGetErrorString(err));
+    hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR, PW>), dim3(grid), dim3(threads), lds, st, a);
+    return FG_OK;
+}
+
 }  // namespace fg
 
 using namespace fg;
@@ -1053,23 +1078,22 @@ static int launch_scenario(const FgParams* params, const FgScenario* sc, int B, 
         // the reference's own shapes: one env per lane, every count a compile-time constant (fg_scn_lane_kernel.hpp)
         const int nbr = sc->kind == FG_SCN_PARTIAL ? sc->num_obs : N - 1;
         bool launched = false;
-#define FG_SCN_LANE(KIND, NN, LL, MM, NBR)                                                                              \
+        const double obs_bytes = (double)((K > 1 ? K : 1) / obs_every) * B * N * 4.0 * scn_obs_dim(sc->kind, N, L, M, nbr);
+#define FG_SCN_LANE(KIND, NN, LL, MM, NBR, WIDE)                                                                        \
         if (!launched && sc->kind == KIND && N == NN && L == LL && M == MM && nbr == NBR) {                                 \
-            constexpr int lds = scn_lane_lds_bytes(KIND, NN, LL, MM, NBR);                                                  \
-            if (describe("scn_lane_kernel<%d,%d,%d,%d,%d> grid %d threads %d lds %d; ", KIND, NN, LL, MM, NBR,               \
-                         8 * (((B + 63) / 64 + 7) / 8), 64 + 64 * scn_lane_writers(KIND), lds)) return FG_OK;               \
-            hipLaunchKernelGGL((scn_lane_kernel<KIND, NN, LL, MM, NBR>), dim3(8 * (((B + 63) / 64 + 7) / 8)),               \
-                               dim3(64 + 64 * scn_lane_writers(KIND)),                                                      \
-                               lds, st, a);                                                                                 \
+            const int rc = (WIDE && scn_lane_wide<KIND>(B, obs_bytes)) ? launch_scn_lane<KIND, NN, LL, MM, NBR, (WIDE ? 4 : 1)>(a, st)  \
+                                                            : launch_scn_lane<KIND, NN, LL, MM, NBR, 1>(a, st);            \
+            if (g_describe) return rc;                                                                                      \
             launched = true;                                                                                                \
         }
-        FG_SCN_LANE(FG_SCN_BASIC, 3, 3, 0, 2)            // basic_formation_env.py:7
-        FG_SCN_LANE(FG_SCN_PARTIAL, 5, 5, 0, 3)          // formation_hd_partial_env.py:15
-        FG_SCN_LANE(FG_SCN_RANGE, 4, 4, 0, 3)            // formation_hd_partial_range_env.py:15
-        FG_SCN_LANE(FG_SCN_OBSTACLE, 4, 4, 3, 3)         // formation_hd_obs_env.py:14
-        FG_SCN_LANE(FG_SCN_PARTIAL, 3, 5, 0, 3)          // make_env(name) passes its own default num_agents = 3 (__init__.py:6-11)
-        FG_SCN_LANE(FG_SCN_RANGE, 3, 4, 0, 2)
-        FG_SCN_LANE(FG_SCN_OBSTACLE, 3, 4, 3, 2)
+        // (WIDE: the 256-env form exists for this shape, see scn_lane_wide)
+        FG_SCN_LANE(FG_SCN_BASIC, 3, 3, 0, 2, true)            // basic_formation_env.py:7
+        FG_SCN_LANE(FG_SCN_PARTIAL, 5, 5, 0, 3, true)          // formation_hd_partial_env.py:15
+        FG_SCN_LANE(FG_SCN_RANGE, 4, 4, 0, 3, true)            // formation_hd_partial_range_env.py:15
+        FG_SCN_LANE(FG_SCN_OBSTACLE, 4, 4, 3, 3, false)        // formation_hd_obs_env.py:14
+        FG_SCN_LANE(FG_SCN_PARTIAL, 3, 5, 0, 3, false)         // make_env(name) passes its own default num_agents = 3 (__init__.py:6-11)
+        FG_SCN_LANE(FG_SCN_RANGE, 3, 4, 0, 2, false)
+        FG_SCN_LANE(FG_SCN_OBSTACLE, 3, 4, 3, 2, false)
 #undef FG_SCN_LANE
         if (launched) {
             const hipError_t err = hipGetLastError();

@@ -72,8 +72,8 @@ def _current(lib):
     for name, kind, N, L, M, num_obs in shapes:
         sc = _native.FgScenario(kind=kind, num_landmarks=L, num_obstacles=M, num_obs=num_obs, obs_range=0.5, obstacle_size=0.15,
                                 obstacle_vx=0.0, obstacle_vy=-1.0, obstacle_floor=-2.2, penalty=1.0)
-        for B in (100, 4096, 65536):
-            for K in (1, 20):
+        for B in (100, 4096, 65536, 131072):
+            for K in (1, 20, 128):
                 out["%s N=%d L=%d M=%d B=%d K=%d" % (name, N, L, M, B, K)] = _describe(lib, _params(), sc, B, N, K)
     return out
 

@@ -94,6 +94,33 @@ def test_lane_kernel_equals_the_runtime_count_kernel(shape, B):
             assert (o0["indiv"] != o0["indiv"][..., :1]).any() or M, "no collision penalty anywhere: the start is not crowded"
 
 
+@pytest.mark.parametrize("shape,B,K,obs_every", [(SHAPES[0], 65536, 32, 1), (SHAPES[0], 393216 + 70, 6, 1), (SHAPES[1], 131072, 8, 1),
+                                                 (SHAPES[2], 131072, 24, 2)],
+                         ids=lambda v: "%s-%d" % v[:2] if isinstance(v, tuple) else str(v))
+def test_wide_lane_kernel_equals_the_runtime_count_kernel(shape, B, K, obs_every):
+    """The 256-env workgroups of the lane kernels (four producer waves; taken where they fill whole generations of 256 workgroups
+    and the observation buffer is beyond the Infinity Cache: profiles/r05_lane_pw_ab.txt) against the run-time-count kernel, bit
+    for bit, a ragged last workgroup and episodes ending inside the launch included."""
+    from formation_gym import _native
+    import ctypes
+    kind, N, L, M = shape[:4]
+    st, p, sc, D = _setup(*shape, B=B, crowd=0.3, seed=5 * N + K)
+    assert (K // obs_every) * B * N * D * 4 > 400e6
+    buf = ctypes.create_string_buffer(512)
+    sc.variant = 0
+    assert _native.load().fg_describe_launch(p, sc, B, N, K, 0, obs_every, 0, buf, len(buf)) == 0
+    assert ("scn_lane_kernel<%d,%d,%d,%d," % (sc.kind, N, L, M)) in buf.value.decode() and ",4> grid" in buf.value.decode(), buf.value
+    W = shape[6]
+    st["step"] = torch.where(torch.arange(B, device="cuda") % 3 == 0, W - 4, 2).to(torch.int32)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(B)
+    acts = (torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1).contiguous()
+    s0, o0 = _rollout(st, p, sc, B, N, D, acts, obs_every, 0)
+    s1, o1 = _rollout(st, p, sc, B, N, D, acts, obs_every, 1)
+    _same(o0, o1, "%s N=%d B=%d K=%d" % (kind, N, B, K))
+    _same(s0, s1, "%s N=%d B=%d K=%d state" % (kind, N, B, K))
+    assert bool(o0["done"].any()) and torch.isfinite(o0["obs"]).all()
+
+
 @pytest.mark.parametrize("shape", SHAPES[:4], ids=lambda s: "%s-%d-%d-%d" % s[:4])
 def test_lane_kernel_observation_only_and_world_options(shape):
     """do_physics = 0 (what env.reset() returns) and the World options (walls, speed clamp, accel, motor noise) go
