@@ -20,34 +20,38 @@
 
 namespace fg {
 
-__host__ __device__ constexpr int hd_lane_block_bytes(int n) { return 64 * scn_lane_pitch(3 * n * n) * 8 + 3 * 64 * n * 4; }
+// (pw producer waves per workgroup: the block is the image of 64 pw envs, see lane_writer_wave)
+__host__ __device__ constexpr int hd_lane_block_bytes(int n, int pw = 1) { return pw * (64 * scn_lane_pitch(3 * n * n) * 8 + 3 * 64 * n * 4); }
 __host__ __device__ constexpr bool hd_lane_double(int n) { return 2 * hd_lane_block_bytes(n) <= 40 * 1024; }
-__host__ __device__ constexpr int hd_lane_lds_bytes(int n) { return (hd_lane_double(n) ? 2 : 1) * hd_lane_block_bytes(n); }
+__host__ __device__ constexpr int hd_lane_lds_bytes(int n, int pw = 1) { return (hd_lane_double(n) ? 2 : 1) * hd_lane_block_bytes(n, pw); }
 
 // PER > 0: closed loop - the action of step k is the demo controller (PER-ary hierarchy, N = PER^L) on the state step k-1 left,
 // evaluated by the env's lane on its registers (bfs_policy_lane); a.act is not read, a.act_out records the actions.  The
 // lane-per-agent closed loop ran 4 x 65536 at 8.6 us/step against the open loop's 4.95 (0.44 of the HBM rate in real bytes).
-template <int N, int PER = 0>
-__global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
+template <int N, int PER = 0, int PW = 1>
+__global__ __launch_bounds__(128 * PW) void hd_lane_kernel(const Args a) {
     constexpr bool POLICY = PER > 0;
     static_assert(N >= 3 && N <= 4, "one env per lane: the LDS block of 64 envs must leave room for four workgroups per CU");
     constexpr int G = 4;                                // the lane group of step_kernel / rollout_kernel at 3 and 4 agents
     constexpr int D = 6 * N, U = 3 * N * N, SU = scn_lane_pitch(U);
     constexpr bool DB = hd_lane_double(N);
-    constexpr int BLOCK_UNITS = hd_lane_block_bytes(N) / 8;
+    constexpr int BLOCK_UNITS = hd_lane_block_bytes(N, PW) / 8;
+    constexpr int ENVS = 64 * PW;
     extern __shared__ __attribute__((aligned(16))) float2 smem_all[];
     const int lane = threadIdx.x & 63;
     const int per_xcd = (int)(gridDim.x >> 3);          // XCD-aware workgroup order, as in scn_lane_kernel
     const int wg = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    const int b0 = wg * 64;
+    const int b0 = wg * ENVS;
     if (b0 >= a.B) return;
-    const int b = b0 + lane;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slot = wave * 64 + lane;                  // the lane's env inside the workgroup (producer waves)
+    const int b = b0 + slot;
     const bool live = b < a.B;
     const int bl = live ? b : a.B - 1;
-    const int El = min(64, a.B - b0);
+    const int El = min(ENVS, a.B - b0);
     const int KS = a.K;
-    if (threadIdx.x >= 64) {
-        lane_writer_wave<N, D, DB, 1>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane, 0);
+    if (wave >= PW) {
+        lane_writer_wave<N, D, DB, PW, PW>(smem_all, KS, a.B, b0, El, a.obs_every, a.obs, a.rew, a.indiv, a.done, lane, wave - PW);
         return;
     }
     // ---- PRODUCER wave: lane = env ----
@@ -203,15 +207,15 @@ __global__ __launch_bounds__(128) void hd_lane_kernel(const Args a) {
         const bool want_obs = a.obs_every <= 1 || (ks + 1) % a.obs_every == 0;
         if (!DB) __syncthreads();                       // A (one block): the writer has read the block of step ks - 1
         float2* const smem = smem_all + (DB ? (ks & 1) * BLOCK_UNITS : 0);
-        float* const s_rew = reinterpret_cast<float*>(smem + 64 * SU);
-        float* const s_ind = s_rew + 64 * N;
-        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + 64 * N);
+        float* const s_rew = reinterpret_cast<float*>(smem + ENVS * SU);
+        float* const s_ind = s_rew + ENVS * N;
+        uint32_t* const s_done = reinterpret_cast<uint32_t*>(s_ind + ENVS * N);
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            s_rew[lane * N + i] = shared; s_ind[lane * N + i] = indiv[i]; s_done[lane * N + i] = done_flag;
+            s_rew[slot * N + i] = shared; s_ind[slot * N + i] = indiv[i]; s_done[slot * N + i] = done_flag;
         }
         if (want_obs) {
-            float2* const mine = smem + lane * SU;
+            float2* const mine = smem + slot * SU;
 #pragma unroll
             for (int i = 0; i < N; ++i) {                // row i: [v_i | p_j - p_i (j != i) | zeros | ideal_shape | ideal_vel]
                 float2* const o = mine + i * (D / 2);

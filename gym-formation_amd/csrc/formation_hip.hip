@@ -463,12 +463,16 @@ static int launch_roll_64(const Args& a, hipStream_t st) {
 // loop (actions from act_seq); else the closed loop of fg_rollout_hd_policy.  Returns false when (N, per) has no instantiation
 // (the caller then runs step_kernel's K-loop / chained launches).
 // 3 and 4 agents, open loop, contiguous observations, a batch that fills the chip: one env per lane (fg_hd_lane_kernel.hpp)
-template <int NC, int PER = 0>
+template <int NC, int PER = 0, int PW = 1>
 static int launch_hd_lane(const Args& a, hipStream_t st) {
-    const int grid = 8 * (((a.B + 63) / 64 + 7) / 8);
-    if (describe("hd_lane_kernel<%d,%d> grid %d lds %d; ", NC, PER, grid, hd_lane_lds_bytes(NC))) return FG_OK;
-    hipLaunchKernelGGL((hd_lane_kernel<NC, PER>), dim3(grid), dim3(128), hd_lane_lds_bytes(NC), st, a);
-    const hipError_t err = hipGetLastError();
+    const int grid = 8 * (((a.B + 64 * PW - 1) / (64 * PW) + 7) / 8);
+    constexpr int lds = hd_lane_lds_bytes(NC, PW);
+    if (describe("hd_lane_kernel<%d,%d,%d> grid %d lds %d; ", NC, PER, PW, grid, lds)) return FG_OK;
+    static std::atomic<unsigned long long> raised{0};
+    hipError_t err = raise_lds_limit((const void*)&hd_lane_kernel<NC, PER, PW>, lds, &raised);
+    if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
+    hipLaunchKernelGGL((hd_lane_kernel<NC, PER, PW>), dim3(grid), dim3(128 * PW), lds, st, a);
+    err = hipGetLastError();
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
@@ -479,6 +483,19 @@ constexpr int FG_HD_LANE_MIN_B = 32768;
 static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
 #define FG_ROLL(FN, NN, PP) if (a.N == NN && per == PP) { *rc = FN<NN, PP>(a, st); return true; }
     if (a.B >= FG_HD_LANE_MIN_B && a.obs_pitch == 3LL * a.N * a.N) {
+        // Several producer waves per workgroup - one span of 256 (128) envs per workgroup and step - into a buffer beyond the
+        // Infinity Cache (profiles/r05_lane_pw_ab.txt): open loop from 65536 envs with four (3 x 65536 3.02 -> 2.79 us/step, 0.73 ->
+        // 0.79 of 8 TB/s in real bytes; 3 x 131072 6.13 -> 5.60, 4 x 131072 10.44 -> 9.61; 4 x 49152 would lose, 3.84 -> 4.47); the
+        // closed loop from 98304 envs with two (3 x 98304 5.02 -> 4.28, 4 x 131072 10.18 -> 9.32; at 65536 one stays ahead, 2.70 vs 2.82)
+        const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+        if (hbm && per == 0 && a.B >= 65536) {
+            if (a.N == 3) { *rc = launch_hd_lane<3, 0, 4>(a, st); return true; }
+            if (a.N == 4) { *rc = launch_hd_lane<4, 0, 4>(a, st); return true; }
+        }
+        if (hbm && per > 0 && a.B >= 98304) {
+            if (a.N == 3 && per == 3) { *rc = launch_hd_lane<3, 3, 2>(a, st); return true; }
+            if (a.N == 4 && per == 2) { *rc = launch_hd_lane<4, 2, 2>(a, st); return true; }
+        }
         if (a.N == 3 && per == 0) { *rc = launch_hd_lane<3>(a, st); return true; }
         if (a.N == 4 && per == 0) { *rc = launch_hd_lane<4>(a, st); return true; }
         // ... and the closed loop with the controller on the lane's registers (bfs_policy_lane)

@@ -100,7 +100,7 @@ def test_the_headline_shapes_take_the_kernels_the_profiles_name(lib):
     assert d(243, 8192, 4).startswith("rollout_kernel_wide<243,4,4,256,0,0> grid 2048")
     assert d(243, 8192, 0).startswith("rollout_kernel_wide<243,4,4,256,0,1>")          # single step: pipelined over env batches
     assert d(27, 4096, 0).startswith("step_kernel<27,32,256,4,0,0,1> grid 1024")
-    assert _describe(lib, _params(), None, 65536, 4, 20, per=2).startswith("hd_lane_kernel<4,2>")
+    assert _describe(lib, _params(), None, 65536, 4, 20, per=2).startswith("hd_lane_kernel<4,2,1>")
 
 
 def test_every_rule_names_a_measurement_that_is_in_the_repo():

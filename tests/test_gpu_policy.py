@@ -155,6 +155,7 @@ def test_policy_closed_loop_reduces_formation_error_and_tracks_reference(golden)
                                         (64, 5, 4, 4), (64, 5, 4, 8), (125, 3, 3, 5), (16, 8192, 4, 4), (64, 2048, 3, 4), (25, 3000, 4, 5),
                                         (9, 5000, 4, 3), (9, 8200, 3, 3),      # 9 agents, closed loop with the gather writer
                                         (3, 32800, 4, 3), (4, 32768, 4, 2), (4, 33000, 3, 4),   # one env per lane, controller on registers
+                                        (3, 98400, 20, 3), (4, 98354, 12, 2),                   # ... two producer waves per workgroup
                                         (8, 5000, 3, 8), (8, 65600, 2, 8),                       # 8 agents: gather writer, two / one writer waves
                                         (8, 32810, 3, 2), (8, 12300, 3, 8),                      # ... and 32-env workgroups from 12288 envs
                                         (36, 6, 3, 6)])          # 6^2: no pipelined instantiation - chained launches
