@@ -184,10 +184,10 @@ class MultiAgentEnv(object):
         call, or pass out=False (fresh, ordinary tensors on every call) or your own `out`.  The four most recently used
         (K, obs_every, policy) shapes keep their buffers; `env.default_placed = False` makes out=None mean out=False."""
         roll = getattr(self.scenario, "rollout_batch", None)
-        if roll is None:
-            raise NotImplementedError("%s has no multi-step launch; call step()" % type(self.scenario).__name__)
-        if self.post_step_callback is not None:
-            raise NotImplementedError("post_step_callback runs on the host after every step; call step()")
+        if roll is None or self.post_step_callback is not None:
+            # no multi-step launch (a reference-style Scenario file: its callbacks run on the host), or a post_step_callback
+            # (environment.py:140-141: a host function after every step): K `step` calls behind the same interface
+            return self._rollout_by_steps(action_seq, out, int(obs_every))
         mode = self._action_mode()
         if mode:
             # the discrete action modes of _set_action (environment.py:194-215): the whole sequence is decoded to raw u in
@@ -246,6 +246,38 @@ class MultiAgentEnv(object):
         rew = out["reward"] if self.shared_reward else out["indiv"]
         return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), {"individual_reward": out["indiv"]}
 
+    def _rollout_by_steps(self, action_seq, out, obs_every):
+        """`rollout` as K calls of `step` (host-paced: one launch - and whatever the scenario / the post_step_callback does on
+        the host - per step), results stacked like `rollout`'s."""
+        K = int(len(action_seq))
+        if K < 1 or obs_every < 1:
+            raise ValueError("need K >= 1 steps and obs_every >= 1")
+        B, N = self.num_envs, self.num_agents
+        D = self._out["obs"].shape[-1]
+        dev = self._act.device
+        if out is None or out is False:
+            f = dict(dtype=torch.float32, device=dev)
+            out = dict(obs=torch.empty((K // obs_every, B, N, D), **f), reward=torch.empty((K, B, N), **f),
+                       indiv=torch.empty((K, B, N), **f), done=torch.zeros((K, B, N), dtype=torch.uint8, device=dev))
+        want = dict(obs=(K // obs_every, B, N, D), reward=(K, B, N), indiv=(K, B, N), done=(K, B, N))
+        for k, shp in want.items():
+            if k not in out or tuple(out[k].shape) != shp:
+                raise ValueError("out[%r] must be a tensor of shape %s" % (k, shp))
+        first = None if self.shared_reward else torch.empty((K, B, N), dtype=torch.float32, device=dev)
+        for k in range(K):
+            act = action_seq[k]
+            if torch.is_tensor(act) and (act.dtype != torch.float32 or act.device != dev) and not self._action_mode():
+                act = act.to(device=dev, dtype=torch.float32)
+            o, r, d, info = self.step(act if torch.is_tensor(act) else torch.as_tensor(act, device=dev))
+            out["reward"][k].copy_(self._out["reward"]); out["indiv"][k].copy_(self._out["indiv"])
+            out["done"][k].copy_(self._out["done"])
+            if first is not None:
+                first[k].copy_(r[..., 0])
+            if (k + 1) % obs_every == 0:
+                out["obs"][k // obs_every].copy_(o)
+        rew = out["reward"] if self.shared_reward else first
+        return out["obs"], rew.unsqueeze(-1), out["done"].view(torch.bool), {"individual_reward": out["indiv"]}
+
     def rollout_policy(self, K, num_agents_per_layer=3, out=None, obs_every=1):
         """The reference's demo loop (test.py:17-27) for K steps in one call:
             act_n = get_action_BFS(ezpolicy, obs_n, num_agents_per_layer); obs_n, ... = env.step(act_n)
@@ -257,9 +289,23 @@ class MultiAgentEnv(object):
             raise NotImplementedError("%s has no built-in controller" % type(self.scenario).__name__)
         if self._action_mode():
             raise NotImplementedError("the built-in controller emits raw continuous actions")
-        if self.post_step_callback is not None:
-            raise NotImplementedError("post_step_callback runs on the host after every step; call step()")
         K, obs_every = int(K), int(obs_every)
+        if self.post_step_callback is not None:
+            # a host function after every step (environment.py:140-141): the demo loop itself, launch by launch
+            from .policy_bfs import ezpolicy, get_action_BFS
+            if K < 1 or obs_every < 1:
+                raise ValueError("need K >= 1 steps and obs_every >= 1")
+            acts = torch.empty((K,) + tuple(self._act.shape), dtype=torch.float32, device=self._act.device)
+            res = {k: [] for k in ("obs", "rew", "done", "indiv")}
+            obs = self._out["obs"]
+            for k in range(K):
+                acts[k].copy_(get_action_BFS(ezpolicy, obs, int(num_agents_per_layer)))
+                obs, r, d, info = self.step(acts[k])
+                if (k + 1) % obs_every == 0:
+                    res["obs"].append(obs.clone())
+                res["rew"].append(r.clone()); res["done"].append(d.clone()); res["indiv"].append(info["individual_reward"].clone())
+            return (torch.stack(res["obs"]) if res["obs"] else obs.new_empty((0,) + tuple(obs.shape)), torch.stack(res["rew"]),
+                    torch.stack(res["done"]), {"individual_reward": torch.stack(res["indiv"]), "actions": acts})
         if K < 1 or obs_every < 1:
             raise ValueError("need K >= 1 steps and obs_every >= 1")
         B, N = self.num_envs, self.num_agents

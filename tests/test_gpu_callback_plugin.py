@@ -190,3 +190,57 @@ class Scenario(BaseScenario):
         # calls 1, 3, 5 are the first per agent; 2, 4, 6 the second
         assert [i["individual_reward"] for i in info_n] == [2.0, 4.0, 6.0]
         assert rew_n == ([[9.0]] * 3 if collab else [[1.0], [3.0], [5.0]])
+
+
+def test_rollout_interface_for_host_paced_envs():
+    """env.rollout for envs that have no multi-step launch - a reference-style Scenario file (callbacks on the host) and an env
+    with a post_step_callback (environment.py:140-141: a host function after every step) - runs K `step` calls behind the same
+    interface: the same results as stepping by hand, the same shapes as the fused launches return."""
+    import formation_gym
+    N, B, K = 5, 3, 7
+    envs = []
+    for _ in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            e = formation_gym.make_env(PLUGIN, False, N, num_envs=B, device="cuda:0")
+        e.seed(4); e.reset()
+        envs.append(e)
+    a, b = envs
+    gen = torch.Generator(device="cuda"); gen.manual_seed(1)
+    acts = torch.rand((K, B, N, 2), generator=gen, device="cuda") * 2 - 1
+    obs, rew, done, info = b.rollout(acts, obs_every=2)
+    assert tuple(obs.shape) == (K // 2, B, N, a._out["obs"].shape[-1]) and tuple(rew.shape) == (K, B, N, 1) and done.dtype == torch.bool
+    for k in range(K):
+        o, r, d, i = a.step(acts[k])
+        assert torch.equal(r, rew[k]) and torch.equal(d, done[k]) and torch.equal(i["individual_reward"], info["individual_reward"][k])
+        if (k + 1) % 2 == 0:
+            assert torch.equal(o, obs[k // 2])
+    assert a.current_step == b.current_step == K
+    # ... and formation_hd_env with a post_step_callback that edits the device state after every step
+    calls = []
+    twins = []
+    for _ in range(2):
+        e = formation_gym.make_env("formation_hd_env", False, 9, num_envs=16, device="cuda:0")
+        e.seed(2); e.reset()
+        e.post_step_callback = lambda world: (calls.append(1), world.vel_x.mul_(0.5))
+        twins.append(e)
+    a, b = twins
+    acts = torch.rand((4, 16, 9, 2), generator=gen, device="cuda") * 2 - 1
+    obs, rew, done, info = b.rollout(acts)
+    assert len(calls) == 4
+    for k in range(4):
+        o, r, d, i = a.step(acts[k])
+        assert torch.equal(o, obs[k]) and torch.equal(r, rew[k]) and torch.equal(d, done[k])
+    assert len(calls) == 8
+    for x, y in zip(a.world.get_state(), b.world.get_state()):
+        assert torch.equal(x, y)
+    # ... and the built-in controller in the loop (rollout_policy) with that callback: the demo loop, launch by launch
+    n0 = len(calls)
+    o_seq, r_seq, d_seq, info = b.rollout_policy(3, 3)
+    assert len(calls) == n0 + 3 and tuple(info["actions"].shape) == (3, 16, 9, 2)
+    obs_a = a._out["obs"]
+    for k in range(3):
+        act = formation_gym.get_action_BFS(formation_gym.ezpolicy, obs_a, 3)
+        assert torch.equal(act, info["actions"][k])
+        obs_a, r, d, i = a.step(act)
+        assert torch.equal(obs_a, o_seq[k]) and torch.equal(r, r_seq[k]) and torch.equal(d, d_seq[k])
