@@ -31,7 +31,7 @@ __host__ __device__ constexpr int hd_lane_lds_bytes(int n, int pw = 1) { return 
 template <int N, int PER = 0, int PW = 1>
 __global__ __launch_bounds__(128 * PW) void hd_lane_kernel(const Args a) {
     constexpr bool POLICY = PER > 0;
-    static_assert(N >= 3 && N <= 4, "one env per lane: the LDS block of 64 envs must leave room for four workgroups per CU");
+    static_assert(N >= 3 && N <= 4, "one env per lane: the LDS block of 64 envs must leave room for four producer waves per CU");
     constexpr int G = 4;                                // the lane group of step_kernel / rollout_kernel at 3 and 4 agents
     constexpr int D = 6 * N, U = 3 * N * N, SU = scn_lane_pitch(U);
     constexpr bool DB = hd_lane_double(N);

@@ -7,9 +7,11 @@
 // and landmarks live in its registers, every pair loop is unrolled, nothing is reduced across lanes, and the 64
 // environments of a wave form ONE contiguous span of the [B][N][D] observation tensor - composed row by row in LDS
 // (conflict-free: odd row pitch) and streamed out with lane-consecutive 16-byte stores.
-// A workgroup is TWO waves sharing 64 environments: the PRODUCER wave (lane = env) runs World.step + reward of step k+1
-// while the WRITER wave streams step k's observations, rewards and done flags from LDS to global memory; two workgroup
-// barriers per step hand the LDS block back and forth.  The split also keeps the two kinds of memory traffic on
+// A workgroup is PW PRODUCER waves (lane = env: 64 PW environments, one span of the tensor) and as many WRITER waves (twice
+// as many for basic_formation_env): the producers run World.step + reward of step k+1 while the writers stream step k's
+// observations, rewards and done flags from LDS to global memory; one or two workgroup barriers per step hand the LDS
+// block(s) back and forth.  PW = 1 everywhere but for large batches into HBM-size buffers, where four producer waves per
+// workgroup - a 256-env span per workgroup and step - run 7-10 % faster (formation_hip.hip: scn_lane_wide).  The split also keeps the two kinds of memory traffic on
 // different waves: on gfx9 loads and stores share one counter (vmcnt), so a wave that both prefetches its next actions
 // and stores its outputs has to drain its whole store stream before it can use the prefetched action - the one-wave form
 // of this kernel spent a third of every step doing that (basic 3 x 65536: 3.99 us/step against the two-wave form's figure
