@@ -268,8 +268,13 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
             return None
 
 
-# a probe whose winner is not at least 3 % faster than the arena's first chunks has learnt nothing from this arena
-ESCALATE_BELOW_GAIN = 0.97
+# A probe whose winner is not at least 8 % faster than the arena's first chunks has learnt too little from this arena: where
+# placement matters at all (the median candidate is not within 2.5 % of the best, see ESCALATE_INSENSITIVE) a normal first arena
+# offers 12-23 % (27 x 4096 x 20: 0.2335-0.24 ms against 0.27-0.28 as created; 9 x 4096 x 128: 0.190 against 0.246); on some boxes
+# its best composition is only 5-7 % ahead (round 5: 0.2555 against 0.2705, the bench at 0.77 of peak instead of 0.83) and the
+# good memory lies outside the first 6-9 GB (round 4's fresh box: 0.73 from 8.7 and 34.5 GB, 0.83 from 138 GB).  (3 % until late
+# round 5.)
+ESCALATE_BELOW_GAIN = 0.92
 # Every probed buffer gets the second look: on one fresh box the first 8.7 GB ran ALL 65 spread compositions of the 1.4 GB
 # headline buffer slower than its first chunks (0.283-0.290 ms against 0.267; a normal arena: 0.236-0.243), 0.73 instead of
 # 0.82 of peak.  The price is paid by launches that placement cannot help: 9 x 4096 x 128, bound by its dependent chain, goes

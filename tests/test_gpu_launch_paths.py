@@ -909,7 +909,7 @@ def test_default_rollout_places_its_buffer_cheaply_and_gives_the_memory_back():
 
 
 def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypatch):
-    """placement.probe_arena escalates - 4 x the arena, twice at most - when its winner is not 3 % faster than the arena's
+    """placement.probe_arena escalates - 4 x the arena, twice at most - when its winner is not 8 % faster than the arena's
     first chunks (some boxes' first ~10 GB run every composition of a multi-GB buffer alike and slow: profiles/r04_place/).
     Forced here by asking for an impossible gain: three stages, each arena closed before the next is made, the kept
     buffer usable, every byte back afterwards."""
