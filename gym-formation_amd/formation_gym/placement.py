@@ -213,8 +213,8 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
     `budget_s` affords them (a 0.25 ms launch can afford many, and its selections differ by 20 %; a 7 ms launch's differ
     by 1 %).  One candidate is mapped at a time (a chunk never has two addresses), the three fastest are mapped and timed
     once more, the winner is mapped for good and every other chunk goes back to the driver.  An arena whose winner is not
-    3 % faster than its own first chunks is closed and followed by one four times as large (`next_arena_bytes`, at most
-    two such steps, report["stages"]); a caller that passes `max_arena_bytes` or escalate=False gets exactly one arena.
+    8 % faster than its own first chunks is followed by one four times as large (`next_arena_bytes`, at most two such steps,
+    report["stages"]; the better of the stages' winners is kept, the other arenas closed); a caller that passes `max_arena_bytes` or escalate=False gets exactly one arena.
     An error of the launch itself (`time_fn` raising) propagates: only arena / mapping failures fall back."""
     import math
     import random
@@ -230,25 +230,37 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         return None
     stages = []
     previous = None
+    held = None        # the winner of an earlier stage, kept (its arena holds only the buffer by then) while a larger arena is tried
     while True:
         placed = _probe_stage(geometry, nfloats, time_fn, device, trials, reps, seed + len(stages), budget_s, free, t_start,
                               stage_index=len(stages))
         if placed is None:
+            if held is not None:                                 # the larger arena could not be made or used: what we have
+                held[1]["stages"] = stages + [{"arena_GB": round(geometry[0] / 1e9, 1), "failed": True}]
+                return held
             if previous is None:
                 return None
-            # the larger arena could not be made or used: the size that worked, once more, and no further stage
+            # (no winner held: cannot happen since an escalation keeps one) the size that worked, once more, and no further stage
             placed = _probe_stage(previous, nfloats, time_fn, device, trials, reps, seed, budget_s, free, t_start)
             if placed is None:
                 return None
             placed[1]["stages"] = stages + [{"arena_GB": placed[1]["arena_GB"], "kept_ms": placed[1]["kept_ms"],
                                              "as_created_ms": placed[1]["as_created_ms"], "after_failed_stage": True}]
             return placed
+        stages.append({"arena_GB": placed[1]["arena_GB"], "kept_ms": placed[1]["kept_ms"], "as_created_ms": placed[1]["as_created_ms"]})
+        if held is not None:
+            # the better of the two winners stays, the other arena goes back to the driver (a larger arena is a different
+            # sample of the device's memory, not a superset: its best composition can be the slower one)
+            keep, drop = (held, placed) if held[1]["kept_ms"] <= placed[1]["kept_ms"] else (placed, held)
+            drop_arena = drop[2]
+            held = placed = drop = None
+            drop_arena.close()
+            placed = keep
         flat, report, arena = placed
-        stages.append({"arena_GB": report["arena_GB"], "kept_ms": report["kept_ms"], "as_created_ms": report["as_created_ms"]})
         report["stages"] = stages
         # Some boxes hand out a first ~10 GB in which EVERY composition of a multi-GB buffer runs alike and slow
         # (profiles/r04_place/README.md: 81 x 2048 x 20 at 62.5 us/step from a 10 GB arena, nothing gained over the plain
-        # allocation, where other boxes reach 50.5): when the arena offered nothing, look at four times as much memory, twice
+        # allocation, where other boxes reach 50.5): when the arena offered too little, look at four times as much memory, twice
         # at most, within `mem_fraction` of what is free.  A caller that names the arena size gets that size.
         bigger = next_arena_bytes(geometry[0], nbytes, free, mem_fraction)
         # ... unless the launch does not care where its buffer lies: when the arena's first chunks and the median spread candidate ran within 2.5 % of the
@@ -260,12 +272,12 @@ def probe_arena(nfloats, time_fn, device, trials=8, mem_fraction=0.5, max_arena_
         if (max_arena_bytes is not None or not escalate or nbytes < ESCALATE_MIN_BYTES or len(stages) >= 3 or bigger is None
                 or insensitive or stages[0]["arena_GB"] * 1e9 >= ESCALATE_MAX_FIRST_ARENA or report["kept_ms"] <= ESCALATE_BELOW_GAIN * report["as_created_ms"]):
             return placed
-        del flat, placed
-        arena.close()
+        held = placed
+        del flat, report, arena, placed
         previous = geometry
         geometry = arena_geometry(nbytes, free, mem_fraction, bigger)
         if geometry is None:                                     # cannot happen (bigger > what worked), but never loop on it
-            return None
+            return held
 
 
 # A probe whose winner is not at least 8 % faster than the arena's first chunks has learnt too little from this arena: where

@@ -925,7 +925,7 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     flat, rep, arena = placement.probe_arena(n, lambda dst: dst.copy_(src), "cuda", trials=4, budget_s=0.1)
     sizes = [s["arena_GB"] for s in rep["stages"]]
     assert len(sizes) == 3 and sizes[1] >= 3.9 * sizes[0] and sizes[2] >= 3.9 * sizes[1], rep
-    assert rep["arena_GB"] == sizes[-1]
+    assert rep["arena_GB"] in sizes and rep["kept_ms"] <= min(s["kept_ms"] for s in rep["stages"]) * 1.0001   # the best stage's winner is kept
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 <= 2 * n * 4 + n * 4 // 4 + (256 << 20), "closed stages still hold memory: %.2f GB" % ((free0 - free1) / 1e9)
     flat.copy_(src); torch.cuda.synchronize()
@@ -935,7 +935,7 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
     del src
     gc.collect(); torch.cuda.empty_cache()
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)
-    # a larger arena that cannot be made: the size that worked is probed once more and kept
+    # a larger arena that cannot be made: the first stage's winner, which was held meanwhile, is what comes back
     real_stage, calls = placement._probe_stage, []
 
     def failing_second(geometry, *args, **kw):
@@ -943,8 +943,8 @@ def test_probe_looks_at_more_memory_when_the_first_arena_gains_nothing(monkeypat
         return None if len(calls) == 2 else real_stage(geometry, *args, **kw)
     monkeypatch.setattr(placement, "_probe_stage", failing_second)
     flat, rep, arena = placement.probe_arena(n, lambda dst: dst.zero_(), "cuda", trials=4, budget_s=0.1)
-    assert len(calls) == 3 and calls[2] == calls[0] and calls[1] > 3.9 * calls[0]
-    assert len(rep["stages"]) == 2 and rep["stages"][1].get("after_failed_stage")
+    assert len(calls) == 2 and calls[1] > 3.9 * calls[0]
+    assert len(rep["stages"]) == 2 and rep["stages"][1].get("failed") and rep["arena_GB"] == rep["stages"][0]["arena_GB"]
     flat.fill_(2.0); torch.cuda.synchronize()
     del flat
     arena.close()
