@@ -19,18 +19,19 @@ namespace fg {
 // rows of one env round-robin over the waves that share it.
 // ---------------------------------------------------------------------------
 // value select (never a pointer select: that would go through scratch + flat loads)
-FG_DEV float2 lds_if(bool c, const float2* __restrict__ p, int idx_if_true) {
-    const float2 t = p[c ? idx_if_true : 0];
-    return make_float2(c ? t.x : 0.0f, c ? t.y : 0.0f);
+template <class V2> FG_DEV V2 lds_if(bool c, const V2* __restrict__ p, int idx_if_true) {
+    V2 t = p[c ? idx_if_true : 0];
+    t.x = c ? t.x : 0.0f; t.y = c ? t.y : 0.0f;
+    return t;
 }
 
 constexpr bool FG_ROWS_MERGED = true;      // N > 64: rows as chunks of 64 consecutive units across the field boundary (below)
 template <int NC, int NW, int E, int PACE = 0>
-FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, int w,
-                           float2* __restrict__ out_env0, size_t env_units, int El, int parts,
+FG_DEV void write_obs_rows(const real2* __restrict__ tables0, int env_stride, int w,
+                           real2* __restrict__ out_env0, size_t env_units, int El, int parts,
                            int wg_part = 0, int wg_parts = 1, bool pace_on = true) {
-    // tables0 / env_stride: A-table of env 0 and the distance (float2) to the next env's;
-    // out_env0 / env_units: observation block of env 0 and the distance (float2 units) to the next env's
+    // tables0 / env_stride: A-table of env 0 and the distance (real2) to the next env's;
+    // out_env0 / env_units: observation block of env 0 and the distance (real2 units) to the next env's
     //   (3 N^2 when the [B][N][6N] tensor is contiguous; larger with a padded env pitch or strided env ownership)
     // w: index of this wave among the NW waves that share the job
     // parts: bit 0 = relative-position units, bit 1 = static units (zeros | shape | ideal_vel)
@@ -43,8 +44,8 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
     const int row0 = (E >= NW) ? 0 : w % WPE;
     constexpr unsigned ROWU = 3u * N;                       // units per row
     for (int ee = (E >= NW) ? w : w / WPE; ee < El; ee += (E >= NW ? ESTEP : E)) {
-        const float2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
-        float2* __restrict__ out = out_env0 + (size_t)ee * env_units;
+        const real2* __restrict__ AA = tables0 + (size_t)ee * env_stride;
+        real2* __restrict__ out = out_env0 + (size_t)ee * env_units;
         if constexpr (N <= 64) {
             // Blocks of RW = 64/N rows: one wave store covers the relative-position part of the
             // whole block, then the static part (zeros | ideal_shape | ideal_vel, the same for every
@@ -53,15 +54,15 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             constexpr int RW = 64 / N;
             const int rsub = lane / N, u = lane - rsub * N;
             const bool act = rsub < RW;
-            const float2 zero = make_float2(0.f, 0.f);
-            const float2 Pm = lds_if(act && u >= 1, AA, u - 1);
-            const float2 Pu = lds_if(act && u >= 1, AA, u);
+            const real2 zero = make_real2(0.f, 0.f);
+            const real2 Pm = lds_if(act && u >= 1, AA, u - 1);
+            const real2 Pu = lds_if(act && u >= 1, AA, u);
             const int xoff = (u == 0) ? 4 * N : 0;          // lane u = 0 reads -v_row (NV = A + 4N)
             constexpr int CS = (2 * N + 63) / 64;           // 64-unit chunks of the static part
             constexpr int RS = (2 * N <= 64) ? 64 / (2 * N) : 1;   // rows per static store
             const int ssub = (2 * N <= 64) ? lane / (2 * N) : 0;
             const int sidx = (2 * N <= 64) ? lane - ssub * 2 * N : lane;
-            float2 sv[CS];
+            real2 sv[CS];
 #pragma unroll
             for (int c = 0; c < CS; ++c)
                 sv[c] = lds_if(ssub < RS && sidx + 64 * c < 2 * N, AA, N + sidx + 64 * c);
@@ -69,9 +70,9 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             for (int rb = row0; rb < N; rb += RW * WPE) {
                 const int r = rb + rsub * WPE;
                 if ((parts & 1) && act && r < N) {
-                    const float2 x = AA[xoff + r];
-                    const float2 c = (u - 1 >= r) ? Pu : Pm;
-                    out[(unsigned)r * ROWU + (unsigned)u] = make_float2(c.x - x.x, c.y - x.y);
+                    const real2 x = AA[xoff + r];
+                    const real2 c = (u - 1 >= r) ? Pu : Pm;
+                    out[(unsigned)r * ROWU + (unsigned)u] = make_real2(c.x - x.x, c.y - x.y);
                 }
 #pragma unroll
                 for (int k0 = 0; k0 < RW; k0 += RS) {
@@ -92,7 +93,7 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             // static lanes hold A[u] in BOTH position registers and subtract nothing.
             constexpr int CR = (3 * N + 63) / 64;                 // chunks per row
             constexpr int C_MIX = N / 64;                         // the chunk that holds unit N (dyn and static lanes)
-            float2 Pm[CR], Pu[CR];
+            real2 Pm[CR], Pu[CR];
 #pragma unroll
             for (int c = 0; c < CR; ++c) {
                 const int u = lane + 64 * c;
@@ -109,22 +110,22 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             const int r_end = min(N, (share + 1) * PER);
 #pragma unroll 2
             for (int r = share * PER; r < r_end; ++r) {
-                const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
-                const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];   // lane 0 of chunk 0: -v_row
-                float2* __restrict__ orow = out + (unsigned)r * ROWU;
+                const real2 xp = AA[r];                    // p_row, wave-uniform broadcast
+                const real2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];   // lane 0 of chunk 0: -v_row
+                real2* __restrict__ orow = out + (unsigned)r * ROWU;
 #pragma unroll
                 for (int c = 0; c < CR; ++c) {
                     const int u = lane + 64 * c;
-                    float2 val;
+                    real2 val;
                     if (c < C_MIX || (c == C_MIX && (N % 64) == 0)) {           // every lane a relative position
-                        const float2 x = (c == 0) ? x0 : xp;
-                        const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
-                        val = make_float2(cc.x - x.x, cc.y - x.y);
+                        const real2 x = (c == 0) ? x0 : xp;
+                        const real2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
+                        val = make_real2(cc.x - x.x, cc.y - x.y);
                     } else if (c == C_MIX) {                                     // relative positions, then static units
                         const bool dyn = u < N;
-                        const float2 x = (c == 0) ? x0 : xp;
-                        const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
-                        val = make_float2(cc.x - (dyn ? x.x : 0.0f), cc.y - (dyn ? x.y : 0.0f));
+                        const real2 x = (c == 0) ? x0 : xp;
+                        const real2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
+                        val = make_real2(cc.x - (dyn ? x.x : 0.0f), cc.y - (dyn ? x.y : 0.0f));
                     } else {
                         val = Pu[c];
                     }
@@ -135,8 +136,8 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
         } else {
             // ---- N > 64: one row per iteration, register-cached chunks of 64 units ----
             constexpr int CD = (N + 63) / 64, CS = (2 * N + 63) / 64;
-            const float2 zero = make_float2(0.f, 0.f);
-            float2 Pm[CD], Pu[CD], sv[CS];
+            const real2 zero = make_real2(0.f, 0.f);
+            real2 Pm[CD], Pu[CD], sv[CS];
 #pragma unroll
             for (int c = 0; c < CD; ++c) {
                 const int u = lane + 64 * c;
@@ -152,15 +153,15 @@ FG_DEV void write_obs_rows(const float2* __restrict__ tables0, int env_stride, i
             const int r_end = min(N, (share + 1) * PER);
 #pragma unroll 2
             for (int r = share * PER; r < r_end; ++r) {
-                const float2 xp = AA[r];                    // p_row, wave-uniform broadcast
-                const float2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
-                float2* __restrict__ orow = out + (unsigned)r * ROWU;
+                const real2 xp = AA[r];                    // p_row, wave-uniform broadcast
+                const real2 x0 = AA[(lane == 0 ? 4 * N : 0) + r];
+                real2* __restrict__ orow = out + (unsigned)r * ROWU;
 #pragma unroll
                 for (int c = 0; c < CD; ++c) {
                     const int u = lane + 64 * c;
-                    const float2 x = (c == 0) ? x0 : xp;
-                    const float2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
-                    if ((parts & 1) && u < N) orow[u] = make_float2(cc.x - x.x, cc.y - x.y);
+                    const real2 x = (c == 0) ? x0 : xp;
+                    const real2 cc = (u - 1 >= r) ? Pu[c] : Pm[c];
+                    if ((parts & 1) && u < N) orow[u] = make_real2(cc.x - x.x, cc.y - x.y);
                 }
 #pragma unroll
                 for (int c = 0; c < CS; ++c)

@@ -39,7 +39,7 @@ template <int NC, int WR, int NWW, int E> constexpr int roll_writer_units() {
 // on gfx9 loads and stores share one counter, and a producer's wait for its prefetched action was also a wait for its own reward
 // stores behind the workgroup's observation stream.  Taken wherever it fits the 160 KiB.
 template <int NC, int TW, int E, int WR, int PER> constexpr int roll_lds_base_bytes() {
-    return E * roll_block_floats(NC) * (int)sizeof(float) + roll_writer_units<NC, WR, TW / 64, E>() * (int)sizeof(float2) +
+    return E * roll_block_floats(NC) * (int)sizeof(real) + roll_writer_units<NC, WR, TW / 64, E>() * (int)sizeof(float2) +
            (PER > 0 ? E * policy_block_units(NC) * (int)sizeof(float2) : 0);
 }
 template <int NC, int E> constexpr int roll_rew_floats() { return 2 * 3 * E * NC; }
@@ -69,8 +69,8 @@ void rollout_kernel(const Args a) {
     static_assert(G <= 64 && E * G == TP && TW % 64 == 0 && TP % 64 == 0, "bad rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64;
     constexpr int NPS = NP <= 16 ? NP : 0;              // small N: partners fetched up front (fg_pair_loops.hpp)
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float* const smemf = reinterpret_cast<float*>(smem);
+    extern __shared__ __attribute__((aligned(16))) real2 smem[];
+    real* const smemf = reinterpret_cast<real*>(smem);
     const int tid = threadIdx.x;
     const bool producer = tid < TP;
     const int e = producer ? tid / G : 0;
@@ -84,36 +84,36 @@ void rollout_kernel(const Args a) {
     const bool env_ok = producer && (b < a.B);
     const bool valid = env_ok && (i < N);
     const int El = min(E, a.B - b0);
-    float* const blk = smemf + e * roll_block_floats(N);
-    float2* const TB0 = reinterpret_cast<float2*>(blk);                 // tables of buffer 0; buffer 1 at + 5N
-    float* const QX = blk + 20 * N;
-    float* const QY = QX + NP; float* const PX = QY + NP; float* const PY = PX + NP;
-    float* const SX = PY + NP; float* const SY = SX + NP;
+    real* const blk = smemf + e * roll_block_floats(N);
+    real2* const TB0 = reinterpret_cast<real2*>(blk);                 // tables of buffer 0; buffer 1 at + 5N
+    real* const QX = blk + 20 * N;
+    real* const QY = QX + NP; real* const PX = QY + NP; real* const PY = PX + NP;
+    real* const SX = PY + NP; real* const SY = SX + NP;
 
-    const float one_minus_damp = 1.0f - a.p.damping;
-    const float dt = a.p.dt;
-    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;
-    const float cutoff2 = cutoff * cutoff;
-    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
-    const float invN = 1.0f / (float)N;
+    const real one_minus_damp = 1.0f - a.p.damping;
+    const real dt = a.p.dt;
+    const real cutoff = a.p.dist_min + (FG_F64 ? 40.0f : 18.0f) * a.p.contact_margin;
+    const real cutoff2 = cutoff * cutoff;
+    const real thr2 = (real)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const real invN = 1.0f / (real)N;
     // read once: a (possible) load from the device counter inside the step loop makes the compiler drain the action
     // prefetch in every step (one counter for all outstanding memory operations on gfx9): 9 x 4096 x 128 2.42 -> 2.25
     // us/step, 8 x 8192 2.63 -> 2.39 (profiles/r04_rew_lds_ab.txt)
     const uint64_t rbase = rng_base(a.p);
 
-    float2 p = make_float2(0.f, 0.f), v = p, s = p, iv = p;
+    real2 p = make_real2(0.f, 0.f), v = p, s = p, iv = p;
     int t_step = 0;
     const size_t sidx = (size_t)b * N + i;
     if (valid) {
-        p = make_float2(a.px[sidx], a.py[sidx]);
-        v = make_float2(a.vx[sidx], a.vy[sidx]);
-        s = reinterpret_cast<const float2*>(a.shape)[sidx];
+        p = make_real2(a.px[sidx], a.py[sidx]);
+        v = make_real2(a.vx[sidx], a.vy[sidx]);
+        s = reinterpret_cast<const real2*>(a.shape)[sidx];
         QX[i] = p.x; QY[i] = p.y; SX[i] = s.x; SY[i] = s.y;
-        if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
+        if (i < N - 1) { TB0[N + i] = make_real2(0.f, 0.f); TB0[5 * N + N + i] = make_real2(0.f, 0.f); }
     } else if (env_ok && i < NP) {
         QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
     }
-    if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+    if (env_ok) { iv = reinterpret_cast<const real2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
 
     // Actions are fetched ahead of their step (small N leaves too little work between the load and its use to cover an HBM
     // round trip inside one step), in one of two forms:
@@ -129,47 +129,47 @@ void rollout_kernel(const Args a) {
     // 8 x 65536 ran 18.0 -> 19.4 us/step and 9 x 16384 5.98 -> 6.16 - fewer, larger read events in a write-only stream are what
     // they buy, profiles/r05_rew_lds_ab.txt)
     constexpr bool ACT4 = !POLICY && ((TP + TW) > 512 || WR == FG_WR_GATHER);
-    float2 u_even = make_float2(0.f, 0.f), u_odd = u_even;
-    const size_t act_stride = (size_t)a.B * N;                  // float2 units between consecutive steps
-    const float2* const act0 = reinterpret_cast<const float2*>(a.act) + (valid ? sidx : 0);
-    const float2* act_next = act0 + (a.K > 1 ? act_stride : 0);
+    real2 u_even = make_real2(0.f, 0.f), u_odd = u_even;
+    const size_t act_stride = (size_t)a.B * N;                  // real2 units between consecutive steps
+    const real2* const act0 = reinterpret_cast<const real2*>(a.act) + (valid ? sidx : 0);
+    const real2* act_next = act0 + (a.K > 1 ? act_stride : 0);
     // (four-step batches: a scalar base per step + the lane's 32-bit offset, so that no 64-bit per-lane pointer is held - and,
     // in the 128-register instantiations, spilled - across the step loop; B N < 2^29 entries)
     const uint32_t lane_off = valid ? (uint32_t)sidx : 0u;
-    float2 cur[4], nxt[4];
+    real2 cur[4], nxt[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { cur[t] = make_float2(0.f, 0.f); nxt[t] = cur[t]; }
-    auto load_batch = [&](float2 (&dst)[4], int j0) {          // actions of steps j0 ... j0 + 3 (clamped to the last step)
+    for (int t = 0; t < 4; ++t) { cur[t] = make_real2(0.f, 0.f); nxt[t] = cur[t]; }
+    auto load_batch = [&](real2 (&dst)[4], int j0) {          // actions of steps j0 ... j0 + 3 (clamped to the last step)
         if (valid) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                dst[t] = (reinterpret_cast<const float2*>(a.act) + (size_t)min(j0 + t, a.K - 1) * act_stride)[lane_off];
+                dst[t] = (reinterpret_cast<const real2*>(a.act) + (size_t)min(j0 + t, a.K - 1) * act_stride)[lane_off];
         }
     };
     if constexpr (ACT4) load_batch(cur, 0);
     else if (!POLICY && valid) u_even = *act0;
     // closed loop: controller tables of this env behind the env blocks and the writers' tiles
-    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW, E>() +
+    real2* const pol_tab = reinterpret_cast<real2*>(smemf + E * roll_block_floats(N)) + roll_writer_units<NC, WR, NWW, E>() +
                             e * policy_block_units(N);
     // reward hand-over (see roll_lds_base_bytes): [2][rew | indiv | done][E][N]
     constexpr bool REWLDS = roll_rew_in_lds<NC, TW, E, WR, PER>();
-    float* const rew_lds = smemf + roll_lds_base_bytes<NC, TW, E, WR, PER>() / (int)sizeof(float);
+    real* const rew_lds = smemf + roll_lds_base_bytes<NC, TW, E, WR, PER>() / (int)sizeof(real);
 
     // one producer step: World.step + reward of step k into table buffer (k & 1);
     // u_cur = action of step k (loaded during step k-1), u_nxt receives the action of step k+1
-    auto produce = [&](int k, const float2& u_cur, float2& u_nxt) {
-        float2* const A = TB0 + (k & 1) * 5 * N;
+    auto produce = [&](int k, const real2& u_cur, real2& u_nxt) {
+        real2* const A = TB0 + (k & 1) * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        float2 u_act = u_cur;
+        real2 u_act = u_cur;
         if constexpr (POLICY) {
             // get_action_BFS(ezpolicy, obs, 3) on the observation the previous step (or the reset) returned:
             // its row 0 holds p_j - p_0, exactly this subtraction; QX / QY hold the current positions
-            if (valid) { pol_tab[i] = make_float2(p.x - QX[0], p.y - QY[0]); pol_tab[N + i] = s; }
+            if (valid) { pol_tab[i] = make_real2(p.x - QX[0], p.y - QY[0]); pol_tab[N + i] = s; }
             WaveSync()();
-            const float2* res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, i, G, WaveSync());
+            const real2* res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, i, G, WaveSync());
             if (valid) {
                 u_act = res[i];
-                if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u_act;
+                if (a.act_out) reinterpret_cast<real2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u_act;
             }
         }
         if (valid) {
@@ -179,7 +179,7 @@ void rollout_kernel(const Args a) {
                 u_nxt = *act_next;
                 act_next += (k + 2 < a.K) ? act_stride : 0;
             }
-            float2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
+            real2 f = contact_force_packed<NPS>(QX, QY, NP, i, p, a.p.contact_force, a.p.contact_margin,
                                                  a.p.dist_min, cutoff2);
             f.x += a.p.mass * (a.p.sensitivity * u_act.x);
             f.y += a.p.mass * (a.p.sensitivity * u_act.y);
@@ -192,26 +192,26 @@ void rollout_kernel(const Args a) {
         t_step += 1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        float sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
+        real sums[4] = {valid ? p.x : 0.f, valid ? p.y : 0.f, valid ? v.x : 0.f, valid ? v.y : 0.f};
         env_reduce<G, G, 4, R_SUM, R_SUM, R_SUM, R_SUM>(sums, nullptr);
-        const float mx = sums[0] * invN, my = sums[1] * invN;
-        const float mvx = sums[2] * invN, mvy = sums[3] * invN;
-        float rowmin = INFINITY, colmin = INFINITY;
+        const real mx = sums[0] * invN, my = sums[1] * invN;
+        const real mvx = sums[2] * invN, mvy = sums[3] * invN;
+        real rowmin = INFINITY, colmin = INFINITY;
         int cnt = 0, arg_lm = 0, arg_ag = 0;
         if (valid)
             reward_pass_packed<false, NPS>(PX, PY, SX, SY, NP, p, p.x - mx, p.y - my, s.x + mx, s.y + my, thr2,
                                            rowmin, colmin, cnt, arg_lm, arg_ag);
-        float red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (float)cnt};
+        real red[3] = {valid ? rowmin : -INFINITY, valid ? colmin : -INFINITY, (real)cnt};
         env_reduce<G, G, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
-        const float H = sqrtf(fmaxf(red[0], red[1]));
-        const float ex = iv.x - mvx, ey = iv.y - mvy;
-        const float velterm = sqrtf(ex * ex + ey * ey);
+        const real H = rsqrt_(rmax(red[0], red[1]));
+        const real ex = iv.x - mvx, ey = iv.y - mvy;
+        const real velterm = rsqrt_(ex * ex + ey * ey);
         const bool is_done = t_step >= a.p.world_length;
         if (valid) {
-            const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
-            const float own = (-H - velterm) - (float)cnt;
+            const real shared = (real)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+            const real own = (-H - velterm) - (real)cnt;
             if constexpr (REWLDS) {
-                float* const R = rew_lds + (k & 1) * 3 * E * N + e * N + i;
+                real* const R = rew_lds + (k & 1) * 3 * E * N + e * N + i;
                 R[0] = shared; R[E * N] = own; reinterpret_cast<uint32_t*>(R)[2 * E * N] = is_done ? 1u : 0u;
             } else {
                 const size_t o = ((size_t)k * a.B + b) * N + i;
@@ -226,30 +226,30 @@ void rollout_kernel(const Args a) {
                 uint32_t c[4] = {(uint32_t)(b + a.p.env_index_base), (uint32_t)i, (uint32_t)(rbase + k),
                                  (uint32_t)((rbase + k) >> 32)};
                 philox4x32(c, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
-                float raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
-                const float rx = raw[0], ry = raw[1];
+                real raw[2] = {valid ? u_pm1(c[2]) : 0.f, valid ? u_pm1(c[3]) : 0.f};
+                const real rx = raw[0], ry = raw[1];
                 env_reduce<G, G, 2, R_SUM, R_SUM, R_SUM, R_SUM>(raw, nullptr);
                 uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rbase + k),
                                   (uint32_t)((rbase + k) >> 32)};
                 philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
                 if (mine) {
-                    iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+                    iv = make_real2(u_pm1(c2[0]), u_pm1(c2[1]));
                     t_step = 0;
                     if (valid) {
-                        p = make_float2(u_pm1(c[0]), u_pm1(c[1]));
-                        v = make_float2(0.f, 0.f);
-                        s = make_float2(__builtin_fmaf(-raw[0], invN, rx), __builtin_fmaf(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
+                        p = make_real2(u_pm1(c[0]), u_pm1(c[1]));
+                        v = make_real2(0.f, 0.f);
+                        s = make_real2(rfma(-raw[0], invN, rx), rfma(-raw[1], invN, ry));   // explicit fma: same bits in every kernel
                         SX[i] = s.x; SY[i] = s.y;
                         int ir = i, br = b;                // opaque: the global addresses of this rarely taken branch are made
                         asm volatile("" : "+v"(ir), "+v"(br));   // here, not kept in registers across the step loop
-                        reinterpret_cast<float2*>(a.shape)[(size_t)br * N + ir] = s;
-                        if (i == 0) reinterpret_cast<float2*>(a.ivel)[br] = iv;
+                        reinterpret_cast<real2*>(a.shape)[(size_t)br * N + ir] = s;
+                        if (i == 0) reinterpret_cast<real2*>(a.ivel)[br] = iv;
                     }
                 }
             }
         }
         if (valid) {                                   // publish this step's tables + next step's partners
-            A[i] = p; A[3 * N + i] = v; A[4 * N + i] = make_float2(-v.x, -v.y);
+            A[i] = p; A[3 * N + i] = v; A[4 * N + i] = make_real2(-v.x, -v.y);
             A[2 * N - 1 + i] = s;
             if (i == 0) A[3 * N - 1] = iv;
             QX[i] = p.x; QY[i] = p.y;
@@ -280,12 +280,12 @@ void rollout_kernel(const Args a) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
     __syncthreads();
     // hand-over step k: producers run step k+1 (consuming u_cur) while writers stream step k
-    auto pipeline_step = [&](int k, const float2& u_cur, float2& u_nxt) {
+    auto pipeline_step = [&](int k, const real2& u_cur, real2& u_nxt) {
         if (producer) {
             if (k + 1 < a.K) produce(k + 1, u_cur, u_nxt);
         } else {
             if constexpr (REWLDS) {                          // step k's rewards and done flags: the workgroup's slice is contiguous
-                const float* const R = rew_lds + (k & 1) * 3 * E * N;
+                const real* const R = rew_lds + (k & 1) * 3 * E * N;
                 const int cnt = El * N;
                 const size_t o0 = ((size_t)k * a.B + b0) * N;
                 int q0 = tid - TP;
@@ -303,24 +303,24 @@ void rollout_kernel(const Args a) {
             if (want_obs) {
                 const size_t unit0 = ((size_t)slot * a.B + b0) * (size_t)a.obs_pitch;
                 const size_t env_units = (size_t)a.obs_pitch;
-                const float2* tables0 = reinterpret_cast<const float2*>(smemf) + (k & 1) * 5 * N;
+                const real2* tables0 = reinterpret_cast<const real2*>(smemf) + (k & 1) * 5 * N;
                 if constexpr (WR == 0)
                     write_obs_rows<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                               reinterpret_cast<float2*>(a.obs) + unit0, env_units, El, 3);
+                                               reinterpret_cast<real2*>(a.obs) + unit0, env_units, El, 3);
                 else if constexpr (WR == FG_WR_GATHER) {
                   if (use_span)
-                    Span::write(span_lut, tables0, (tid - TP) >> 6, reinterpret_cast<float2*>(a.obs) + unit0);
+                    Span::write(span_lut, tables0, (tid - TP) >> 6, reinterpret_cast<real2*>(a.obs) + unit0);
                   else {
                     GatherEntries<(WR == FG_WR_GATHER ? NC : 2)> gather_entries;      // (the rare form: no state kept across steps)
                     write_obs_gather<NC, NWW, E>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
                                                  reinterpret_cast<const uint4*>(smemf + E * roll_block_floats(N)),
-                                                 reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El, gather_entries);
+                                                 reinterpret_cast<real2*>(a.obs) + unit0, unit0, env_units, El, gather_entries);
                   }
                 }
                 else
                     write_obs_tiled<NC, NWW, E, WR - 1, STREAM>(tables0, roll_block_floats(N) / 2, (tid - TP) >> 6,
-                                                                reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)),
-                                                                reinterpret_cast<float2*>(a.obs) + unit0, unit0, env_units, El);
+                                                                reinterpret_cast<real2*>(smemf + E * roll_block_floats(N)),
+                                                                reinterpret_cast<real2*>(a.obs) + unit0, unit0, env_units, El);
             }
         }
         __syncthreads();
@@ -364,8 +364,8 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
     static_assert(!(BATCHES && POLICY), "the batch-pipelined single step takes its actions from the caller");
     static_assert(A * 64 >= NC && (A - 1) * 64 < NC && TW % 64 == 0, "bad wide rollout geometry");
     constexpr int N = NC, NP = npad(NC), NWW = TW / 64, TP = E * 64;
-    extern __shared__ __attribute__((aligned(16))) float2 smem[];
-    float* const smemf = reinterpret_cast<float*>(smem);
+    extern __shared__ __attribute__((aligned(16))) real2 smem[];
+    real* const smemf = reinterpret_cast<real*>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index as a scalar: the env, its validity and every branch on them are wave-uniform (s_cbranch, no exec masks
     // held in SGPR pairs across the step loop - the kernel sat at the 102-SGPR limit and spilled 20-46 of them)
@@ -376,35 +376,35 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
     const int wg0 = blockIdx.x * E * NG;
     int b = wg0 + e;
     bool env_ok = producer && (b < a.B);
-    float* const blk = smemf + e * roll_block_floats(N);
-    float2* const TB0 = reinterpret_cast<float2*>(blk);
-    float* const QX = blk + 20 * N;
-    float* const QY = QX + NP; float* const PX = QY + NP; float* const PY = PX + NP;
-    float* const SX = PY + NP; float* const SY = SX + NP;
+    real* const blk = smemf + e * roll_block_floats(N);
+    real2* const TB0 = reinterpret_cast<real2*>(blk);
+    real* const QX = blk + 20 * N;
+    real* const QY = QX + NP; real* const PX = QY + NP; real* const PY = PX + NP;
+    real* const SX = PY + NP; real* const SY = SX + NP;
 
-    const float one_minus_damp = 1.0f - a.p.damping;
-    const float dt = a.p.dt;
-    const float cutoff = a.p.dist_min + 18.0f * a.p.contact_margin;
-    const float cutoff2 = cutoff * cutoff;
-    const float thr2 = (float)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
-    const float invN = 1.0f / (float)N;
-    const float inv_k = 1.0f / a.p.contact_margin;
+    const real one_minus_damp = 1.0f - a.p.damping;
+    const real dt = a.p.dt;
+    const real cutoff = a.p.dist_min + (FG_F64 ? 40.0f : 18.0f) * a.p.contact_margin;
+    const real cutoff2 = cutoff * cutoff;
+    const real thr2 = (real)((double)a.p.collide_thresh * (double)a.p.collide_thresh);
+    const real invN = 1.0f / (real)N;
+    const real inv_k = 1.0f / a.p.contact_margin;
     const uint64_t rbase = rng_base(a.p);               // read once, not inside the step loop (see rollout_kernel)
 
-    float2 p[A], v[A], s[A];
+    real2 p[A], v[A], s[A];
     // The action of the NEXT produce call, loaded one call ahead and in front of the current call's reward stores: a load at
     // the point of use queues up behind the workgroup's observation stream (round 4: open loop slower than closed loop,
     // 125 x 4096 260.7 vs 231.9 us/step), and its wait must not include stores issued after it (one counter on gfx9).
-    float2 u_pre[A];
+    real2 u_pre[A];
     // agent lane + 64 q of the wave's env exists: slices below the last one are full, so their test is the scalar env_ok
     auto valid = [&](int q) { return env_ok && (q < A - 1 || lane < N - 64 * (A - 1)); };
-    float2 iv = make_float2(0.f, 0.f);
+    real2 iv = make_real2(0.f, 0.f);
     int t_step = 0;
     if (producer) {                                     // row-independent table entries and loop sentinels: once
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             const int i = lane + 64 * q;
-            if (i < N - 1) { TB0[N + i] = make_float2(0.f, 0.f); TB0[5 * N + N + i] = make_float2(0.f, 0.f); }
+            if (i < N - 1) { TB0[N + i] = make_real2(0.f, 0.f); TB0[5 * N + N + i] = make_real2(0.f, 0.f); }
             if (i >= N && i < NP) {
                 QX[i] = FAR_AWAY; QY[i] = FAR_AWAY; PX[i] = FAR_AWAY; PY[i] = FAR_AWAY; SX[i] = FAR_AWAY; SY[i] = FAR_AWAY;
             }
@@ -416,23 +416,23 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             const int i = lane + 64 * q;
-            p[q] = v[q] = s[q] = make_float2(0.f, 0.f);
+            p[q] = v[q] = s[q] = make_real2(0.f, 0.f);
             if (valid(q)) {
                 const size_t o = (size_t)b * N + i;
-                p[q] = make_float2(a.px[o], a.py[o]);
-                v[q] = make_float2(a.vx[o], a.vy[o]);
-                s[q] = reinterpret_cast<const float2*>(a.shape)[o];
+                p[q] = make_real2(a.px[o], a.py[o]);
+                v[q] = make_real2(a.vx[o], a.vy[o]);
+                s[q] = reinterpret_cast<const real2*>(a.shape)[o];
                 QX[i] = p[q].x; QY[i] = p[q].y; SX[i] = s[q].x; SY[i] = s[q].y;
             }
         }
-        iv = make_float2(0.f, 0.f); t_step = 0;
-        if (env_ok) { iv = reinterpret_cast<const float2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
+        iv = make_real2(0.f, 0.f); t_step = 0;
+        if (env_ok) { iv = reinterpret_cast<const real2*>(a.ivel)[b]; if (a.step) t_step = a.step[b]; }
     };
     auto load_actions = [&](int k) {                    // of step k -> u_pre
 #pragma unroll
         for (int q = 0; q < A; ++q) {
-            u_pre[q] = make_float2(0.f, 0.f);
-            if (valid(q)) u_pre[q] = reinterpret_cast<const float2*>(a.act)[((size_t)k * a.B + b) * N + lane + 64 * q];
+            u_pre[q] = make_real2(0.f, 0.f);
+            if (valid(q)) u_pre[q] = reinterpret_cast<const real2*>(a.act)[((size_t)k * a.B + b) * N + lane + 64 * q];
         }
     };
     auto store_group = [&]() {
@@ -446,47 +446,47 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
         if (a.step && env_ok && lane == 0) a.step[b] = t_step;
     };
 
-    float2* const pol_tab = reinterpret_cast<float2*>(smemf + E * roll_block_floats(N)) + e * policy_block_units(N);
+    real2* const pol_tab = reinterpret_cast<real2*>(smemf + E * roll_block_floats(N)) + e * policy_block_units(N);
     auto produce = [&](int k, int buf) {
-        float2* const T = TB0 + buf * 5 * N;
+        real2* const T = TB0 + buf * 5 * N;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const float2* pol_res = nullptr;
+        const real2* pol_res = nullptr;
         if constexpr (POLICY) {                         // closed loop: see rollout_kernel
 #pragma unroll
             for (int q = 0; q < A; ++q) {
                 const int i = lane + 64 * q;
-                if (valid(q)) { pol_tab[i] = make_float2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
+                if (valid(q)) { pol_tab[i] = make_real2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
             }
             WaveSync()();
             pol_res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
         }
-        float2 u_cur[A];
+        real2 u_cur[A];
         if constexpr (!POLICY) {
 #pragma unroll
             for (int q = 0; q < A; ++q) u_cur[q] = u_pre[q];
             if constexpr (!BATCHES) load_actions(min(k + 1, a.K - 1));   // always issued (clamped): a known number of younger loads
         }
         // ---- World.step: all A agents of the lane against each partner pair ----
-        float fx[A], fy[A];
+        real fx[A], fy[A];
 #pragma unroll
         for (int q = 0; q < A; ++q) { fx[q] = 0.f; fy[q] = 0.f; }
         if (env_ok) {
             for (int j = 0; j < NP; j += 2) {
-                const f32x2 qx = *reinterpret_cast<const f32x2*>(QX + j);
-                const f32x2 qy = *reinterpret_cast<const f32x2*>(QY + j);
+                const realx2 qx = *reinterpret_cast<const realx2*>(QX + j);
+                const realx2 qy = *reinterpret_cast<const realx2*>(QY + j);
 #pragma unroll
                 for (int q = 0; q < A; ++q) {
                     const int i = lane + 64 * q;
-                    const f32x2 dx = (f32x2){p[q].x, p[q].x} - qx, dy = (f32x2){p[q].y, p[q].y} - qy;
-                    const f32x2 d2 = dx * dx + dy * dy;
+                    const realx2 dx = (realx2){p[q].x, p[q].x} - qx, dy = (realx2){p[q].y, p[q].y} - qy;
+                    const realx2 d2 = dx * dx + dy * dy;
                     const bool n0 = (d2.x < cutoff2) && (j != i) && valid(q);
                     const bool n1 = (d2.y < cutoff2) && (j + 1 != i) && valid(q);
                     if (n0 || n1) {
-                        auto add = [&](float ddx, float ddy, float dd2) {
-                            const float d = __builtin_amdgcn_sqrtf(dd2);
-                            const float x = (a.p.dist_min - d) * inv_k;
-                            const float pen = a.p.contact_margin * (fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(x))));
-                            const float c = a.p.contact_force * pen * __builtin_amdgcn_rcpf(d);
+                        auto add = [&](real ddx, real ddy, real dd2) {
+                            const real d = hw_sqrt(dd2);
+                            const real x = (a.p.dist_min - d) * inv_k;
+                            const real pen = a.p.contact_margin * (rmax(x, real(0)) + hw_log(1.0f + hw_exp(-rabs(x))));
+                            const real c = a.p.contact_force * pen * hw_rcp(d);
                             fx[q] += ddx * c; fy[q] += ddy * c;
                         };
                         if (n0) add(dx.x, dy.x, d2.x);
@@ -495,24 +495,24 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 }
             }
         }
-        // float sums are reduced per 64-agent slice and then combined slice by slice: the exact
+        // real sums are reduced per 64-agent slice and then combined slice by slice: the exact
         // association order of step_kernel (wave butterfly, then waves in order) -> bit-identical
-        float sums[4] = {0.f, 0.f, 0.f, 0.f};
-        float part[A][4];
+        real sums[4] = {0.f, 0.f, 0.f, 0.f};
+        real part[A][4];
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             part[q][0] = part[q][1] = part[q][2] = part[q][3] = 0.f;
             if (valid(q)) {
                 const int i = lane + 64 * q;
-                float2 u;
+                real2 u;
                 if constexpr (POLICY) {
                     u = pol_res[i];
-                    if (a.act_out) reinterpret_cast<float2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u;
+                    if (a.act_out) reinterpret_cast<real2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u;
                 } else {
                     u = u_cur[q];
                 }
-                const float ffx = fx[q] + a.p.mass * (a.p.sensitivity * u.x);
-                const float ffy = fy[q] + a.p.mass * (a.p.sensitivity * u.y);
+                const real ffx = fx[q] + a.p.mass * (a.p.sensitivity * u.x);
+                const real ffy = fy[q] + a.p.mass * (a.p.sensitivity * u.y);
                 v[q].x = v[q].x * one_minus_damp + (ffx / a.p.mass) * dt;
                 v[q].y = v[q].y * one_minus_damp + (ffy / a.p.mass) * dt;
                 p[q].x += v[q].x * dt;
@@ -530,62 +530,62 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             if (q == 0) { sums[0] = part[0][0]; sums[1] = part[0][1]; sums[2] = part[0][2]; sums[3] = part[0][3]; }
             else { sums[0] += part[q][0]; sums[1] += part[q][1]; sums[2] += part[q][2]; sums[3] += part[q][3]; }
         }
-        const float mx = sums[0] * invN, my = sums[1] * invN;
-        const float mvx = sums[2] * invN, mvy = sums[3] * invN;
+        const real mx = sums[0] * invN, my = sums[1] * invN;
+        const real mvx = sums[2] * invN, mvy = sums[3] * invN;
         // ---- reward pass ----
-        float rowmin[A], colmin[A];
+        real rowmin[A], colmin[A];
         int cnt[A];
 #pragma unroll
         for (int q = 0; q < A; ++q) { rowmin[q] = INFINITY; colmin[q] = INFINITY; cnt[q] = -1; }
         if (env_ok) {
             for (int j = 0; j < NP; j += 2) {
-                const f32x2 qx = *reinterpret_cast<const f32x2*>(PX + j);
-                const f32x2 qy = *reinterpret_cast<const f32x2*>(PY + j);
-                const f32x2 sx = *reinterpret_cast<const f32x2*>(SX + j);
-                const f32x2 sy = *reinterpret_cast<const f32x2*>(SY + j);
+                const realx2 qx = *reinterpret_cast<const realx2*>(PX + j);
+                const realx2 qy = *reinterpret_cast<const realx2*>(PY + j);
+                const realx2 sx = *reinterpret_cast<const realx2*>(SX + j);
+                const realx2 sy = *reinterpret_cast<const realx2*>(SY + j);
 #pragma unroll
                 for (int q = 0; q < A; ++q) {
-                    const f32x2 cx = qx - (f32x2){p[q].x, p[q].x}, cy = qy - (f32x2){p[q].y, p[q].y};
-                    const f32x2 dc = cx * cx + cy * cy;
+                    const realx2 cx = qx - (realx2){p[q].x, p[q].x}, cy = qy - (realx2){p[q].y, p[q].y};
+                    const realx2 dc = cx * cx + cy * cy;
                     cnt[q] += (dc.x < thr2 ? 1 : 0) + (dc.y < thr2 ? 1 : 0);
-                    const float ptx = p[q].x - mx, pty = p[q].y - my;
-                    const f32x2 rx = (f32x2){ptx, ptx} - sx, ry = (f32x2){pty, pty} - sy;
-                    const f32x2 dr = rx * rx + ry * ry;
-                    const float tx = s[q].x + mx, ty = s[q].y + my;
-                    const f32x2 ux = qx - (f32x2){tx, tx}, uy = qy - (f32x2){ty, ty};
-                    const f32x2 dq = ux * ux + uy * uy;
-                    rowmin[q] = fminf(fminf(rowmin[q], dr.x), dr.y);
-                    colmin[q] = fminf(fminf(colmin[q], dq.x), dq.y);
+                    const real ptx = p[q].x - mx, pty = p[q].y - my;
+                    const realx2 rx = (realx2){ptx, ptx} - sx, ry = (realx2){pty, pty} - sy;
+                    const realx2 dr = rx * rx + ry * ry;
+                    const real tx = s[q].x + mx, ty = s[q].y + my;
+                    const realx2 ux = qx - (realx2){tx, tx}, uy = qy - (realx2){ty, ty};
+                    const realx2 dq = ux * ux + uy * uy;
+                    rowmin[q] = rmin(rmin(rowmin[q], dr.x), dr.y);
+                    colmin[q] = rmin(rmin(colmin[q], dq.x), dq.y);
                 }
             }
         }
-        float red[3] = {-INFINITY, -INFINITY, 0.f};
+        real red[3] = {-INFINITY, -INFINITY, 0.f};
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             if (valid(q)) {
                 cnt[q] += (thr2 > 0.0f ? 0 : 1);
-                red[0] = fmaxf(red[0], rowmin[q]); red[1] = fmaxf(red[1], colmin[q]); red[2] += (float)cnt[q];
+                red[0] = rmax(red[0], rowmin[q]); red[1] = rmax(red[1], colmin[q]); red[2] += (real)cnt[q];
             }
         }
         env_reduce<64, 64, 3, R_MAX, R_MAX, R_SUM, R_SUM>(red, nullptr);
-        const float H = sqrtf(fmaxf(red[0], red[1]));
-        const float ex = iv.x - mvx, ey = iv.y - mvy;
-        const float velterm = sqrtf(ex * ex + ey * ey);
+        const real H = rsqrt_(rmax(red[0], red[1]));
+        const real ex = iv.x - mvx, ey = iv.y - mvy;
+        const real velterm = rsqrt_(ex * ex + ey * ey);
         const bool is_done = t_step >= a.p.world_length;
-        const float shared = (float)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
+        const real shared = (real)(-(double)N * ((double)H + (double)velterm) - (double)red[2]);
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             if (valid(q)) {
                 const size_t o = ((size_t)k * a.B + b) * N + lane + 64 * q;
                 if (a.rew) a.rew[o] = shared;
-                if (a.indiv) a.indiv[o] = (-H - velterm) - (float)cnt[q];
+                if (a.indiv) a.indiv[o] = (-H - velterm) - (real)cnt[q];
                 if (a.done) a.done[o] = is_done ? 1 : 0;
             }
         }
         if (a.p.auto_reset && is_done && env_ok) {            // wave-uniform: the wave owns one env
-            float raw[2] = {0.f, 0.f};
-            float rawp[A][2];
-            float rx[A], ry[A];
+            real raw[2] = {0.f, 0.f};
+            real rawp[A][2];
+            real rx[A], ry[A];
             uint32_t c0[A], c1[A];
 #pragma unroll
             for (int q = 0; q < A; ++q) {
@@ -604,27 +604,27 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
             uint32_t c2[4] = {(uint32_t)(b + a.p.env_index_base), 0xFFFFFFFFu, (uint32_t)(rbase + k),
                               (uint32_t)((rbase + k) >> 32)};
             philox4x32(c2, (uint32_t)a.p.seed, (uint32_t)(a.p.seed >> 32));
-            iv = make_float2(u_pm1(c2[0]), u_pm1(c2[1]));
+            iv = make_real2(u_pm1(c2[0]), u_pm1(c2[1]));
             t_step = 0;
 #pragma unroll
             for (int q = 0; q < A; ++q) {
                 if (valid(q)) {
                     const int i = lane + 64 * q;
                     const size_t o = (size_t)b * N + i;
-                    p[q] = make_float2(u_pm1(c0[q]), u_pm1(c1[q]));
-                    v[q] = make_float2(0.f, 0.f);
-                    s[q] = make_float2(__builtin_fmaf(-raw[0], invN, rx[q]), __builtin_fmaf(-raw[1], invN, ry[q]));
+                    p[q] = make_real2(u_pm1(c0[q]), u_pm1(c1[q]));
+                    v[q] = make_real2(0.f, 0.f);
+                    s[q] = make_real2(rfma(-raw[0], invN, rx[q]), rfma(-raw[1], invN, ry[q]));
                     SX[i] = s[q].x; SY[i] = s[q].y;
-                    reinterpret_cast<float2*>(a.shape)[o] = s[q];
+                    reinterpret_cast<real2*>(a.shape)[o] = s[q];
                 }
             }
-            if (lane == 0) reinterpret_cast<float2*>(a.ivel)[b] = iv;
+            if (lane == 0) reinterpret_cast<real2*>(a.ivel)[b] = iv;
         }
 #pragma unroll
         for (int q = 0; q < A; ++q) {
             if (valid(q)) {
                 const int i = lane + 64 * q;
-                T[i] = p[q]; T[3 * N + i] = v[q]; T[4 * N + i] = make_float2(-v[q].x, -v[q].y);
+                T[i] = p[q]; T[3 * N + i] = v[q]; T[4 * N + i] = make_real2(-v[q].x, -v[q].y);
                 T[2 * N - 1 + i] = s[q];
                 QX[i] = p[q].x; QY[i] = p[q].y;
             }
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 // (1 KiB store instructions on the absolute 64-byte grid, every unit recomputed from two LDS reads - the span form of
                 // the gather writer - lose here: 81 x 2048 49.5 -> 54.7 us/step, 243 x 8192 1 740 -> 2 065, with eight writer
                 // waves 57 / 1 943: profiles/r05_wide_span_ab.txt.  The register-cached rows writer stays.)
-                write_obs_rows<NC, NWW, E>(reinterpret_cast<const float2*>(smemf) + (it & 1) * 5 * N,
+                write_obs_rows<NC, NWW, E>(reinterpret_cast<const real2*>(smemf) + (it & 1) * 5 * N,
                                            roll_block_floats(N) / 2, w,
-                                           reinterpret_cast<float2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
+                                           reinterpret_cast<real2*>(a.obs) + unit0, (size_t)a.obs_pitch, El, 3);
             }
             __syncthreads();
         }

@@ -26,6 +26,8 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
         lib.fg64_step_hd.restype = ctypes.c_int
         lib.fg64_step_hd.argtypes = [ctypes.POINTER(Fg64Params), ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 16
+        lib.fg64_rollout_hd.restype = ctypes.c_int
+        lib.fg64_rollout_hd.argtypes = [ctypes.POINTER(Fg64Params), ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 13
         _lib = lib
     return _lib
 
@@ -79,3 +81,25 @@ class Env64(object):
 
     def vel(self):
         return torch.stack((self.vx, self.vy), -1).cpu().numpy()
+
+
+def rollout64(g, params=None):
+    """The fixture's T steps in ONE launch of the fp64 build of the PIPELINED rollout kernel (fg64_rollout_hd: rollout_kernel<9 | 27,
+    ...> with real = double), free-running from the fixture's initial state.  Returns dict(pos, vel [B,N,2] after the launch;
+    obs [T,B,N,6N], reward, indiv [T,B,N], done [T,B,N])."""
+    acts = np.ascontiguousarray(np.asarray(g["acts"], dtype=np.float64))                # [T,B,N,2], fp32-representable values
+    T, B, N = acts.shape[:3]
+    env = Env64(g["pos0"], g["vel0"], g["ideal_shape"], g["ideal_vel"], indices=False)
+    f = dict(dtype=torch.float64, device="cuda")
+    act = torch.as_tensor(acts, **f)
+    obs = torch.full((T, B, N, 6 * N), float("nan"), **f)
+    rew = torch.full((T, B, N), float("nan"), **f)
+    indiv = torch.full((T, B, N), float("nan"), **f)
+    done = torch.full((T, B, N), 7, dtype=torch.uint8, device="cuda")
+    rc = load().fg64_rollout_hd(params or env.params, B, N, T, env.px.data_ptr(), env.py.data_ptr(), env.vx.data_ptr(), env.vy.data_ptr(),
+                                act.data_ptr(), env.shape.data_ptr(), env.ivel.data_ptr(), env.step_count.data_ptr(),
+                                obs.data_ptr(), rew.data_ptr(), indiv.data_ptr(), done.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, "fg64_rollout_hd returned %d" % rc
+    torch.cuda.synchronize()
+    return dict(pos=env.pos(), vel=env.vel(), obs=obs.cpu().numpy(), reward=rew.cpu().numpy(), indiv=indiv.cpu().numpy(),
+                done=done.cpu().numpy(), step=env.step_count.cpu().numpy())

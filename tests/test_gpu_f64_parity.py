@@ -47,3 +47,27 @@ def test_f64_kernel_against_the_oracle_at_other_agent_counts(N, B):
         ok = out["cnt_margin"] > 1e-9
         np.testing.assert_allclose(env.indiv.cpu().numpy()[ok], out["indiv"][ok], rtol=0, atol=1e-10)
         np.testing.assert_allclose(env.obs.cpu().numpy(), out["obs"], rtol=0, atol=1e-10)
+
+
+@pytest.mark.parametrize("name", ["hd_n9", "hd_n9_crowd", "hd_n27", "hd_n27_crowd"])
+def test_f64_pipelined_rollout_kernel_free_runs_on_the_reference_trajectory(golden, name):
+    """The PIPELINED rollout kernel (fg_rollout_kernels.hpp: producer / writer waves, double-buffered LDS tables, action prefetch,
+    the rows writer) in the fp64 build: the fixture's whole horizon in ONE launch, free-running from the initial state, against
+    the reference's float64 trajectory - every step's observations, rewards and done flags and the final state.  The K-step
+    path's own link to the reference (it used to inherit the step kernel's); the fp32 product kernels are the same
+    source with real = float (byte-identical device code before and after the type was made a parameter)."""
+    from tests import f64_parity
+    g = golden(name)
+    T, B, N = g["acts"].shape[:3]
+    r = f64_parity.rollout64(g)
+    tol = 1e-9
+    assert np.abs(r["pos"] - g["pos"][-1]).max() <= tol and np.abs(r["vel"] - g["vel"][-1]).max() <= tol
+    assert (r["step"] == T).all()
+    ok = g["cnt_margin"] > 1e-9                                              # [T,B]: no collision count on its threshold
+    assert np.abs(r["indiv"] - g["indiv"])[ok].max() <= tol
+    shared = g["shared"] if g["shared"].ndim == 3 else np.repeat(g["shared"][..., None], N, -1)
+    assert (np.abs(r["reward"] - shared)[ok] <= 1e-9 * np.maximum(1.0, np.abs(shared[ok]))).all()
+    np.testing.assert_array_equal(r["done"].astype(bool), g["done"])
+    for t in g["obs_steps"]:
+        assert np.abs(r["obs"][t - 1] - g["obs_t%d" % t]).max() <= tol, "observation of step %d" % t
+    assert np.isfinite(r["obs"]).all() and ok.mean() > 0.9
