@@ -1,7 +1,7 @@
 // formation_hip_f64.hip - "parity mode" build of the fused step kernel: the SAME kernel source as
 // libformation_hip (fg_step_kernel.hpp, fg_pair_loops.hpp, the reductions of fg_common.hpp) compiled with
 // real = double, run-time agent count, flat observation writer - and of the pipelined rollout kernel
-// (fg_rollout_kernels.hpp: rollout_kernel<9 | 27, ...> with the rows writer).  TEST INFRASTRUCTURE ONLY (tests/test_gpu_f64_parity.py):
+// (fg_rollout_kernels.hpp: rollout_kernel<9 | 27, ...> and rollout_kernel_wide<81 | 243, ...> with the rows writer).  TEST INFRASTRUCTURE ONLY (tests/test_gpu_f64_parity.py):
 // it lets the kernel's algorithm free-run against the reference's float64 trajectories
 // (/root/reference/formation_gym/core.py:206-225, :289-322; environment.py:113-142) over whole fixtures, which an
 // fp32 run cannot do beyond ~10 steps because stiff contacts amplify rounding chaotically.  Not shipped in the
@@ -26,6 +26,17 @@ static hipError_t launch_roll64(const Args& a, hipStream_t st) {
     constexpr int lds = roll_lds_bytes<NC, TW, E, 0, 0>();
     static_assert(lds <= 64 * 1024, "the parity build stays inside the default LDS limit");
     hipLaunchKernelGGL((rollout_kernel<NC, G, TP, TW, E, 0, 0, false>), dim3(grid), dim3(TP + TW), lds, st, a);
+    return hipGetLastError();
+}
+
+// ... and the one-env-per-producer-wave form for 81 / 243 agents (rollout_kernel_wide)
+template <int NC, int A, int E, int TW>
+static hipError_t launch_wide64(Args a, hipStream_t st) {
+    a.groups = 1;
+    const int grid = (a.B + E - 1) / E;
+    constexpr int lds = E * roll_block_floats(NC) * (int)sizeof(real);
+    static_assert(lds <= 64 * 1024, "the parity build stays inside the default LDS limit");
+    hipLaunchKernelGGL((rollout_kernel_wide<NC, A, E, TW, 0, false>), dim3(grid), dim3(E * 64 + TW), lds, st, a);
     return hipGetLastError();
 }
 
@@ -86,7 +97,7 @@ int fg64_step_hd(const Fg64Params* params, int B, int N,
     return err == hipSuccess ? 0 : -4;
 }
 
-// fg_rollout_hd in fp64 for 9 and 27 agents: K steps in ONE launch of the pipelined kernel; act [K][B][N][2], obs [K][B][N][6N],
+// fg_rollout_hd in fp64 for 9, 27, 81 and 243 agents (the reference's own hierarchy sizes): K steps in ONE launch of the pipelined kernel; act [K][B][N][2], obs [K][B][N][6N],
 // reward / indiv_reward / done [K][B][N].  No auto-reset (the fixtures' episodes do not end inside a launch).
 int fg64_rollout_hd(const Fg64Params* params, int B, int N, int K,
                     double* pos_x, double* pos_y, double* vel_x, double* vel_y,
@@ -95,7 +106,7 @@ int fg64_rollout_hd(const Fg64Params* params, int B, int N, int K,
     using namespace fg;
     if (!params || B < 0 || K < 1 || !pos_x || !pos_y || !vel_x || !vel_y || !act || !ideal_shape || !ideal_vel || !step || !obs || !reward)
         return -1;
-    if (N != 9 && N != 27) return -2;
+    if (N != 9 && N != 27 && N != 81 && N != 243) return -2;
     if (B == 0) return 0;
     Args a; memset(&a, 0, sizeof(a));
     a.p.dt = params->dt; a.p.damping = params->damping; a.p.contact_force = params->contact_force;
@@ -107,7 +118,8 @@ int fg64_rollout_hd(const Fg64Params* params, int B, int N, int K,
     a.shape = ideal_shape; a.ivel = ideal_vel; a.step = step;
     a.obs = obs; a.rew = reward; a.indiv = indiv_reward; a.done = done;
     hipStream_t st = (hipStream_t)stream;
-    const hipError_t err = N == 9 ? launch_roll64<9, 16, 64, 128, 4>(a, st) : launch_roll64<27, 32, 128, 256, 4>(a, st);
+    const hipError_t err = N == 9 ? launch_roll64<9, 16, 64, 128, 4>(a, st) : N == 27 ? launch_roll64<27, 32, 128, 256, 4>(a, st)
+                         : N == 81 ? launch_wide64<81, 2, 2, 128>(a, st) : launch_wide64<243, 4, 1, 256>(a, st);
     return err == hipSuccess ? 0 : -4;
 }
 

@@ -49,7 +49,7 @@ def test_f64_kernel_against_the_oracle_at_other_agent_counts(N, B):
         np.testing.assert_allclose(env.obs.cpu().numpy(), out["obs"], rtol=0, atol=1e-10)
 
 
-@pytest.mark.parametrize("name", ["hd_n9", "hd_n9_crowd", "hd_n27", "hd_n27_crowd"])
+@pytest.mark.parametrize("name", ["hd_n9", "hd_n9_crowd", "hd_n27", "hd_n27_crowd", "hd_n81", "hd_n81_crowd", "hd_n243"])
 def test_f64_pipelined_rollout_kernel_free_runs_on_the_reference_trajectory(golden, name):
     """The PIPELINED rollout kernel (fg_rollout_kernels.hpp: producer / writer waves, double-buffered LDS tables, action prefetch,
     the rows writer) in the fp64 build: the fixture's whole horizon in ONE launch, free-running from the initial state, against
