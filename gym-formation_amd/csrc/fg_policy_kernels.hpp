@@ -119,9 +119,14 @@ FG_DEV float2 ez_policy(const float2* __restrict__ cR, const float2* __restrict_
 // The hierarchy for one env.  `tab` = this env's policy_block_units(N) float2 of LDS with R and S filled and
 // published; `lane` / `lanes`: this thread's index among the threads that share the env.  Every one of them must
 // call (the level loops synchronise).  Returns the N actions (LDS, published).
-template <int PER, class Sync>
+// LCT: the number of levels when the caller knows it at compile time (the pipelined rollout kernels: N = PER^LCT is a template
+// parameter) - the level loops unroll and the per-lane search for a problem's level becomes a select chain: closed loop 9 x 4096
+// 2.52 -> 2.01 us/step, 4 x 16384 2.39 -> 1.77, 8 x 65536 21.7 -> 18.4, 9 x 65536 29.8 -> 27.7 (profiles/r05_policy_ct_ab.txt);
+// 0: pl.L at run time (the stand-alone controller launches).  The operations and their order are the same.
+template <int PER, int LCT = 0, class Sync>
 FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPolicyLevels& pl, float2 iv,
                                     int lane, int lanes, Sync sync) {
+    const int L = LCT > 0 ? LCT : pl.L;
     float2* const R = tab;
     float2* const S = tab + N;
     float2* const SR = tab + 2 * N;
@@ -130,7 +135,7 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     const float2* srcR = R;
     const float2* srcS = S;
     int n_l = N, off = 0;
-    for (int l = 1; l < pl.L; ++l) {
+    for (int l = 1; l < L; ++l) {
         n_l /= PER;
         for (int j = lane; j < n_l; j += lanes) {
             float2 a = srcR[j * PER], b = srcS[j * PER];
@@ -149,9 +154,9 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     float2* const BA = tab + 4 * N;
     float* const BW = reinterpret_cast<float*>(tab + 6 * N);
     int P = 0;
-    for (int lev = pl.L, n = PER; lev >= 1; --lev, n *= PER) P += n;
+    for (int lev = L, n = PER; lev >= 1; --lev, n *= PER) P += n;
     for (int p = lane; p < P; p += lanes) {
-        int lev = pl.L, start = 0, n = PER, off_l = off - PER;   // level of problem p: its first index, its size,
+        int lev = L, start = 0, n = PER, off_l = off - PER;   // level of problem p: its first index, its size,
         while (p >= start + n) {                                  // where its child level starts in SR / SS
             start += n; n *= PER; off_l -= n; --lev;
         }
@@ -169,13 +174,13 @@ FG_DEV const float2* bfs_policy_env(float2* __restrict__ tab, int N, const FgPol
     sync();
     // ---- top-down: target velocity of a sub-group = (act + w * target velocity of its group) x level (:43-46, :78-79)
     int start = 0, n = PER, pstart = 0;
-    for (int lev = pl.L; lev >= 1; --lev) {
+    for (int lev = L; lev >= 1; --lev) {
         const float flev = (float)lev;
         for (int sg = lane; sg < n; sg += lanes) {
             // value select, never a pointer select (that puts `iv` into scratch memory); at the top level the entry read is
             // a valid one of this table whose value is not used
             const float2 up = BA[pstart + sg / PER];
-            const bool top = lev == pl.L;
+            const bool top = lev == L;
             const float2 tv = make_float2(top ? iv.x : up.x, top ? iv.y : up.y);
             float2 a = BA[start + sg];
             const float w = BW[start + sg];

@@ -166,7 +166,7 @@ void rollout_kernel(const Args a) {
             // its row 0 holds p_j - p_0, exactly this subtraction; QX / QY hold the current positions
             if (valid) { pol_tab[i] = make_real2(p.x - QX[0], p.y - QY[0]); pol_tab[N + i] = s; }
             WaveSync()();
-            const real2* res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, i, G, WaveSync());
+            const real2* res = bfs_policy_env<(PER > 0 ? PER : 3), policy_levels_ct<NC, (PER > 0 ? PER : 3)>()>(pol_tab, N, a.pl, iv, i, G, WaveSync());
             if (valid) {
                 u_act = res[i];
                 if (a.act_out) reinterpret_cast<real2*>(a.act_out)[((size_t)k * a.B + b) * N + i] = u_act;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(E * 64 + TW) void rollout_kernel_wide(const Args a)
                 if (valid(q)) { pol_tab[i] = make_real2(p[q].x - QX[0], p[q].y - QY[0]); pol_tab[N + i] = s[q]; }
             }
             WaveSync()();
-            pol_res = bfs_policy_env<(PER > 0 ? PER : 3)>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
+            pol_res = bfs_policy_env<(PER > 0 ? PER : 3), policy_levels_ct<NC, (PER > 0 ? PER : 3)>()>(pol_tab, N, a.pl, iv, lane, 64, WaveSync());
         }
         real2 u_cur[A];
         if constexpr (!POLICY) {
