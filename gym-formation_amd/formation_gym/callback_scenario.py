@@ -224,8 +224,6 @@ class CallbackScenario(BaseScenario):
         self._cache = out
 
     def step_batch(self, world, act, out, auto_reset=False, rng_offset=0):
-        if auto_reset:
-            raise NotImplementedError("device auto-reset needs a batched scenario; use FormationVecEnv(reset_mode='host')")
         if self._bodies:                          # the bodies behind the agents take no action (core.py:229-237: agents only)
             world.action_u.zero_()
             world.action_u[:, :self._num_real].copy_(act)
@@ -236,6 +234,20 @@ class CallbackScenario(BaseScenario):
         world.step_count.add_(1)
         self._step_host += 1
         self._callbacks(world, out)
+        if auto_reset:
+            # the vec-env worker's rule (env_wrappers.py:14-18) on the host, where this scenario's callbacks live: an env whose
+            # agents are all done restarts from its own stream and the RESET observation goes out with the finished step's
+            # reward / done (what FormationVecEnv's default reset mode asks of every scenario)
+            finished = self._step_host[:world.num_envs] >= int(world.world_length)
+            if finished.any():
+                keep = {k: out[k].clone() for k in ("reward", "indiv", "done") if out.get(k) is not None}
+                first = self.first_reward
+                self.reset_world(world, env_mask=finished)
+                self._callbacks(world, {"obs": out["obs"]}, rewards=False)
+                for k, v in keep.items():
+                    out[k].copy_(v)
+                self.first_reward = first
+                self._cache = None
 
     def observe_batch(self, world, out):
         self._callbacks(world, out, rewards=False)

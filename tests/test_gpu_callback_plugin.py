@@ -244,3 +244,31 @@ def test_rollout_interface_for_host_paced_envs():
         assert torch.equal(act, info["actions"][k])
         obs_a, r, d, i = a.step(act)
         assert torch.equal(obs_a, o_seq[k]) and torch.equal(r, r_seq[k]) and torch.equal(d, d_seq[k])
+
+
+def test_reference_style_plugin_under_the_default_vec_env_reset_mode():
+    """FormationVecEnv's default reset mode ('device': the env restarts inside the step) with a reference-style Scenario file: the
+    restart happens where that scenario's callbacks live, on the host, from each env's own stream - the same results as the 'host'
+    mode (reset between steps, env_wrappers.py:14-18)."""
+    import formation_gym
+    from formation_gym.vec_env import FormationVecEnv
+    N, B, T = 5, 4, 17
+    vs = []
+    for mode in ("device", "host"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            e = formation_gym.make_env(PLUGIN, False, N, num_envs=B, device="cuda:0", episode_length=6)
+        e.seed(11)
+        vs.append(FormationVecEnv(e, reset_mode=mode))
+    a, b = vs
+    assert torch.equal(a.reset(), b.reset())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(2)
+    ends = 0
+    for t in range(T):
+        act = torch.rand((B, N, 2), generator=gen, device="cuda") * 2 - 1
+        oa, ra, da, ia = a.step(act.clone())
+        ob, rb, db, ib = b.step(act.clone())
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), "step %d" % t
+        assert torch.equal(ia["individual_reward"], ib["individual_reward"])
+        ends += int(da.all(1).sum())
+    assert ends == 2 * B
