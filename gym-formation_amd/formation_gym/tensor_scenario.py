@@ -2,8 +2,8 @@
 
 The reference's plugin API (formation_gym/scenario.py:4-12; call sites environment.py:113-184) hands a scenario one agent
 of one world at a time: `observation(agent, world)`, `reward(agent, world)`, NumPy vectors in `entity.state`.  A file
-written that way still loads here (callback_scenario.py) but pays a device -> host copy and B x N Python calls per step, and
-it can neither restart episodes on the device nor run several steps per call.  A scenario that wants the whole batch on the
+written that way still loads here (callback_scenario.py) but pays a device -> host copy and B x N Python calls per step; its
+episode restarts and K-step calls run on the host, step by step.  A scenario that wants the whole batch on the
 GPU without writing a kernel derives from `TensorScenario` instead and states the same four things on tensors:
 
     class Scenario(TensorScenario):
