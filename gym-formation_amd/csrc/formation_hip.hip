@@ -430,6 +430,12 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
          "profiles/r03_wide/ab_27_small_batches_*.txt: 27 x 2048 8.0 -> 6.0-6.5 us/step, placed or not; the HBM-streaming form of the tile writer"},
         {0, 2048, R_CACHED, roll_fn<N27 && !POLICY, NC, 32, 256, 512, 8, WR, 0, false>(), "... and its plain form while the buffer stays in the Infinity Cache"},
         // (27 x 2560 and up are faster with 16 envs per workgroup)
+        // 25 and 32 agents into buffers beyond the Infinity Cache: the rows writer with four writer waves (their 5- and 8-row tiles
+        // are smaller than 27's 9-row ones, and the streaming form's pacing was tuned on those)
+        {4096, B_ANY, R_HBM | R_PLACED, roll_fn<!POLICY && !N27, NC, 32, 512, 256, 16, 0, 0>(),
+         "profiles/r05_25_32_ab.txt: placed buffers - 25 x 4096 x 20 10.71 -> 10.44 us/step, 25 x 8192 21.29 -> 20.23, 32 x 4096 15.50 -> 15.20"},
+        {4096, B_ANY, R_HBM, roll_fn<!POLICY && NC == 32, NC, 32, 512, 256, 16, 0, 0>(),
+         "profiles/r05_25_32_ab.txt: ordinary allocations - 32 x 4096 x 20 18.56 -> 18.00 us/step"},
         {0, B_ANY, R_HBM | R_PLACED, roll_fn<POLICY, NC, 32, 512, 512, 16, 0, PER>(),
          "profiles/r03_wide/ab_closed_loop_*: the closed-loop instantiation cannot hold 16 tiles beside its controller tables; it takes its "
          "8 writer waves with the rows writer - 11.7 vs 13.35 us/step"},
@@ -441,8 +447,10 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
          "profiles/r03_wide/ab_27_mid_batches.txt: ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (a "
          "workgroup's own store rate is the bound then): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072 12.5 -> 10.7 "
          "(27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4)"},
-        {0, 16383, R_HBM, roll_fn<!POLICY, NC, 32, 512, 256, 16, WR, 0, true>(),
-         "profiles/README.md (round 2): line ownership + paced stores for batches of a few workgroup generations whose buffer does not fit the Infinity Cache"},
+        {0, 16383, R_HBM, roll_fn<!POLICY && N27, NC, 32, 512, 256, 16, WR, 0, true>(),
+         "profiles/README.md (round 2): line ownership + paced stores for batches of a few workgroup generations whose buffer does not fit the "
+         "Infinity Cache; 27 agents only - profiles/r05_25_32_ab.txt: at 25 agents on an ordinary allocation this form ran 15.1 us/step (4096 "
+         "envs) and 30.8 (8192) where the plain tile writer below runs 11.5 and 23.5"},
         {0, 16383, R_HBM, roll_fn<POLICY && N27, NC, 32, 512, 256, 16, WR, PER, true>(), "as above, closed loop"},
         {0, B_ANY, 0, roll_fn<true, NC, 32, 512, 256, 16, WR, PER>(), "the default of this class (comment above)"},
     };
