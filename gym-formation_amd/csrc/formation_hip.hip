@@ -447,6 +447,9 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
          "profiles/r03_wide/ab_27_mid_batches.txt: ... and so does any buffer while fewer than ~200 of the 256 CUs have a workgroup (a "
          "workgroup's own store rate is the bound then): 27 x 2560 x 37 on an ordinary allocation 12.4 -> 8.1 us/step, 27 x 3072 12.5 -> 10.7 "
          "(27 x 3584 equal, 27 x 4000 12.8 vs 14.0 stays with 4)"},
+        {8192, B_ANY, R_HBM, roll_fn<!POLICY && N27, NC, 32, 512, 512, 16, WR, 0, true>(),
+         "profiles/r05_hint_audit.txt, r05_25_32_ab.txt: from 8192 envs the eight paced writer waves win on an ordinary allocation too - "
+         "27 x 8192 x 10 26.0-26.2 -> 25.2-25.5 us/step, 27 x 16384 49.6 -> 48.8-49.1 (27 x 4096 keeps four: 12.8 vs 13.1-13.2)"},
         {0, 16383, R_HBM, roll_fn<!POLICY && N27, NC, 32, 512, 256, 16, WR, 0, true>(),
          "profiles/README.md (round 2): line ownership + paced stores for batches of a few workgroup generations whose buffer does not fit the "
          "Infinity Cache; 27 agents only - profiles/r05_25_32_ab.txt: at 25 agents on an ordinary allocation this form ran 15.1 us/step (4096 "
