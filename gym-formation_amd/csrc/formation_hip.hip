@@ -436,9 +436,10 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
          "profiles/r05_25_32_ab.txt: placed buffers - 25 x 4096 x 20 10.71 -> 10.44 us/step, 25 x 8192 21.29 -> 20.23, 32 x 4096 15.50 -> 15.20"},
         {4096, B_ANY, R_HBM, roll_fn<!POLICY && NC == 32, NC, 32, 512, 256, 16, 0, 0>(),
          "profiles/r05_25_32_ab.txt: ordinary allocations - 32 x 4096 x 20 18.56 -> 18.00 us/step"},
-        {0, B_ANY, R_HBM | R_PLACED, roll_fn<POLICY, NC, 32, 512, 512, 16, 0, PER>(),
+        {0, B_ANY, R_HBM, roll_fn<POLICY, NC, 32, 512, 512, 16, 0, PER>(),
          "profiles/r03_wide/ab_closed_loop_*: the closed-loop instantiation cannot hold 16 tiles beside its controller tables; it takes its "
-         "8 writer waves with the rows writer - 11.7 vs 13.35 us/step"},
+         "8 writer waves with the rows writer - 11.7 vs 13.35 us/step on a placed buffer; profiles/r05_hint_audit.txt: on an ordinary "
+         "allocation as well (27 x 2560 x 32 13.05 -> 8.44, 27 x 8192 27.6 -> 26.0, 25 x 4096 12.8 -> 11.9; 27 x 4096 equal)"},
         {0, B_ANY, R_HBM | R_PLACED, roll_fn<!POLICY, NC, 32, 512, 512, 16, WR, 0, true>(),
          "profiles/r03_wide/ab_27_writers_*.txt: a buffer composed of chunks spread over the device's memory takes the stream of 8 paced writer "
          "waves - 27 x 4096 x 20 11.6-11.8 us/step against 12.9 with 4, 27 x 8192 23.3-23.5 against 25.9-26.4, 27 x 16384 47.6-48.4 against "

@@ -22,8 +22,13 @@ def rate(fn, byts):
         blocks.append(e0.elapsed_time(e1) / reps)
     return sorted(blocks)[2]
 print("# us/step: [placed buffer: hint 1 (as shipped) | hint 0]  [ordinary buffer: hint 0 (as shipped) | hint 1]")
-for N, B, K in ((27, 4096, 20), (27, 2560, 32), (27, 8192, 10), (27, 16384, 5), (25, 4096, 20), (32, 4096, 20), (64, 2048, 20), (81, 2048, 20),
-                (125, 1024, 16), (243, 2048, 4), (16, 8192, 24), (9, 4096, 128), (8, 4096, 160)):
+CLOSED = "--closed" in sys.argv           # the closed loop (env.rollout_policy) instead of the open loop
+PER = {27: 3, 25: 5, 32: 2, 9: 3, 16: 4, 8: 2, 64: 4, 81: 3}
+SHAPES = ((27, 4096, 20), (27, 2560, 32), (27, 8192, 10), (27, 16384, 5), (25, 4096, 20), (32, 4096, 20), (64, 2048, 20), (81, 2048, 20),
+          (125, 1024, 16), (243, 2048, 4), (16, 8192, 24), (9, 4096, 128), (8, 4096, 160))
+if CLOSED:
+    SHAPES = ((27, 4096, 20), (27, 8192, 10), (27, 2560, 32), (25, 4096, 20), (25, 8192, 10), (32, 4096, 20), (32, 8192, 10), (16, 8192, 24), (64, 2048, 20))
+for N, B, K in SHAPES:
     env = formation_gym.make_env("formation_hd_env", False, N, num_envs=B, device=dev)
     env.scenario.reset_device(env.world, rng_offset=1)
     env.auto_reset = True
@@ -32,11 +37,12 @@ for N, B, K in ((27, 4096, 20), (27, 2560, 32), (27, 8192, 10), (27, 16384, 5), 
     row = []
     for label, cand in (("placed", 8), ("ordinary", 1)):
         placement.is_placed = real_is_placed
-        out = env.alloc_rollout_buffers(K, candidates=cand)
+        out = env.alloc_rollout_buffers(K, candidates=cand, policy=CLOSED)
         for forced in ((1, 0) if label == "placed" else (0, 1)):
             placement.is_placed = (lambda address, v=forced: bool(v))
             env._roll_launchers.clear()
-            row.append("%.2f" % (rate(lambda: env.rollout(acts, out=out), real) / K * 1e3))
+            fn = (lambda: env.rollout_policy(K, PER[N], out=out)) if CLOSED else (lambda: env.rollout(acts, out=out))
+            row.append("%.2f" % (rate(fn, real) / K * 1e3))
         del out
     placement.is_placed = real_is_placed
     print("%d x %d x %d: placed [%s | %s]  ordinary [%s | %s]" % ((N, B, K) + tuple(row)), flush=True)
