@@ -320,6 +320,9 @@ enum : unsigned {
     R_HBM = 1u,          // the launch's observation buffer does not fit the 256 MiB Infinity Cache (> 400 MB)
     R_CACHED = 2u,       // ... it does
     R_PLACED = 4u,       // FgParams.obs_placed: the buffer was composed of chunks spread over the device's memory (fg_arena_*)
+    R_BEYOND_IC = 16u,   // ... it exceeds the Infinity Cache at all (> 260 MB): the late-round-5 geometry rules, which win from there on
+                         // (profiles/r05_hbm_threshold_ab.txt: 9 x 8192 x 20 = 318 MB 3.30 -> 3.21 us/step, 8 x 16384 x 10 5.01 -> 4.59;
+                         // at 100-150 MB they lose 3-4 %)
     R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), come in whole generations of 256 - or
                          // in at least six generations, where a ragged last one weighs little
 };
@@ -337,10 +340,12 @@ constexpr RollFn roll_fn() {
 }
 template <size_t R>
 static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t st) {
-    const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
+    const double obs_bytes = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0;
+    const bool hbm = obs_bytes > 400e6, beyond_ic = obs_bytes > 260e6;
     for (const RollRule& r : rules) {
         if (!r.fn || a.B < r.b_lo || a.B > r.b_hi) continue;
         if (((r.need & R_HBM) && !hbm) || ((r.need & R_CACHED) && hbm) || ((r.need & R_PLACED) && !a.p.obs_placed)) continue;
+        if ((r.need & R_BEYOND_IC) && !beyond_ic) continue;
         if ((r.need & R_FILL32) && ((a.B + 31) / 32) % 256 != 0 && (a.B + 31) / 32 < 6 * 256) continue;
         return r.fn(a, st);
     }
@@ -359,7 +364,7 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
          "profiles/r04_writers_ab.txt: one workgroup per CU into a buffer beyond the Infinity Cache, 16 envs and eight writer waves "
          "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it); profiles/r05_8x32_ab.txt: with the span form of "
          "the gather writer instead of LDS tiles 8 x 4096 x 160 1.152 -> 1.057 (0.74 -> 0.81 real), 8 x 4500 2.18 -> 1.98"},
-        {8192, 49152, R_HBM, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
+        {8192, 49152, R_BEYOND_IC, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
          "profiles/r05_8x32_ab.txt: 32 envs, 4 producer and 8 writer waves per workgroup - 8 x 8192 x 80 2.36 -> 2.22 us/step, 8 x 16384 "
          "4.74-4.97 -> 4.28-4.39, 8 x 24576 6.96 -> 6.48, 8 x 32768 8.99 -> 8.61, 8 x 49152 13.36 -> 13.10 (0.80 of 8 TB/s in real bytes); "
          "8 x 65536 stays with the small workgroups (17.6-17.8 vs 17.9-18.1)"},
@@ -400,11 +405,11 @@ static int launch_roll_16(const Args& a, hipStream_t st) {
          "profiles/r04_writers_ab.txt, r04_gather_geom.txt: 9 x 4096 x 128 2.42 -> 1.83 us/step (1.43 since: profiles/r05_9x4096_rollout.md)"},
         {2049, 4096, R_HBM, roll_fn<N9 && !OPEN, NC, 16, 256, 256, 16, WR, PER>(),
          "profiles/r04_writers_ab.txt: the closed loop's controller tables leave LDS for four writer waves"},
-        {8192, B_ANY, R_HBM | R_FILL32, roll_fn<N9 && OPEN, NC, 16, 512, 512, 32, WR, PER>(),
+        {8192, B_ANY, R_BEYOND_IC | R_FILL32, roll_fn<N9 && OPEN, NC, 16, 512, 512, 32, WR, PER>(),
          "profiles/r05_9x32_ab.txt: 32 envs, 8 producer and 8 writer waves per workgroup - 9 x 8192 x 64 2.97 -> 2.84 us/step, 9 x 16384 5.69 -> "
          "5.44, 9 x 32768 11.49 -> 11.10, 9 x 65536 23.9 -> 23.3 (0.76 -> 0.78-0.795 of 8 TB/s in real bytes); a batch that leaves the last "
          "generation half empty loses (9 x 12288: 4.42 -> 4.97)"},
-        {8192, 32768, R_HBM, roll_fn<NC == 16 && OPEN, NC, 16, 256, 512, 16, WR, PER>(),
+        {8192, 32768, R_BEYOND_IC, roll_fn<NC == 16 && OPEN, NC, 16, 256, 512, 16, WR, PER>(),
          "profiles/r05_16x_ab.txt: eight writer waves per 16 envs - 16 x 8192 x 24 8.61 -> 8.10 us/step, 16 x 16384 16.91 -> 16.03, 16 x 32768 "
          "33.8 -> 33.55 (0.77-0.79 -> 0.80-0.83 of 8 TB/s in real bytes); 16 x 65536 and the closed loop keep four (69.8 vs 73.7; 16.5 vs 17.25)"},
         {8192, B_ANY, 0, roll_fn<true, NC, 16, 256, 256, 16, WR, PER>(), "profiles/README.md (round 2 sweeps): store-bound, whole lines per workgroup"},
@@ -434,7 +439,7 @@ static int launch_roll_32(const Args& a, hipStream_t st) {
         // are smaller than 27's 9-row ones, and the streaming form's pacing was tuned on those)
         {4096, B_ANY, R_HBM | R_PLACED, roll_fn<!POLICY && !N27, NC, 32, 512, 256, 16, 0, 0>(),
          "profiles/r05_25_32_ab.txt: placed buffers - 25 x 4096 x 20 10.71 -> 10.44 us/step, 25 x 8192 21.29 -> 20.23, 32 x 4096 15.50 -> 15.20"},
-        {4096, B_ANY, R_HBM, roll_fn<!POLICY && NC == 32, NC, 32, 512, 256, 16, 0, 0>(),
+        {4096, B_ANY, R_BEYOND_IC, roll_fn<!POLICY && NC == 32, NC, 32, 512, 256, 16, 0, 0>(),
          "profiles/r05_25_32_ab.txt: ordinary allocations - 32 x 4096 x 20 18.56 -> 18.00 us/step"},
         {0, B_ANY, R_HBM, roll_fn<POLICY, NC, 32, 512, 512, 16, 0, PER>(),
          "profiles/r03_wide/ab_closed_loop_*: the closed-loop instantiation cannot hold 16 tiles beside its controller tables; it takes its "
@@ -499,10 +504,11 @@ static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
         // Infinity Cache (profiles/r05_lane_pw_ab.txt): open loop from 65536 envs with four (3 x 65536 3.02 -> 2.79 us/step, 0.73 ->
         // 0.79 of 8 TB/s in real bytes; 3 x 131072 6.13 -> 5.60, 4 x 131072 10.44 -> 9.61; 4 x 49152 would lose, 3.84 -> 4.47); the
         // closed loop from 98304 envs with two (3 x 98304 5.02 -> 4.28, 4 x 131072 10.18 -> 9.32; at 65536 one stays ahead, 2.70 vs 2.82)
-        const bool hbm = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0 > 400e6;
-        if (hbm && per == 0 && a.B >= 65536) {
-            if (a.N == 3) { *rc = launch_hd_lane<3, 0, 4>(a, st); return true; }
-            if (a.N == 4) { *rc = launch_hd_lane<4, 0, 4>(a, st); return true; }
+        const double obs_bytes = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0;
+        const bool hbm = obs_bytes > 400e6;
+        if (per == 0 && a.B >= 65536) {                 // (3 agents from 260 MB: 3 x 65536 x 20 = 283 MB 3.32 -> 3.06 us/step; 4 agents at 251 MB lose)
+            if (a.N == 3 && obs_bytes > 260e6) { *rc = launch_hd_lane<3, 0, 4>(a, st); return true; }
+            if (a.N == 4 && hbm) { *rc = launch_hd_lane<4, 0, 4>(a, st); return true; }
         }
         if (hbm && per > 0 && a.B >= 98304) {
             if (a.N == 3 && per == 3) { *rc = launch_hd_lane<3, 3, 2>(a, st); return true; }
@@ -577,10 +583,10 @@ static int check_params(const FgParams* p) {
 //   basic 3 x 65536 3.04 -> 2.83 us/step (0.72 -> 0.77 of 8 TB/s, all bytes), 3 x 131072 6.26 -> 5.67 (0.70 -> 0.77);
 //   partial 5 x 131072 12.85 -> 12.51, range 4 x 131072 10.20 -> 9.33 (equal or slower at 65536: 6.44 / 6.40, 4.60 / 4.80);
 //   obstacle never (5.47 / 5.65, 11.25 / 11.24); half-filled generations lose everywhere (32768 envs: 1.70 -> 2.40).
-// Measured on rollouts whose observation buffer does not fit the Infinity Cache (> 400 MB, as for the formation_hd_env rules): only those.
+// Measured on rollouts whose observation buffer does not fit the Infinity Cache (> 260 MB: R_BEYOND_IC of the formation_hd_env rules): only those.
 template <int KIND> static bool scn_lane_wide(int B, double obs_bytes) {
     const int wgs = (B + 255) / 256;
-    if (obs_bytes <= 400e6 || (wgs % 256 != 0 && wgs < 6 * 256)) return false;
+    if (obs_bytes <= 260e6 || (wgs % 256 != 0 && wgs < 6 * 256)) return false;
     return KIND == FG_SCN_BASIC ? B >= 65536 : (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 131072;
 }
 template <int KIND, int NN, int LL, int MM, int NBR, int PW>
