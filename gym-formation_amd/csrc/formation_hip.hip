@@ -323,8 +323,8 @@ enum : unsigned {
     R_BEYOND_IC = 16u,   // ... it exceeds the Infinity Cache at all (> 260 MB): the late-round-5 geometry rules, which win from there on
                          // (profiles/r05_hbm_threshold_ab.txt: 9 x 8192 x 20 = 318 MB 3.30 -> 3.21 us/step, 8 x 16384 x 10 5.01 -> 4.59;
                          // at 100-150 MB they lose 3-4 %)
-    R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), come in whole generations of 256 - or
-                         // in at least six generations, where a ragged last one weighs little
+    R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), fill their generations of 256 well enough
+                         // (run_roll_rules)
 };
 struct RollRule {
     int b_lo, b_hi;      // batch sizes the rule covers (inclusive)
@@ -346,7 +346,13 @@ static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t
         if (!r.fn || a.B < r.b_lo || a.B > r.b_hi) continue;
         if (((r.need & R_HBM) && !hbm) || ((r.need & R_CACHED) && hbm) || ((r.need & R_PLACED) && !a.p.obs_placed)) continue;
         if ((r.need & R_BEYOND_IC) && !beyond_ic) continue;
-        if ((r.need & R_FILL32) && ((a.B + 31) / 32) % 256 != 0 && (a.B + 31) / 32 < 6 * 256) continue;
+        if (r.need & R_FILL32) {
+            // generations of 256 workgroups (one 1024-thread workgroup per CU): whole ones, a last one at least three quarters full,
+            // from the third on at least half full, or six and more - profiles/r05_fill_rule_ab.txt: 1.00 +8 %, 1.12 -10 %, 1.25 -7 %,
+            // 1.50 -2 %, 1.75 +12 %, 2.25 -3 %, 2.50 +1 %, 3.50 +2.5 %, 3.75 +9 %, 4.50 +3 %, 5.50 +3.5 %, 6.00 +7 %
+            const int wgs = (a.B + 31) / 32, full = wgs / 256, rest = wgs % 256;
+            if (!(rest == 0 || rest >= 192 || (full >= 2 && rest >= 128) || full >= 6)) continue;
+        }
         return r.fn(a, st);
     }
     return fail(FG_ERR_UNSUPPORTED_N, "no rollout rule for this shape%s");       // (unreachable: every table ends with a catch-all)

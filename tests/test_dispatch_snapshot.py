@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SNAPSHOT = os.path.join(ROOT, "tests", "golden", "dispatch.json")
 
 AGENTS = [3, 4, 8, 9, 10, 16, 25, 27, 32, 64, 81, 100, 125, 243, 300]
-BATCHES = [64, 256, 512, 1024, 2048, 2560, 3072, 4096, 5000, 8192, 16384, 32768, 65536]
+BATCHES = [64, 256, 512, 1024, 2048, 2560, 3072, 4096, 5000, 8192, 10240, 14336, 16384, 32768, 65536]
 STEPS = [0, 2, 20, 128]                                   # 0 = fg_step_hd, else fg_rollout_hd with K steps
 PER = {3: 3, 4: 2, 8: 2, 9: 3, 16: 4, 25: 5, 27: 3, 32: 2, 64: 4, 81: 3, 125: 5, 243: 3}
 

@@ -770,7 +770,7 @@ def test_arena_mappings_get_fresh_addresses_and_chunks_keep_their_contents():
                                                  # and a padded env pitch (the per-env form)
                                                  # (9 x 8192 and up into a buffer beyond the Infinity Cache: 32-env workgroups;
                                                  # 49169 envs: a ragged last workgroup among 1537)
-                                                 (9, 8192, 60, 2, False), (9, 8192, 26, 1, True), (9, 49169, 6, 1, False),
+                                                 (9, 8192, 60, 2, False), (9, 8192, 26, 1, True), (9, 49169, 6, 1, False), (9, 14350, 12, 1, False),
                                                  # 8 / 16 agents beyond the Infinity Cache: 32-env workgroups / eight writer waves
                                                  (8, 8200, 70, 1, False), (8, 16384, 40, 2, False), (16, 8200, 17, 1, False)])
 def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every, pad):
