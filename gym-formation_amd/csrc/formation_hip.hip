@@ -325,6 +325,8 @@ enum : unsigned {
                          // at 100-150 MB they lose 3-4 %)
     R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), fill their generations of 256 well enough
                          // (run_roll_rules)
+    R_FILL32B = 32u,     // the same for the 512- / 768-thread 32-env workgroups of 8 agents (two per CU): not a first or second generation
+                         // with a last round less than half full (profiles/r05_fill_rule_ab.txt)
 };
 struct RollRule {
     int b_lo, b_hi;      // batch sizes the rule covers (inclusive)
@@ -346,6 +348,10 @@ static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t
         if (!r.fn || a.B < r.b_lo || a.B > r.b_hi) continue;
         if (((r.need & R_HBM) && !hbm) || ((r.need & R_CACHED) && hbm) || ((r.need & R_PLACED) && !a.p.obs_placed)) continue;
         if ((r.need & R_BEYOND_IC) && !beyond_ic) continue;
+        if (r.need & R_FILL32B) {
+            const int wgs = (a.B + 31) / 32, full = wgs / 256, rest = wgs % 256;
+            if (!(rest == 0 || rest >= 128 || full >= 3)) continue;
+        }
         if (r.need & R_FILL32) {
             // generations of 256 workgroups (one 1024-thread workgroup per CU): whole ones, a last one at least three quarters full,
             // from the third on at least half full, or six and more - profiles/r05_fill_rule_ab.txt: 1.00 +8 %, 1.12 -10 %, 1.25 -7 %,
@@ -370,15 +376,15 @@ static int launch_roll_8(const Args& a, hipStream_t st) {
          "profiles/r04_writers_ab.txt: one workgroup per CU into a buffer beyond the Infinity Cache, 16 envs and eight writer waves "
          "per workgroup - 8 x 4096 x 120 1.69 -> 1.36 us/step (the writer waves bound it); profiles/r05_8x32_ab.txt: with the span form of "
          "the gather writer instead of LDS tiles 8 x 4096 x 160 1.152 -> 1.057 (0.74 -> 0.81 real), 8 x 4500 2.18 -> 1.98"},
-        {8192, 49152, R_BEYOND_IC, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
+        {8192, 49152, R_BEYOND_IC | R_FILL32B, roll_fn<N8 && OPEN, NC, G, 256, 512, 32, FG_WR_GATHER, PER>(),
          "profiles/r05_8x32_ab.txt: 32 envs, 4 producer and 8 writer waves per workgroup - 8 x 8192 x 80 2.36 -> 2.22 us/step, 8 x 16384 "
          "4.74-4.97 -> 4.28-4.39, 8 x 24576 6.96 -> 6.48, 8 x 32768 8.99 -> 8.61, 8 x 49152 13.36 -> 13.10 (0.80 of 8 TB/s in real bytes); "
          "8 x 65536 stays with the small workgroups (17.6-17.8 vs 17.9-18.1)"},
-        {12288, B_ANY, 0, roll_fn<N8 && PER == 2, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
+        {12288, B_ANY, R_FILL32B, roll_fn<N8 && PER == 2, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
          "profiles/r05_8x32_ab.txt: closed loop, 32 envs, 4 + 4 waves per workgroup - 8 x 12288 6.18 -> 3.90 us/step, 8 x 16384 6.88 -> 4.65, "
          "8 x 24576 9.54 -> 7.39, 8 x 32768 10.64 -> 9.42, 8 x 65536 20.1-20.4 -> 18.95-19.4 (0.50-0.69 -> 0.72-0.74 real); 8 x 8192 keeps the "
          "small workgroups (2.92 vs 3.03)"},
-        {12288, 49152, 0, roll_fn<N8 && PER == 8, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
+        {12288, 49152, R_FILL32B, roll_fn<N8 && PER == 8, NC, G, 256, 256, 32, FG_WR_GATHER, PER>(),
          "profiles/r05_8x32_ab.txt: the one-level 8-ary controller - 8 x 16384 9.93 -> 6.52 us/step, 8 x 24576 13.49 -> 9.87, 8 x 32768 14.65 -> "
          "13.28, 8 x 49152 21.25 -> 20.35; equal at 65536 (27.9 vs 28.2)"},
         {32768, B_ANY, 0, roll_fn<N8 && PER == 8, NC, G, 64, 64, E, FG_WR_GATHER, PER>(),

@@ -772,7 +772,7 @@ def test_arena_mappings_get_fresh_addresses_and_chunks_keep_their_contents():
                                                  # 49169 envs: a ragged last workgroup among 1537)
                                                  (9, 8192, 60, 2, False), (9, 8192, 26, 1, True), (9, 49169, 6, 1, False), (9, 14350, 12, 1, False),
                                                  # 8 / 16 agents beyond the Infinity Cache: 32-env workgroups / eight writer waves
-                                                 (8, 8200, 70, 1, False), (8, 16384, 40, 2, False), (16, 8200, 17, 1, False)])
+                                                 (8, 12300, 50, 1, False), (8, 16384, 40, 2, False), (16, 8200, 17, 1, False)])
 def test_placed_rollout_buffers_with_obs_every_and_env_pitch(N, B, K, obs_every, pad):
     """alloc_rollout_buffers with every obs_every-th observation kept and / or env blocks padded to whole 128-byte lines
     (FgParams.obs_env_pitch): the placed, strided buffer takes the same bits as K step calls."""
