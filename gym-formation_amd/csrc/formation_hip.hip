@@ -505,6 +505,13 @@ static int launch_hd_lane(const Args& a, hipStream_t st) {
     if (err != hipSuccess) return fail(FG_ERR_HIP, "rollout launch failed: %s", hipGetErrorString(err));
     return FG_OK;
 }
+// One-env-per-lane kernels with four producer waves (256-env workgroups): how full the generations of 256 such workgroups (one per CU) must be - profiles/r05_fill_rule_ab.txt, eleven batch sizes per kernel:
+// whole generations or a last one at least three quarters full (a single one: seven eighths: 57344 envs +12 %, 49152 -11 %); `half`:
+// a last generation at least half full is enough (basic and formation_hd_env at 3 agents: 98304 envs +5 ... +8 %).
+static bool lane_wide_fill(int B, bool half) {
+    const int wgs = (B + 255) / 256, full = wgs / 256, rest = wgs % 256;
+    return rest == 0 || (full >= 1 && rest >= (half ? 128 : 192)) || (full == 0 && rest >= 224) || full >= 6;
+}
 // from 32768 envs (512 workgroups of 64 envs: two per CU) the one-env-per-lane kernel wins - 3 x 65536 6.3 -> 3.4 us/step, 4 x 65536
 // 9.2 -> 5.0; below, the lane-per-agent kernel spreads a batch over more waves (3 x 16384: 1.62 vs 1.89): profiles/r04_hd_lane_ab.txt
 constexpr int FG_HD_LANE_MIN_B = 32768;
@@ -518,9 +525,9 @@ static bool launch_pipelined(const Args& a, int per, hipStream_t st, int* rc) {
         // closed loop from 98304 envs with two (3 x 98304 5.02 -> 4.28, 4 x 131072 10.18 -> 9.32; at 65536 one stays ahead, 2.70 vs 2.82)
         const double obs_bytes = (double)(a.K / a.obs_every) * a.B * (double)a.obs_pitch * 8.0;
         const bool hbm = obs_bytes > 400e6;
-        if (per == 0 && a.B >= 65536) {                 // (3 agents from 260 MB: 3 x 65536 x 20 = 283 MB 3.32 -> 3.06 us/step; 4 agents at 251 MB lose)
-            if (a.N == 3 && obs_bytes > 260e6) { *rc = launch_hd_lane<3, 0, 4>(a, st); return true; }
-            if (a.N == 4 && hbm) { *rc = launch_hd_lane<4, 0, 4>(a, st); return true; }
+        if (per == 0) {                                 // (3 agents from 260 MB: 3 x 65536 x 20 = 283 MB 3.32 -> 3.06 us/step; 4 agents at 251 MB lose)
+            if (a.N == 3 && obs_bytes > 260e6 && lane_wide_fill(a.B, true)) { *rc = launch_hd_lane<3, 0, 4>(a, st); return true; }
+            if (a.N == 4 && hbm && lane_wide_fill(a.B, false)) { *rc = launch_hd_lane<4, 0, 4>(a, st); return true; }
         }
         if (hbm && per > 0 && a.B >= 98304) {
             if (a.N == 3 && per == 3) { *rc = launch_hd_lane<3, 3, 2>(a, st); return true; }
@@ -597,9 +604,9 @@ static int check_params(const FgParams* p) {
 //   obstacle never (5.47 / 5.65, 11.25 / 11.24); half-filled generations lose everywhere (32768 envs: 1.70 -> 2.40).
 // Measured on rollouts whose observation buffer does not fit the Infinity Cache (> 260 MB: R_BEYOND_IC of the formation_hd_env rules): only those.
 template <int KIND> static bool scn_lane_wide(int B, double obs_bytes) {
-    const int wgs = (B + 255) / 256;
-    if (obs_bytes <= 260e6 || (wgs % 256 != 0 && wgs < 6 * 256)) return false;
-    return KIND == FG_SCN_BASIC ? B >= 65536 : (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 131072;
+    if (obs_bytes <= 260e6) return false;
+    if (KIND == FG_SCN_BASIC) return lane_wide_fill(B, true);
+    return (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 114688 && lane_wide_fill(B, false);
 }
 template <int KIND, int NN, int LL, int MM, int NBR, int PW>
 static int launch_scn_lane(const ScnArgs& a, hipStream_t st) {

@@ -62,7 +62,7 @@ def _snapshot(env):
 
 @pytest.mark.parametrize("N,B,K", [(27, 4096, 20), (9, 4096, 20), (81, 2048, 20), (243, 8192, 4),
                                     (9, 5003, 7), (9, 8200, 6), (9, 32768, 4), (27, 16384, 3), (27, 4099, 7), (27, 4099, 3),
-                                    (3, 66001, 3), (3, 66001, 30), (4, 65636, 18),   # (the last two: four producer waves per workgroup)
+                                    (3, 66001, 3), (3, 98400, 20), (4, 114700, 10),   # (the last two: four producer waves per workgroup, a ragged last one)
                                     # agent counts of the other hierarchies (per_layer 2, 4, 5, 8): compile-time-N single steps with
                                     # the rows writer, pipelined rollouts in every batch-size class of launch_roll_* / launch_wide
                                     (4, 5000, 4), (8, 3000, 5), (8, 5000, 4), (16, 8192, 8), (16, 4100, 5), (16, 700, 6), (25, 4096, 20), (25, 600, 5),
