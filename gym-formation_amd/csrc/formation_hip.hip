@@ -606,7 +606,10 @@ static int check_params(const FgParams* p) {
 template <int KIND> static bool scn_lane_wide(int B, double obs_bytes) {
     if (obs_bytes <= 260e6) return false;
     if (KIND == FG_SCN_BASIC) return lane_wide_fill(B, true);
-    return (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 114688 && lane_wide_fill(B, false);
+    // partial / range: whole generations from the second on only - on boxes whose placed buffers run fast the 256-env form loses 1-5 % at
+    // 57344 / 65536 / 114688 envs (it wins 7-13 % there on slow compositions and ordinary allocations), at 131072 it wins on both
+    const int wgs = (B + 255) / 256;
+    return (KIND == FG_SCN_PARTIAL || KIND == FG_SCN_RANGE) && B >= 131072 && (wgs % 256 == 0 || wgs >= 6 * 256);
 }
 template <int KIND, int NN, int LL, int MM, int NBR, int PW>
 static int launch_scn_lane(const ScnArgs& a, hipStream_t st) {
