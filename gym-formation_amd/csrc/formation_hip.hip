@@ -354,10 +354,11 @@ static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t
         }
         if (r.need & R_FILL32) {
             // generations of 256 workgroups (one 1024-thread workgroup per CU): whole ones, a last one at least three quarters full,
-            // from the third on at least half full, or six and more - profiles/r05_fill_rule_ab.txt: 1.00 +8 %, 1.12 -10 %, 1.25 -7 %,
-            // 1.50 -2 %, 1.75 +12 %, 2.25 -3 %, 2.50 +1 %, 3.50 +2.5 %, 3.75 +9 %, 4.50 +3 %, 5.50 +3.5 %, 6.00 +7 %
+            // or six and more - profiles/r05_fill_rule_ab.txt: 1.00 +8 %, 1.12 -10 %, 1.25 -7 %, 1.50 -2 %, 1.75 +12 % (placed: +7 %),
+            // 2.25 -3 %, 3.75 +9 % (placed: +2 %), 6.00 +7 %; half-full last generations (2.50 +1 %, 3.50 +2.5 %, 4.50 +3 % on ordinary
+            // allocations) lose on placed buffers (3.50: -6.5 % on two boxes) and are left out
             const int wgs = (a.B + 31) / 32, full = wgs / 256, rest = wgs % 256;
-            if (!(rest == 0 || rest >= 192 || (full >= 2 && rest >= 128) || full >= 6)) continue;
+            if (!(rest == 0 || rest >= 192 || full >= 6)) continue;
         }
         return r.fn(a, st);
     }
