@@ -325,8 +325,8 @@ enum : unsigned {
                          // at 100-150 MB they lose 3-4 %)
     R_FILL32 = 8u,       // workgroups of 32 envs, one per CU at a time (1024 threads), fill their generations of 256 well enough
                          // (run_roll_rules)
-    R_FILL32B = 32u,     // the same for the 512- / 768-thread 32-env workgroups of 8 agents (two per CU): not a first or second generation
-                         // with a last round less than half full (profiles/r05_fill_rule_ab.txt)
+    R_FILL32B = 32u,     // the same for the 512- / 768-thread 32-env workgroups of 8 agents: whole generations of 256, a last one at least
+                         // half full, or six and more (profiles/r05_fill_rule_ab.txt: 1.12 / 1.25 / 2.25 generations lose 0-11 %)
 };
 struct RollRule {
     int b_lo, b_hi;      // batch sizes the rule covers (inclusive)
@@ -350,7 +350,7 @@ static int run_roll_rules(const RollRule (&rules)[R], const Args& a, hipStream_t
         if ((r.need & R_BEYOND_IC) && !beyond_ic) continue;
         if (r.need & R_FILL32B) {
             const int wgs = (a.B + 31) / 32, full = wgs / 256, rest = wgs % 256;
-            if (!(rest == 0 || rest >= 128 || full >= 3)) continue;
+            if (!(rest == 0 || rest >= 128 || full >= 6)) continue;
         }
         if (r.need & R_FILL32) {
             // generations of 256 workgroups (one 1024-thread workgroup per CU): whole ones, a last one at least three quarters full,
