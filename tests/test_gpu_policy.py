@@ -157,7 +157,7 @@ def test_policy_closed_loop_reduces_formation_error_and_tracks_reference(golden)
                                         (3, 32800, 4, 3), (4, 32768, 4, 2), (4, 33000, 3, 4),   # one env per lane, controller on registers
                                         (3, 98400, 20, 3), (4, 98354, 12, 2),                   # ... two producer waves per workgroup
                                         (8, 5000, 3, 8), (8, 65600, 2, 8),                       # 8 agents: gather writer, two / one writer waves
-                                        (8, 32810, 3, 2), (8, 12300, 3, 8),                      # ... and 32-env workgroups from 12288 envs
+                                        (8, 36870, 3, 2), (8, 12300, 3, 8),                      # ... and 32-env workgroups from 12288 envs
                                         (36, 6, 3, 6)])          # 6^2: no pipelined instantiation - chained launches
 def test_closed_loop_rollout_equals_policy_plus_step_calls(N, B, K, per):
     """env.rollout_policy(K) - the controller inside the pipelined rollout kernels (N = per^L up to 243 agents for per 2, 3,
